@@ -1,0 +1,319 @@
+"""oracle.ops -- TEST INFRASTRUCTURE ONLY: numpy restatement of the reference's host-side glue.
+
+The reference runs these steps in numpy on the host (one thread); they are restated here in the
+dtype the 2018-era numpy would have used (fp32 throughout, python scalars weak). Each function
+cites the reference file:line. Tie orders that the reference leaves to numpy/torch sort internals
+are pinned as in SURVEY.md Appendix A3:
+  (i)   ``x.argsort()[::-1]``            == stable ascending sort, reversed (equal keys: higher index first)
+  (ii)  pre-NMS top-k                    == (score desc, anchor index asc)
+  (iii) ``torch.sort(-scores)``          == stable (score desc, concatenation index asc)
+"""
+import numpy as np
+
+from . import (mask_removal_core, nms_sorted, panoptic_fuse, roi_align_forward, seg_term_core)
+
+F32 = np.float32
+BBOX_XFORM_CLIP = F32(np.log(1000.0 / 16.0))  # bbox_transform.py:312 (fp32 after value-based cast)
+
+
+def exp_f32(x):
+    """np.exp on fp32 restated as the correctly-rounded fp32 exp (through double)."""
+    return np.exp(np.asarray(x, np.float32).astype(np.float64)).astype(np.float32)
+
+
+def log2_f32(x):
+    return np.log2(np.asarray(x, np.float32).astype(np.float64)).astype(np.float32)
+
+
+def argsort_desc(x):
+    """Rule (i): ``x.argsort()[::-1]`` with a stable sort (gpu_nms.pyx:33, mask_removal.py:50)."""
+    return np.argsort(np.asarray(x), kind="stable")[::-1]
+
+
+# ------------------------------------------------------------------ anchors (generate_anchors.py)
+def _whctrs(a):
+    w = a[2] - a[0] + 1
+    h = a[3] - a[1] + 1
+    return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)  # generate_anchors.py:156-165
+
+
+def _mkanchors(ws, hs, xc, yc):
+    ws, hs = ws[:, None], hs[:, None]  # :168-180
+    return np.hstack((xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)))
+
+
+def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1, 2)):
+    """generate_anchors.py:50-76, 183-206 (float64; np.round is round-half-even)."""
+    scales = np.array(sizes, dtype=np.float64) / stride
+    ratios = np.array(aspect_ratios, dtype=np.float64)
+    base = np.array([1, 1, stride, stride], dtype=np.float64) - 1
+    w, h, xc, yc = _whctrs(base)
+    size_ratios = (w * h) / ratios
+    ws = np.round(np.sqrt(size_ratios))
+    hs = np.round(ws * ratios)
+    ratio_anchors = _mkanchors(ws, hs, xc, yc)
+    out = []
+    for i in range(ratio_anchors.shape[0]):
+        w, h, xc, yc = _whctrs(ratio_anchors[i])
+        out.append(_mkanchors(w * scales, h * scales, xc, yc))
+    return np.vstack(out)
+
+
+# ------------------------------------------------------------------ boxes (bbox_transform.py)
+def bbox_transform(boxes, deltas, weights=(1.0, 1.0, 1.0, 1.0)):
+    """bbox_transform.py:290-330, everything in fp32 (the dtype of ``deltas``)."""
+    deltas = np.asarray(deltas, F32)
+    if boxes.shape[0] == 0:
+        return np.zeros((0, deltas.shape[1]), dtype=F32)
+    boxes = np.asarray(boxes).astype(F32)
+    widths = boxes[:, 2] - boxes[:, 0] + F32(1.0)
+    heights = boxes[:, 3] - boxes[:, 1] + F32(1.0)
+    ctr_x = boxes[:, 0] + F32(0.5) * widths
+    ctr_y = boxes[:, 1] + F32(0.5) * heights
+    wx, wy, ww, wh = [F32(w) for w in weights]
+    dx = deltas[:, 0::4] / wx
+    dy = deltas[:, 1::4] / wy
+    dw = np.minimum(deltas[:, 2::4] / ww, BBOX_XFORM_CLIP)
+    dh = np.minimum(deltas[:, 3::4] / wh, BBOX_XFORM_CLIP)
+    pcx = dx * widths[:, None] + ctr_x[:, None]
+    pcy = dy * heights[:, None] + ctr_y[:, None]
+    pw = exp_f32(dw) * widths[:, None]
+    ph = exp_f32(dh) * heights[:, None]
+    out = np.zeros(deltas.shape, dtype=F32)
+    out[:, 0::4] = pcx - F32(0.5) * pw
+    out[:, 1::4] = pcy - F32(0.5) * ph
+    out[:, 2::4] = pcx + F32(0.5) * pw - F32(1)
+    out[:, 3::4] = pcy + F32(0.5) * ph - F32(1)
+    return out
+
+
+def clip_boxes(boxes, im_shape):
+    """bbox_transform.py:45-60 (im_shape = unpadded (H, W))."""
+    h1, w1 = F32(im_shape[0]) - F32(1), F32(im_shape[1]) - F32(1)
+    boxes = boxes.copy()
+    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], w1), 0)
+    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], h1), 0)
+    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], w1), 0)
+    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], h1), 0)
+    return boxes
+
+
+# ------------------------------------------------------------------ NMS
+def gpu_nms(dets, thresh):
+    """gpu_nms.pyx:23-38: returns indices into the unsorted dets, in visiting order."""
+    dets = np.asarray(dets, F32)
+    if dets.shape[0] == 0:
+        return np.zeros((0,), np.int64)
+    order = argsort_desc(dets[:, 4])
+    keep = nms_sorted(dets[order], thresh)
+    return order[keep]
+
+
+def py_nms(dets, thresh):
+    """nms.py:48-85 restated (suppress ``ovr > thresh``); used to cross-check ``gpu_nms``."""
+    dets = np.asarray(dets, F32)
+    if dets.shape[0] == 0:
+        return np.zeros((0,), np.int64)
+    x1, y1, x2, y2 = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3]
+    areas = (x2 - x1 + F32(1)) * (y2 - y1 + F32(1))
+    order = argsort_desc(dets[:, 4])
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(i)
+        r = order[1:]
+        w = np.maximum(F32(0), np.minimum(x2[i], x2[r]) - np.maximum(x1[i], x1[r]) + F32(1))
+        h = np.maximum(F32(0), np.minimum(y2[i], y2[r]) - np.maximum(y1[i], y1[r]) + F32(1))
+        inter = w * h
+        ovr = inter / (areas[i] + areas[r] - inter)
+        order = r[np.where(ovr <= thresh)[0]]
+    return np.array(keep, np.int64)
+
+
+# ------------------------------------------------------------------ proposals
+def pyramid_proposal(cls_probs, bbox_preds, im_info, feat_stride=(4, 8, 16, 32, 64), scales=(8,),
+                     ratios=(0.5, 1, 2), pre_nms_top_n=1000, post_nms_top_n=1000, nms_thresh=0.7,
+                     min_size=0, return_levels=False):
+    """functions/pyramid_proposal.py:62-222 (individual_proposals=True) + modules/pyramid_proposal.py:61-67.
+
+    cls_probs[l] [1,A,H,W], bbox_preds[l] [1,4A,H,W] numpy fp32; im_info [3] = (H, W, scale).
+    Returns rois [K,5] fp32 (col 0 = 0) and scores [K].
+    """
+    im_info = np.asarray(im_info, F32).reshape(-1)
+    prop_l, score_l = [], []
+    for s, stride in enumerate(feat_stride):
+        stride = int(stride)
+        sub_anchors = generate_anchors(stride=stride, sizes=np.array(scales) * stride, aspect_ratios=ratios)
+        scores = np.asarray(cls_probs[s], F32)
+        deltas = np.asarray(bbox_preds[s], F32)
+        height, width = scores.shape[-2:]
+        shift_x, shift_y = np.meshgrid(np.arange(0, width) * stride, np.arange(0, height) * stride)
+        shifts = np.vstack((shift_x.ravel(), shift_y.ravel(), shift_x.ravel(), shift_y.ravel())).transpose()
+        A, K = sub_anchors.shape[0], shifts.shape[0]
+        anchors = (sub_anchors.reshape((1, A, 4)) + shifts.reshape((1, K, 4)).transpose((1, 0, 2))).reshape((K * A, 4))
+        deltas = deltas.transpose((0, 2, 3, 1)).reshape((-1, 4))
+        scores = scores.transpose((0, 2, 3, 1)).reshape((-1,))
+        # :121-130 top-k, pinned as rule (ii): (score desc, anchor index asc)
+        order = np.argsort(-scores, kind="stable")
+        if 0 < pre_nms_top_n < len(scores):
+            order = order[:pre_nms_top_n]
+        deltas, anchors, scores = deltas[order], anchors[order], scores[order]
+        proposals = clip_boxes(bbox_transform(anchors, deltas), im_info[:2])
+        ws = proposals[:, 2] - proposals[:, 0] + F32(1)
+        hs = proposals[:, 3] - proposals[:, 1] + F32(1)
+        ms = F32(min_size) * im_info[2]
+        keep = np.where((ws >= ms) & (hs >= ms))[0]
+        proposals, scores = proposals[keep], scores[keep]
+        keep = gpu_nms(np.hstack((proposals, scores[:, None])).astype(F32), nms_thresh)
+        if post_nms_top_n > 0:
+            keep = keep[:post_nms_top_n]
+        prop_l.append(proposals[keep])
+        score_l.append(scores[keep])
+    proposals = np.vstack(prop_l)
+    scores = np.concatenate(score_l)
+    blob = np.hstack((np.zeros((proposals.shape[0], 1), F32), proposals.astype(F32)))
+    idx = np.argsort(-scores, kind="stable")[:post_nms_top_n]  # rule (iii)
+    if return_levels:
+        return blob[idx], scores[idx], [p.shape[0] for p in prop_l]
+    return blob[idx], scores[idx]
+
+
+# ------------------------------------------------------------------ FPN ROIAlign
+def fpn_level(rois):
+    """fpn_roi_align.py:36-38, fp32 (log2 through double)."""
+    rois = np.asarray(rois, F32)
+    w = rois[:, 3] - rois[:, 1] + F32(1)
+    h = rois[:, 4] - rois[:, 2] + F32(1)
+    x = np.sqrt(w * h) / F32(224) + F32(1e-6)
+    return np.clip(np.floor(F32(2) + log2_f32(x)), 0, 3).astype(np.int64)
+
+
+def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale=(1 / 4., 1 / 8., 1 / 16., 1 / 32.)):
+    """fpn_roi_align.py:32-62 restated literally (dummy ROI for empty levels, argsort inverse perm)."""
+    rois = np.asarray(rois, F32)
+    feat_id = fpn_level(rois)
+    feat_no, rois_fpn = [], []
+    for i in range(4):
+        idx = np.where(feat_id == i)[0]
+        if len(idx) == 0:
+            rois_fpn.append(np.zeros((1, 5), F32))
+            feat_no.append(np.array([-1]))
+        else:
+            rois_fpn.append(rois[idx])
+            feat_no.append(idx)
+    rois_index = np.argsort(np.hstack(feat_no), kind="stable")[-rois.shape[0]:]
+    pooled = [roi_align_forward(feats[i], rois_fpn[i], pooled_h, pooled_w, spatial_scale[i]) for i in range(4)]
+    return np.concatenate(pooled, 0)[rois_index]
+
+
+# ------------------------------------------------------------------ detection selection
+def mask_roi(rois, bbox_delta, cls_prob, im_info, num_classes, nms_thresh=0.5, score_thresh=0.05,
+             max_det=100, class_agnostic=False, bbox_reg_weights=(10., 10., 5., 5.)):
+    """modules/mask_roi.py:36-146 -> (scores [n], boxes [n,5], cls_idx [n] int64)."""
+    rois, bbox_delta, cls_prob = np.asarray(rois, F32), np.asarray(bbox_delta, F32), np.asarray(cls_prob, F32)
+    im_info = np.asarray(im_info, F32).reshape(-1, 3)
+    proposal = clip_boxes(bbox_transform(rois[:, 1:], bbox_delta, bbox_reg_weights), im_info[0, :2])
+    N = proposal.shape[0]
+    cls_idx = [np.full((N,), j, np.int64) for j in range(num_classes)]
+    nms_classes = num_classes
+    if class_agnostic:  # :59-76
+        p = cls_prob[:, 1:].reshape((-1, 1))
+        cls_prob = np.hstack((np.zeros_like(p), p))
+        pr = proposal.reshape((N, -1, 4))[:, 1:, :].reshape((-1, 4))
+        proposal = np.hstack((np.zeros_like(pr), pr))
+        ci = np.array(cls_idx).T[:, 1:].reshape((1, -1))
+        cls_idx = [np.zeros_like(ci[0]), ci[0]]
+        nms_classes = 2
+    cls_boxes = [np.zeros((0, 5), F32) for _ in range(nms_classes)]
+    for j in range(1, nms_classes):  # :87-101
+        inds = np.where(cls_prob[:, j] > F32(score_thresh))[0]
+        dets_j = np.hstack((proposal[inds, j * 4:(j + 1) * 4], cls_prob[inds, j][:, None])).astype(F32)
+        keep = gpu_nms(dets_j, nms_thresh) if len(dets_j) else np.zeros((0,), np.int64)
+        cls_boxes[j] = dets_j[keep, :]
+        cls_idx[j] = cls_idx[j][inds][keep]
+    if max_det > 0:  # :104-119
+        image_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, nms_classes)])
+        if len(image_scores) > max_det:
+            image_thresh = np.sort(image_scores)[-max_det]
+            for j in range(1, nms_classes):
+                keep = np.where(cls_boxes[j][:, -1] >= image_thresh)[0]
+                cls_boxes[j] = cls_boxes[j][keep, :]
+                cls_idx[j] = cls_idx[j][keep]
+    im_results = np.vstack([cls_boxes[j] for j in range(1, nms_classes)])
+    if im_results.shape[0] == 0:  # :135-141 dummy
+        return np.ones((1,), F32), np.zeros((1, 5), F32), np.zeros((1,), np.int64)
+    boxes = np.zeros((im_results.shape[0], 5), F32)
+    boxes[:, 1:] = im_results[:, :4]
+    return im_results[:, 4].copy(), boxes, np.hstack(cls_idx[1:]).astype(np.int64)
+
+
+# ------------------------------------------------------------------ panoptic head
+def mask_removal(mask_rois, cls_prob, mask_logit, cls_idx, im_shape, fraction_threshold=0.3,
+                 want_energy=True):
+    """modules/mask_removal.py:29-93 -> (keep_inds int64 [k], mask_energy [1,k,H,W] or None)."""
+    H, W = int(im_shape[0]), int(im_shape[1])
+    cls_idx = np.asarray(cls_idx, np.int64).reshape(-1)
+    cls_prob = np.asarray(cls_prob, F32).reshape(-1)
+    if len(cls_idx) == 1 and cls_idx[0] == 0:  # :55-57 dummy detection
+        return np.array([0], np.int64), (np.zeros((1, 1, H, W), F32) if want_energy else None)
+    order = argsort_desc(cls_prob)
+    mask_logit = np.asarray(mask_logit, F32).reshape(len(cls_idx), -1)
+    ms = int(round(np.sqrt(mask_logit.shape[1])))
+    keep, energy = mask_removal_core(np.asarray(mask_rois, F32), mask_logit.reshape(-1, ms, ms), cls_idx, order,
+                                     H, W, int(np.max(cls_idx)), fraction_threshold, want_energy)
+    if len(keep) == 0:  # :90-92
+        return np.array([0], np.int64), (np.zeros((1, 1, H, W), F32) if want_energy else None)
+    return keep, (energy[None] if want_energy else None)
+
+
+def class_mapping(num_seg_classes, num_classes):
+    """unary_logits.py:73: thing class c -> semantic channel."""
+    m = np.zeros((num_classes,), np.int64)
+    for c, ch in zip(range(1, num_classes), range(num_seg_classes - num_classes + 1, num_seg_classes)):
+        m[c] = ch
+    return m
+
+
+def seg_term(cls_indices, seg_score, boxes, num_seg_classes, num_classes, box_scale=0.25):
+    """unary_logits.py:78-105: seg_score [1,S,H,W]; boxes [k,5] (already x4) -> (seg [1,S_stuff,H,W], seg_inst [1,k,H,W])."""
+    seg_score = np.asarray(seg_score, F32)
+    cls_indices = np.asarray(cls_indices, np.int64).reshape(-1)
+    n_inst = num_classes - 1
+    seg = seg_score[[0], :-n_inst]
+    b = np.asarray(boxes, F32)[:, 1:] * F32(box_scale)
+    inst = seg_term_core(seg_score[0], b, cls_indices, class_mapping(num_seg_classes, num_classes))
+    return seg, inst[None]
+
+
+def panoptic_head(fcn_output, mask_rois, cls_prob, mask_logit, cls_idx, num_seg_classes, num_classes,
+                  enable_void=True):
+    """resnet_upsnet.py:223-243 composed: returns dict(keep_inds, panoptic, sem, k)."""
+    fcn_output = np.asarray(fcn_output, F32)
+    H, W = fcn_output.shape[2:]
+    keep, energy = mask_removal(np.asarray(mask_rois, F32)[:, 1:], cls_prob, mask_logit, cls_idx, (H, W))
+    mr = np.asarray(mask_rois, F32)[keep]
+    ci = np.asarray(cls_idx, np.int64)[keep]
+    seg, inst = seg_term(ci, fcn_output, mr * F32(4.0), num_seg_classes, num_classes)
+    s_stuff = num_seg_classes - (num_classes - 1)
+    pan, sem = panoptic_fuse(fcn_output[0], s_stuff, inst[0], energy[0], enable_void)
+    return dict(keep_inds=keep, panoptic=pan, sem=sem, cls_idx=ci, k=len(keep))
+
+
+def panoptic_fuse_numpy(fcn_output, seg_inst, mask_energy, s_stuff, enable_void=True):
+    """Literal tensor-level restatement of resnet_upsnet.py:234-243 (materialises every plane)."""
+    fcn_output, seg_inst, mask_energy = [np.asarray(a, F32) for a in (fcn_output, seg_inst, mask_energy)]
+    seg = fcn_output[:s_stuff]
+    inst = seg_inst + mask_energy
+    if enable_void:
+        void = fcn_output[s_stuff:].max(0, keepdims=True) - seg_inst.max(0, keepdims=True)
+        logits = np.concatenate([seg, inst, void], 0)
+        out = np.argmax(logits, 0).astype(np.int64)
+        out[out == logits.shape[0] - 1] = 255
+        return out
+    logits = np.concatenate([seg, inst], 0)
+    m = logits.max(0, keepdims=True)
+    e = exp_f32(logits - m)
+    s = np.zeros_like(e[0])
+    for c in range(e.shape[0]):
+        s = s + e[c]
+    return np.argmax(e / s, 0).astype(np.int64)
