@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""bench.py -- whole-job throughput of the UPSNet per-image inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of UPSNet-50 (Cityscapes config) over one synthetic 1x3x1024x2048 image per
+rank, inputs resident in HBM, followed by a device sync (the reference's net_time window,
+upsnet_end2end_test.py:244-252). Rank 0 prints ONE JSON line. `value` = images of all ranks / wall time
+(max over ranks, barrier + synchronize bracketed, includes the final RCCL gather of the label maps).
+
+Extra objects: "roofline" for the dominant hand-written kernel (the fused deformable convolution,
+timed live with events on the launch stream inside the timed region) and "cpu_baseline" (the CPU oracle's
+composite forward timed on the host cores of the same box, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the same guide)
+
+
+def dcn_algorithmic(levels_hw, layers):
+    """fused DCN bytes = 4*HW*(Cin + 2*kh*kw*dg + Cout) + 4*Cout*Cin*kh*kw,
+    flops = 2*Cout*Cin*kh*kw*HW, per launch (= one layer over all FPN levels)."""
+    hw = sum(h * w for h, w in levels_hw)
+    out = []
+    for cin, cout in layers:
+        out.append((4.0 * hw * (cin + 18 + cout) + 4.0 * cout * cin * 9, 2.0 * cout * cin * 9 * hw))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='upsnet50_cityscapes_1024x2048')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-scale', type=float, default=0.5,
+                    help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
+    args = ap.parse_args()
+
+    from upsnet_amd import ops
+    from upsnet_amd.upsnet_end2end_test import upsnet_test
+
+    ops.PROFILE['enabled'] = True
+    ops.PROFILE['events'] = []
+    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup)
+    ops.PROFILE['enabled'] = False
+    rank, world = res['rank'], res['world']
+    if rank != 0:
+        return
+    torch.cuda.synchronize()
+    n_images = args.steps * world
+    value = n_images / res['elapsed']
+    net = sorted(res['net_times'])
+    p50_ms = 1000.0 * net[len(net) // 2]
+
+    # ---- roofline of the dominant hand-written kernel (fused DCN), from events inside the timed region
+    ev = ops.PROFILE['events'][-2 * args.steps:] if args.steps else []
+    dcn_ms = [s.elapsed_time(e) for (name, s, e) in ev if name == 'dcn_fused']
+    H, W = res['H'], res['W']
+    ph, pw = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    levels = [(ph // s, pw // s) for s in (4, 8, 16, 32)]
+    from upsnet_amd.config.config import config
+    layers = [(256, 128), (128, 128)] if config.network.fcn_num_layers == 2 else [(256, 256), (256, 128), (128, 128)]
+    alg = dcn_algorithmic(levels, layers)
+    roofline = None
+    if dcn_ms:
+        launches = len(dcn_ms)
+        avg_s = sum(dcn_ms) / launches / 1000.0
+        flops_per_launch = sum(a[1] for a in alg) / len(alg)
+        bytes_per_launch = sum(a[0] for a in alg) / len(alg)
+        achieved = flops_per_launch / avg_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_dcn_pmc.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roofline = {'kernel': 'dcn_fused_nhwc_kernel', 'bound': 'mfma', 'achieved': round(achieved, 3),
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'traffic': traffic, 'avg_launch_ms': round(avg_s * 1000, 4), 'launches_timed': launches,
+                    'algorithmic_flops_per_launch': flops_per_launch, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                    'hbm_equiv_GBs': round(bytes_per_launch / avg_s / 1e9, 1),
+                    'hbm_equiv_frac': round(bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, 4)}
+
+    # ---- CPU baseline: the oracle's composite forward on the host cores (bounded sample)
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.forward import cpu_copy, forward_cpu
+        from upsnet_amd.synthetic import make_image
+        cores = os.cpu_count()
+        torch.set_num_threads(cores)
+        sc = args.cpu_baseline_scale
+        h, w = int(H * sc) // 32 * 32, int(W * sc) // 32 * 32
+        m_cpu = cpu_copy(res['model'])
+        img = make_image(h, w, seed=0, device='cpu')
+        stages = {}
+        t0 = time.perf_counter()
+        out_cpu = forward_cpu(m_cpu, img, stages)
+        dt = time.perf_counter() - t0
+        # scale the sample's time to a full-size image by pixel count (all heavy stages are O(pixels))
+        full = dt * (H * W) / float(h * w)
+        cpu_baseline = {'value': round(1.0 / full, 5), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+                        'sample': '1 image %dx%d (%.2fx linear scale of the workload) in %.1f s, extrapolated by pixel count; '
+                                  'torch-CPU convs on %d threads + single-thread C oracle ops' % (h, w, sc, dt, cores),
+                        'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
+                        'n_inst': out_cpu['n_inst']}
+
+    last = res['last_out']
+    line = {
+        'metric': 'images/sec (whole node), UPSNet-50 1024x2048', 'value': round(value, 4), 'unit': 'images/sec',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
+        'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
+                   'backbone': 'PyTorch-ROCm (MIOpen) fp32, channels_last, frozen BN folded',
+                   'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, panoptic fusion',
+                   'parallelism': 'one image per rank, final RCCL all_gather',
+                   'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
+        'roofline': roofline, 'cpu_baseline': cpu_baseline,
+    }
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == '__main__':
+    main()

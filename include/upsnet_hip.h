@@ -1,0 +1,199 @@
+/*
+ * upsnet_hip.h -- C ABI of libupsnet_hip.so: the MI355X (gfx950 / CDNA4) replacement for the native
+ * operators on UPSNet's per-image inference hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream; NULL = default stream);
+ *   - the caller allocates every output and every workspace (the reference does the same:
+ *     functions/deform_conv.py:44-45, functions/roialign.py:37); the library never allocates
+ *     device memory, except upsnet_nms_host (the `_nms` drop-in, which the reference also lets malloc);
+ *   - functions return 0 on success, non-zero on error; upsnet_last_error() then describes it
+ *     (the reference returned 1/0 and printed, SURVEY.md section 8b "Errors");
+ *   - layouts: "nchw" entry points take the reference's contiguous NCHW tensors and are drop-in
+ *     replacements for the reference natives; "nhwc" entry points are the MI355X-native fast path
+ *     (channels-last physical layout so that a bilinear tap is one contiguous C-vector).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root, uber-research/UPSNet).
+ */
+#ifndef UPSNET_HIP_H
+#define UPSNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Last error message of the calling thread ("" if none). */
+const char *upsnet_last_error(void);
+/* Library ABI version (bumped on any signature change). */
+int upsnet_abi_version(void);
+
+/* ============================== ROIAlign ============================== */
+
+/* Replaces roi_align_forward_gpu_kernel_launcher (upsnet/operators/src/roi_align_cuda.cpp:26-30,
+ * bound to Python as roi_align_cuda.roi_align_forward, roi_align_cuda.cpp:39-75,114-118).
+ * bottom_data [B,C,H,W] NCHW, bottom_rois [N,5] = (batch,x1,y1,x2,y2), top_data [N,C,PH,PW]. */
+int upsnet_roi_align_forward(void *stream, const float *bottom_data, float spatial_scale, int num_rois,
+                             int height, int width, int channels, int pooled_height, int pooled_width,
+                             int sampling_ratio, const float *bottom_rois, float *top_data);
+
+/* Same op on channels-last features: feat [B,H,W,C], out [N,PH,PW,C]. C % 4 == 0. */
+int upsnet_roi_align_forward_nhwc(void *stream, const float *feat_nhwc, int batch, int height, int width,
+                                  int channels, float spatial_scale, const float *rois, int num_rois,
+                                  int pooled_height, int pooled_width, int sampling_ratio, float *out_nhwc);
+
+/* Replaces FPNRoIAlign.forward (upsnet/operators/modules/fpn_roi_align.py:32-62): level assignment
+ * floor(2+log2(sqrt(wh)/224+1e-6)) on device, all four levels in one launch, output in the
+ * original ROI order. feat_nhwc[l] is [H_l,W_l,C]; out_nhwc [N,PH,PW,C]; levels_out (optional) [N].
+ * num_rois_dev (optional): device int32 with the number of valid rois (<= num_rois); rows beyond it
+ * are written as zeros. The pointer arrays themselves are HOST arrays of 4 entries. */
+int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
+                                 const int feat_w[4], const float spatial_scale[4], int channels,
+                                 const float *rois, int num_rois, const int *num_rois_dev, int pooled_height,
+                                 int pooled_width, int sampling_ratio, float *out_nhwc, int *levels_out);
+
+/* ============================== Deformable convolution ============================== */
+
+/* Replaces deformable_im2col_gpu_kernel_launcher (upsnet/operators/src/deform_conv_cuda.cpp:25-30,
+ * bound as deform_conv_cuda.deform_im2col, deform_conv_cuda.cpp:49-68). NCHW, parallel_imgs images.
+ * data_col is [C*kh*kw, parallel_imgs, Ho, Wo]. */
+int upsnet_deform_im2col(void *stream, const float *data_im, const float *data_offset, int channels,
+                         int height, int width, int ksize_h, int ksize_w, int pad_h, int pad_w, int stride_h,
+                         int stride_w, int dilation_h, int dilation_w, int parallel_imgs, int deformable_group,
+                         float *data_col);
+
+/* Replaces modulated_deformable_im2col_gpu_kernel_launcher
+ * (upsnet/operators/src/mod_deform_conv_cuda.cpp:24-31, bound as mod_deform_im2col :51-74). */
+int upsnet_mod_deform_im2col(void *stream, const float *data_im, const float *data_offset,
+                             const float *data_mask, int batch_size, int channels, int height_im, int width_im,
+                             int height_col, int width_col, int kernel_h, int kernel_w, int pad_h, int pad_w,
+                             int stride_h, int stride_w, int dilation_h, int dilation_w, int deformable_group,
+                             float *data_col);
+
+/* Fused deformable convolution forward (v1 when mask == NULL, v2 otherwise), the MI355X-native
+ * replacement for DeformConvFunction.forward's im2col + torch.mm (functions/deform_conv.py:43-57)
+ * with no column buffer: bilinear sampling into LDS tiles feeding fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Up to 4 feature maps that share the same weights (the FCN head's four FPN levels) go in ONE launch.
+ *   x[l]      [H_l, W_l, Cin]  NHWC
+ *   offset[l] [Ho_l, Wo_l, dg*2*kh*kw] NHWC (channel order as the reference: 2*(i*kw+j) = dh, +1 = dw)
+ *   mask[l]   [Ho_l, Wo_l, dg*kh*kw]  NHWC or NULL array
+ *   wpack     [kh*kw*Cin, Cout_pad] (tap-major, channel-minor rows; see upsnet_deform_conv_pack_weight)
+ *   bias      [Cout] or NULL;  out[l] [Ho_l, Wo_l, Cout] NHWC;  relu != 0 fuses max(.,0).
+ * Pointer/shape arrays are HOST arrays of nlev entries. Cin % 32 == 0, Cout % 32 == 0, Cout <= 256. */
+int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                    const float *const mask[], float *const out[], const int height[],
+                                    const int width[], int cin, int cout, int kh, int kw, int pad_h, int pad_w,
+                                    int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
+                                    const float *wpack, const float *bias, int relu);
+
+/* weight [Cout, Cin, kh, kw] (reference layout, modules/deform_conv.py:43-44) -> wpack [kh*kw*Cin, Cout]. */
+int upsnet_deform_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw,
+                                   float *wpack);
+
+/* ============================== NMS ============================== */
+
+/* Drop-in for `_nms` (upsnet/nms/gpu_nms.hpp:15, nms_kernel.cu:97-150): HOST pointers in and out,
+ * boxes already sorted by descending score, keep_out = indices into the sorted array. */
+int upsnet_nms_host(int *keep_out_host, int *num_out_host, const float *boxes_host, int boxes_num,
+                    int boxes_dim, float nms_overlap_thresh, int device_id);
+
+/* Batched device-resident hard NMS: P independent problems in one set of launches, no host round trip.
+ * Replaces gpu_nms (upsnet/nms/gpu_nms.pyx:23-38) including its score sort: visiting order is
+ * (score desc, index desc), the pinned meaning of scores.argsort()[::-1].
+ *   boxes [P,nmax,4], scores [P,nmax], counts [P] (device int32, counts[p] <= nmax <= 8192)
+ *   pre_removed (optional) [P,nmax] uint8: boxes dropped before NMS (min-size filter)
+ *   keep_idx [P,nmax] int32 out (original indices, visiting order), keep_cnt [P] int32 out
+ *   workspace: upsnet_nms_workspace_bytes(P, nmax) bytes. */
+size_t upsnet_nms_workspace_bytes(int num_problems, int nmax);
+int upsnet_nms_batched(void *stream, const float *boxes, const float *scores, const int *counts,
+                       const uint8_t *pre_removed, int num_problems, int nmax, float thresh, int *keep_idx,
+                       int *keep_cnt, void *workspace);
+
+/* Device soft-NMS, bit-compatible with cpu_soft_nms (upsnet/nms/cpu_nms.pyx:91-196) on the returned
+ * prefix: boxes [n,5] modified in place (rows >= *n_out unspecified), inds [n] int64 out (original
+ * index of each surviving row), n_out device int32. workspace: upsnet_soft_nms_workspace_bytes(n).
+ * method: 0 hard, 1 linear, 2 gaussian. */
+size_t upsnet_soft_nms_workspace_bytes(int n);
+int upsnet_soft_nms(void *stream, float *boxes, int64_t *inds, int n, float sigma, float Nt, float threshold,
+                    int method, int *n_out, void *workspace);
+
+/* ============================== RPN proposals ============================== */
+
+/* Replaces PyramidProposalFunction.forward + PyramidProposal.forward
+ * (upsnet/operators/functions/pyramid_proposal.py:62-222, modules/pyramid_proposal.py:61-67) with
+ * individual_proposals=True, entirely on device.
+ *   cls_prob[l] [A,H_l,W_l] NCHW (A anchors), bbox_pred[l] [4A,H_l,W_l] NCHW  (HOST arrays of pointers)
+ *   anchors_host [nlev*A*4] base anchors (generate_anchors), strides_host [nlev]
+ *   im_info (device) [3] = (H, W, scale)
+ *   rois_out [post_nms_top_n,5], scores_out [post_nms_top_n], num_out device int32
+ *   workspace: upsnet_proposal_workspace_bytes(...) bytes. */
+size_t upsnet_proposal_workspace_bytes(int nlev, const int *heights_host, const int *widths_host, int num_anchors,
+                                       int pre_nms_top_n, int post_nms_top_n);
+int upsnet_pyramid_proposals(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                             const int *heights_host, const int *widths_host, const int *strides_host,
+                             const float *anchors_host, int num_anchors, const float *im_info, int pre_nms_top_n,
+                             int post_nms_top_n, float nms_thresh, float min_size, float *rois_out,
+                             float *scores_out, int *num_out, void *workspace);
+
+/* ============================== Detection selection (MaskROI) ============================== */
+
+/* Replaces MaskROI.forward (upsnet/operators/modules/mask_roi.py:36-146): decode + clip, per-class (or
+ * class-agnostic) score threshold, NMS, global top-max_det; dummy ROI when nothing survives.
+ *   rois [N,5], bbox_delta [N,4*C], cls_prob [N,C], num_rois_dev optional device count
+ *   boxes_out [cap,5], scores_out [cap], cls_out [cap] int64, src_out [cap] int32 (ROI row of each det),
+ *   num_out device int32; cap = upsnet_mask_roi_capacity(N, C, class_agnostic). */
+int upsnet_mask_roi_capacity(int num_rois, int num_classes, int class_agnostic);
+size_t upsnet_mask_roi_workspace_bytes(int num_rois, int num_classes, int class_agnostic);
+int upsnet_mask_roi(void *stream, const float *rois, const float *bbox_delta, const float *cls_prob, int num_rois,
+                    const int *num_rois_dev, int num_classes, const float *im_info, int class_agnostic,
+                    float score_thresh, float nms_thresh, int max_det, const float reg_weights_host[4],
+                    float *boxes_out, float *scores_out, int64_t *cls_out, int *src_out, int *num_out,
+                    void *workspace);
+
+/* ============================== Panoptic head ============================== */
+
+/* Replaces MaskRemoval.forward's selection (upsnet/operators/modules/mask_removal.py:50-93):
+ *   mask_rois [m,4], cls_prob [m], mask_logit [m,ms,ms], cls_idx [m] int64 (1-based; 0 = dummy)
+ *   keep_inds [m] int64 out (visiting order), num_keep device int32 (>=1: the reference's [0] fallback)
+ *   real_keep device int32: 0 when the fallback fired (then the single mask plane is all zeros). */
+size_t upsnet_mask_removal_workspace_bytes(int m, int num_thing_classes, int height, int width);
+int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_prob, const float *mask_logit,
+                        const int64_t *cls_idx, int m, int mask_size, int num_thing_classes, int height, int width,
+                        double fraction_threshold, int64_t *keep_inds, int *num_keep, int *real_keep,
+                        void *workspace);
+
+/* Materialise MaskRemoval's mask_energy [k,H,W] (mask_removal.py:86) for the kept instances. */
+int upsnet_mask_paste(void *stream, const float *mask_rois, const float *mask_logit, const int64_t *keep_inds,
+                      const int *num_keep, const int *real_keep, int kmax, int mask_size, int height, int width,
+                      float *mask_energy);
+
+/* Materialise SegTerm's seg_inst_energy [k,H,W] (upsnet/operators/modules/unary_logits.py:95-103).
+ * boxes [k,4] image coords (already scaled), cls [k] int64, class_map [num_classes] int64. */
+int upsnet_seg_term(void *stream, const float *fcn_output, int num_seg, int height, int width, const float *boxes,
+                    const int64_t *cls, const int64_t *class_map, int k, float *seg_inst);
+
+/* Fused parameter-free panoptic head (upsnet/models/resnet_upsnet.py:223-243 + SegTerm + mask paste):
+ * one pass over fcn_output, nothing materialised.
+ *   fcn_output [S,H,W] planar; mask_rois [m,5] (col 0 = batch), mask_logit [m,ms,ms], cls_idx [m] int64,
+ *   keep_inds/num_keep/real_keep from upsnet_mask_removal; class_map [num_classes] int64
+ *   pan_out [H,W] int64, sem_out [H,W] int64 or NULL (argmax over S, resnet_upsnet.py:213). */
+int upsnet_panoptic_fuse(void *stream, const float *fcn_output, int num_seg, int height, int width, int num_stuff,
+                         const float *mask_rois, const float *mask_logit, const int64_t *cls_idx,
+                         const int64_t *keep_inds, const int *num_keep, const int *real_keep, int kmax,
+                         int mask_size, const int64_t *class_map, int enable_void, int64_t *pan_out,
+                         int64_t *sem_out);
+
+/* Reference-shaped fusion on materialised planes (resnet_upsnet.py:234-243):
+ * seg_inst, mask_energy [k,H,W]. */
+int upsnet_panoptic_argmax(void *stream, const float *fcn_output, int num_seg, int height, int width, int num_stuff,
+                           const float *seg_inst, const float *mask_energy, int k, int enable_void,
+                           int64_t *pan_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPSNET_HIP_H */

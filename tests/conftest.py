@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+# ---------------------------------------------------------------- shared synthetic generators
+def gen_rois(rng, n, im_h=1024, im_w=2048, smin=16, smax=512):
+    size = np.exp(rng.uniform(np.log(smin), np.log(smax), n))
+    ar = np.exp(rng.uniform(np.log(0.5), np.log(2.0), n))
+    w, h = size * np.sqrt(ar), size / np.sqrt(ar)
+    cx, cy = rng.uniform(0, im_w, n), rng.uniform(0, im_h, n)
+    b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, im_w - 1)
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, im_h - 1)
+    return np.hstack([np.zeros((n, 1)), b]).astype(np.float32)
+
+
+def gen_dets(rng, n, im_h=1024, im_w=2048, ties=True, cluster=True):
+    r = gen_rois(rng, n, im_h, im_w)[:, 1:]
+    if cluster and n > 8:  # jittered copies so that NMS actually suppresses
+        src = rng.integers(0, n, n // 2)
+        r[n // 2:n // 2 + len(src)] = r[src] + rng.normal(0, 4, (len(src), 4)).astype(np.float32)
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    if ties and n > 4:
+        k = max(1, n // 20)
+        s[rng.integers(0, n, k)] = s[rng.integers(0, n, 1)]
+        s[rng.integers(0, n, k)] = np.float32(1.0)  # saturated scores
+    return np.hstack([r, s[:, None]]).astype(np.float32)

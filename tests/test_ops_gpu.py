@@ -1,0 +1,309 @@
+"""GPU parity tests: every HIP op called through the C ABI vs the CPU oracle on the same seeded inputs.
+Bit-exact (==) for index / integer / sampled-value outputs; 1e-4 for GEMM-accumulated logits."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ops as oops
+from conftest import gen_dets, gen_rois
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def U():
+    from upsnet_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------ ROIAlign
+@pytest.mark.parametrize("C,H,W,ph,scale", [(8, 20, 30, 7, 0.25), (16, 64, 128, 14, 0.125), (4, 5, 7, 7, 1.0 / 32)])
+def test_roi_align_nchw_bitexact(U, C, H, W, ph, scale):
+    rng = np.random.default_rng(0)
+    feat = rng.normal(size=(1, C, H, W)).astype(np.float32)
+    rois = gen_rois(rng, 50, int(H / scale), int(W / scale), 4, max(8, int(H / scale)))
+    rois = np.vstack([rois, [[0, 0, 0, 0, 0]], [[0, -20, -20, -5, -5]], [[0, W / scale + 50, 3, W / scale + 90, 9]],
+                      [[0, 10, 10, 5, 5]]]).astype(np.float32)  # degenerate / outside / inverted
+    ref = oracle.roi_align_forward(feat, rois, ph, ph, scale)
+    out = U.roi_align_nchw(cu(feat), cu(rois), ph, ph, scale).cpu().numpy()
+    assert np.array_equal(out, ref)
+    out2 = U.roi_align_nhwc(cu(feat).contiguous(memory_format=torch.channels_last), cu(rois), ph, ph, scale)
+    assert np.array_equal(out2.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("N,ph", [(300, 7), (64, 14), (1, 7)])
+def test_fpn_roi_align_bitexact(U, N, ph):
+    rng = np.random.default_rng(1)
+    H, W, C = 128, 256, 32
+    feats = [rng.normal(size=(1, C, H // s, W // s)).astype(np.float32) for s in (4, 8, 16, 32)]
+    rois = gen_rois(rng, N, H, W, 4, 200)
+    # force boundary cases of the level formula: sqrt(wh)/224 + 1e-6 == 0.5 / 1 / 2
+    for i, side in enumerate([112, 224, 448]):
+        if i < N:
+            rois[i] = [0, 0, 0, side - 1, side - 1]
+    ref = oops.fpn_roi_align(feats, rois, ph, ph)
+    out, lv = U.fpn_roi_align([cu(f) for f in feats], cu(rois), ph, ph, [1 / 4., 1 / 8., 1 / 16., 1 / 32.], return_levels=True)
+    assert np.array_equal(lv.cpu().numpy(), oops.fpn_level(rois))
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_fpn_roi_align_padded_tail(U):
+    rng = np.random.default_rng(2)
+    feats = [rng.normal(size=(1, 8, 64 // s, 64 // s)).astype(np.float32) for s in (4, 8, 16, 32)]
+    rois = gen_rois(rng, 10, 64, 64, 4, 60)
+    nd = torch.tensor([6], dtype=torch.int32).cuda()
+    out = U.fpn_roi_align([cu(f) for f in feats], cu(rois), 7, 7, [1 / 4., 1 / 8., 1 / 16., 1 / 32.], num_rois_dev=nd).cpu().numpy()
+    assert np.array_equal(out[:6], oops.fpn_roi_align(feats, rois[:6], 7, 7))
+    assert not out[6:].any()
+
+
+# ------------------------------------------------------------------ deformable conv
+@pytest.mark.parametrize("C,H,W,k,pad,stride,dil,dg", [(8, 12, 17, 3, 1, 1, 1, 1), (12, 9, 9, 3, 2, 1, 2, 2), (4, 16, 16, 3, 1, 2, 1, 1)])
+def test_deform_im2col_bitexact(U, C, H, W, k, pad, stride, dil, dg):
+    rng = np.random.default_rng(3)
+    im = rng.normal(size=(C, H, W)).astype(np.float32)
+    Ho, Wo = U.out_hw(H, W, (k, k), (pad, pad), (stride, stride), (dil, dil))
+    off = (rng.normal(size=(dg * 2 * k * k, Ho, Wo)) * 2).astype(np.float32)
+    off[:, 0, 0] = 0.0
+    off[0, 1, 1] = -1.0 - pad  # lands exactly on the -1 border
+    mask = rng.uniform(0, 2, size=(dg * k * k, Ho, Wo)).astype(np.float32)
+    ref = oracle.deform_im2col(im, off, (k, k), (pad, pad), (stride, stride), (dil, dil), dg)
+    col = torch.zeros((C * k * k, Ho, Wo), device='cuda')
+    U.deform_im2col(cu(im), cu(off), (1, C, H, W), tuple(col.shape), (k, k), (pad, pad), (stride, stride), (dil, dil), 1, dg, col)
+    assert np.array_equal(col.cpu().numpy(), ref)
+    ref2 = oracle.deform_im2col(im, off, (k, k), (pad, pad), (stride, stride), (dil, dil), dg, mask=mask)
+    col.zero_()
+    U.mod_deform_im2col(cu(im), cu(off), cu(mask), (1, C, H, W), tuple(col.shape), (k, k), (pad, pad), (stride, stride), (dil, dil), dg, col)
+    assert np.array_equal(col.cpu().numpy(), ref2)
+
+
+def _dcn_ref(x, off, w, b, k, pad, stride, dil, mask=None, relu=False):
+    col = oracle.deform_im2col(x, off, (k, k), (pad, pad), (stride, stride), (dil, dil), 1, mask=mask)
+    out = (w.reshape(w.shape[0], -1).astype(np.float64) @ col.reshape(col.shape[0], -1).astype(np.float64))
+    out = out.reshape(w.shape[0], col.shape[1], col.shape[2])
+    if b is not None:
+        out = out + b[:, None, None]
+    return np.maximum(out, 0) if relu else out
+
+
+@pytest.mark.parametrize("cin,cout,sizes,mod,relu", [(32, 32, [(9, 13)], False, False), (64, 128, [(16, 24), (8, 12), (4, 6), (2, 3)], False, True),
+                                                     (32, 64, [(10, 10)], True, False), (32, 256, [(7, 19), (3, 5)], False, False)])
+def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu):
+    rng = np.random.default_rng(4)
+    w = (rng.normal(size=(cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    xs = [rng.normal(size=(1, cin, h, ww)).astype(np.float32) for h, ww in sizes]
+    offs = [(rng.normal(size=(1, 18, h, ww)) * 2).astype(np.float32) for h, ww in sizes]
+    masks = [rng.uniform(0, 2, size=(1, 9, h, ww)).astype(np.float32) for h, ww in sizes] if mod else None
+    wp = U.pack_dcn_weight(cu(w))
+    assert np.array_equal(wp.cpu().numpy(), w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    outs = U.deform_conv_fused([cu(x) for x in xs], [cu(o) for o in offs], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1),
+                               masks=[cu(m) for m in masks] if mod else None, relu=relu)
+    for i, o in enumerate(outs):
+        ref = _dcn_ref(xs[i][0], offs[i][0], w, b, 3, 1, 1, 1, masks[i][0] if mod else None, relu)
+        got = o.cpu().numpy()[0]
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)  # fp32 logits within 1e-4 (BASELINE.json)
+
+
+def test_deform_conv_function_and_module(U):
+    from upsnet_amd.operators.modules.deform_conv import DeformConvWithOffset
+    torch.manual_seed(0)
+    for cin, cout in [(32, 64), (8, 8)]:  # fused path, im2col+mm path
+        m = DeformConvWithOffset(cin, cout, kernel_size=3, padding=1).cuda()
+        with torch.no_grad():
+            m.conv_offset.weight.normal_(0, 0.05)
+        x = torch.randn(2, cin, 11, 14, device='cuda')
+        with torch.no_grad():
+            y = m(x)
+            off = m.conv_offset(x)
+        for i in range(2):
+            ref = _dcn_ref(x[i].cpu().numpy(), off[i].cpu().numpy(), m.conv.weight.detach().cpu().numpy(),
+                           m.conv.bias.detach().cpu().numpy(), 3, 1, 1, 1)
+            np.testing.assert_allclose(y[i].cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(Exception):
+        m.cpu()(torch.randn(1, 8, 4, 4))
+
+
+# ------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 1500])
+@pytest.mark.parametrize("thresh", [0.5, 0.7])
+def test_gpu_nms_bitexact(U, n, thresh):
+    rng = np.random.default_rng(n)
+    d = gen_dets(rng, n)
+    ref = oops.gpu_nms(d, thresh)
+    got = U.gpu_nms(cu(d), thresh).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # `_nms` drop-in on host pointers, sorted input
+    order = oops.argsort_desc(d[:, 4])
+    keep = U.nms_host(d[order], thresh)
+    assert np.array_equal(order[keep], ref)
+
+
+def test_nms_wrappers_and_empty(U):
+    from upsnet_amd.nms.nms import gpu_nms_wrapper
+    rng = np.random.default_rng(9)
+    d = gen_dets(rng, 200)
+    assert gpu_nms_wrapper(0.5, 0)(d) == oops.gpu_nms(d, 0.5).tolist()
+    assert gpu_nms_wrapper(0.5, 0)(np.zeros((0, 5), np.float32)) == []
+
+
+def test_nms_batched_with_counts_and_preremoved(U):
+    rng = np.random.default_rng(10)
+    P, nmax = 5, 1000
+    counts = [1000, 777, 64, 1, 0]
+    boxes = np.zeros((P, nmax, 4), np.float32)
+    scores = np.zeros((P, nmax), np.float32)
+    pre = np.zeros((P, nmax), np.uint8)
+    refs = []
+    for p, c in enumerate(counts):
+        d = gen_dets(rng, c) if c else np.zeros((0, 5), np.float32)
+        boxes[p, :c], scores[p, :c] = d[:, :4], d[:, 4]
+        pre[p, :c] = rng.uniform(size=c) < 0.1
+        live = np.where(pre[p, :c] == 0)[0]
+        refs.append(live[oops.gpu_nms(d[live], 0.7)] if len(live) else np.zeros((0,), np.int64))
+    keep, cnt = U.nms_batched(cu(boxes), cu(scores), cu(np.array(counts, np.int32)), 0.7, cu(pre))
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for p in range(P):
+        assert cnt[p] == len(refs[p])
+        assert np.array_equal(keep[p, :cnt[p]], refs[p])
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 5, 200, 1300])
+def test_soft_nms_bitexact(U, method, n):
+    rng = np.random.default_rng(100 + n)
+    d = gen_dets(rng, n)
+    rb, ri = oracle.soft_nms(d, sigma=0.5, Nt=0.3, threshold=0.001 if method else 0.001, method=method)
+    gb, gi = U.soft_nms(cu(d), 0.5, 0.3, 0.001, method)
+    gi = gi.cpu().numpy()
+    assert np.array_equal(gi, ri)
+    assert np.array_equal(gb.cpu().numpy()[:len(ri)], rb[:len(ri)])
+
+
+# ------------------------------------------------------------------ proposals
+def _rpn_inputs(rng, H, W, strides=(4, 8, 16, 32, 64), A=3, sat=True):
+    cls, box = [], []
+    for s in strides:
+        h, w = max(H // s, 1), max(W // s, 1)
+        logit = rng.normal(0, 2.5, size=(1, A, h, w)).astype(np.float32)
+        p = (1.0 / (1.0 + np.exp(-logit.astype(np.float64)))).astype(np.float32)
+        if sat:
+            p[0, :, ::3, ::5] = np.float32(1.0)   # saturated sigmoid => real ties
+            p[0, 0, 1::4, 2::7] = p[0, 1, 0, 0]
+        cls.append(p)
+        box.append((rng.normal(0, 0.5, size=(1, 4 * A, h, w))).astype(np.float32))
+    return cls, box
+
+
+@pytest.mark.parametrize("H,W,pre,post", [(256, 512, 1000, 1000), (64, 96, 1000, 300), (1024, 2048, 1000, 1000), (32, 32, 50, 20)])
+def test_pyramid_proposals_bitexact(U, H, W, pre, post):
+    from upsnet_amd.operators.modules.pyramid_proposal import PyramidProposal
+    rng = np.random.default_rng(H + W)
+    cls, box = _rpn_inputs(rng, H, W)
+    im_info = np.array([[H - 3, W - 5, 1.0]], np.float32)
+    ref_rois, ref_scores = oops.pyramid_proposal(cls, box, im_info[0], pre_nms_top_n=pre, post_nms_top_n=post, nms_thresh=0.7)
+    pp = PyramidProposal((4, 8, 16, 32, 64), (8,), (0.5, 1, 2), pre, post, 0.7, 0, individual_proposals=True)
+    rois, scores = pp([cu(c) for c in cls], [cu(b) for b in box], im_info)
+    assert rois.shape[0] == ref_rois.shape[0]
+    assert np.array_equal(scores.cpu().numpy(), ref_scores)
+    assert np.array_equal(rois.cpu().numpy(), ref_rois)
+
+
+# ------------------------------------------------------------------ detection selection
+def _rcnn_inputs(rng, N, C, H, W, peaky):
+    rois = gen_rois(rng, N, H, W, 8, 300)
+    rois[N // 2:] = rois[:N - N // 2] + np.hstack([np.zeros((N - N // 2, 1)), rng.normal(0, 3, (N - N // 2, 4))]).astype(np.float32)
+    delta = rng.normal(0, 0.5, size=(N, 4 * C)).astype(np.float32)
+    logit = rng.normal(0, peaky, size=(N, C)).astype(np.float64)
+    prob = np.exp(logit - logit.max(1, keepdims=True))
+    prob = (prob / prob.sum(1, keepdims=True)).astype(np.float32)
+    prob[::11] = prob[3]  # duplicated rows => tied scores
+    return rois, delta, prob
+
+
+@pytest.mark.parametrize("N,C,agn,thresh,peaky", [(1000, 9, False, 0.05, 1.0), (1000, 9, True, 0.6, 3.0), (300, 81, False, 0.05, 2.0),
+                                                  (300, 81, True, 0.6, 4.0), (50, 9, True, 0.999, 0.1), (7, 9, False, 0.05, 1.0)])
+def test_mask_roi_bitexact(U, N, C, agn, thresh, peaky):
+    from upsnet_amd.config.config import config
+    from upsnet_amd.operators.modules.mask_roi import MaskROI
+    config.dataset.num_classes = C
+    rng = np.random.default_rng(N + C)
+    H, W = 512, 1024
+    rois, delta, prob = _rcnn_inputs(rng, N, C, H, W, peaky)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    rs, rb, rc = oops.mask_roi(rois, delta, prob, im_info, C, 0.5, thresh, 100, agn)
+    m = MaskROI(True, False, 100, C, nms_thresh=0.5, class_agnostic=agn, score_thresh=thresh)
+    s, b, c = m(cu(rois), cu(delta), cu(prob), im_info)
+    assert np.array_equal(c.cpu().numpy(), rc)
+    assert np.array_equal(s.cpu().numpy(), rs)
+    assert np.array_equal(b.cpu().numpy(), rb)
+    config.dataset.num_classes = 9
+
+
+# ------------------------------------------------------------------ panoptic head
+def _pan_inputs(rng, m, S, C, H, W, ms=28):
+    fcn = rng.normal(0, 3, size=(1, S, H, W)).astype(np.float32)
+    rois = gen_rois(rng, m, H, W, 8, min(H, W))
+    rois[:, 1:] += rng.uniform(-0.9, 0.9, size=(m, 4)).astype(np.float32)
+    rois[:, 1:] = np.maximum(rois[:, 1:], 0)
+    prob = rng.uniform(0.6, 1.0, size=m).astype(np.float32)
+    if m > 3:
+        prob[m // 2] = prob[0]
+    logit = rng.normal(0.3, 2, size=(m, 1, ms, ms)).astype(np.float32)
+    cls = rng.integers(1, C, size=m).astype(np.int64)
+    return fcn, rois, prob, logit, cls
+
+
+@pytest.mark.parametrize("m,S,C,H,W", [(30, 19, 9, 128, 256), (100, 19, 9, 256, 512), (1, 19, 9, 64, 64), (12, 133, 81, 96, 100), (40, 19, 9, 1024, 2048)])
+@pytest.mark.parametrize("void", [True, False])
+def test_panoptic_head_bitexact(U, m, S, C, H, W, void):
+    if not void and H * W > 300000:
+        pytest.skip("softmax variant checked at small sizes")
+    from upsnet_amd.config.config import config
+    config.dataset.num_classes, config.dataset.num_seg_classes = C, S
+    rng = np.random.default_rng(m + S)
+    fcn, rois, prob, logit, cls = _pan_inputs(rng, m, S, C, H, W)
+    ref = oops.panoptic_head(fcn, rois, prob, logit, cls, S, C, enable_void=void)
+    keep, num, real = U.mask_removal(cu(rois[:, 1:]), cu(prob), cu(logit), cu(cls), C - 1, (H, W))
+    k = int(num.item())
+    assert np.array_equal(keep[:k].cpu().numpy(), ref['keep_inds'])
+    cmap = cu(oops.class_mapping(S, C))
+    pan, sem = U.panoptic_fuse(cu(fcn), S - (C - 1), cu(rois), cu(logit), cu(cls), keep, num, real, cmap, void)
+    assert np.array_equal(sem.cpu().numpy()[0], ref['sem'])
+    assert np.array_equal(pan.cpu().numpy()[0], ref['panoptic'])
+    # materialising module-level path gives the same label map
+    energy = U.mask_paste(cu(rois[:, 1:]), cu(logit), keep, num, real, k, (H, W))
+    kk = keep[:k]
+    seg_inst = U.seg_term(cu(fcn), (cu(rois)[kk] * 4.0)[:, 1:] * 0.25, cu(cls)[kk], cmap)
+    pan2 = U.panoptic_argmax(cu(fcn), S - (C - 1), seg_inst, energy, void)
+    assert np.array_equal(pan2.cpu().numpy()[0], ref['panoptic'])
+    config.dataset.num_classes, config.dataset.num_seg_classes = 9, 19
+
+
+def test_mask_removal_modules_and_dummy(U):
+    from upsnet_amd.operators.modules.mask_removal import MaskRemoval
+    from upsnet_amd.operators.modules.unary_logits import SegTerm
+    rng = np.random.default_rng(77)
+    fcn, rois, prob, logit, cls = _pan_inputs(rng, 20, 19, 9, 96, 160)
+    rk, re = oops.mask_removal(rois[:, 1:], prob, logit, cls, (96, 160))
+    k, e = MaskRemoval(0.3)(cu(rois[:, 1:]), cu(prob), cu(logit), cu(cls), (96, 160))
+    assert np.array_equal(k.cpu().numpy(), rk)
+    assert np.array_equal(e.cpu().numpy(), re)
+    seg, inst = SegTerm(19)(cu(cls)[k], cu(fcn), cu(rois)[k] * 4.0)
+    rseg, rinst = oops.seg_term(cls[rk], fcn, rois[rk] * np.float32(4.0), 19, 9)
+    assert np.array_equal(inst.cpu().numpy(), rinst) and np.array_equal(seg.cpu().numpy(), rseg)
+    # dummy detection (MaskROI's empty result): keep = [0], one all-zero plane
+    k, e = MaskRemoval(0.3)(torch.zeros(1, 4).cuda(), torch.ones(1).cuda(), cu(logit[:1]), torch.zeros(1, dtype=torch.int64).cuda(), (96, 160))
+    assert k.tolist() == [0] and e.shape == (1, 1, 96, 160) and not e.any()
+    # nothing survives (all logits negative) -> same fallback
+    k, e = MaskRemoval(0.3)(cu(rois[:, 1:]), cu(prob), cu(-np.abs(logit) - 1), cu(cls), (96, 160))
+    assert k.tolist() == [0] and not e.any()

@@ -1,0 +1,110 @@
+"""ctypes binding of libupsnet_hip.so (the C ABI declared in include/upsnet_hip.h).
+
+The HIP library IS the product: there is no CPU / eager fallback. If the shared library is missing
+(or a kernel launch fails) the ops raise RuntimeError.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libupsnet_hip.so")
+
+c_int, c_float, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+P = c_void_p
+
+_SIGNATURES = {
+    "upsnet_last_error": (ctypes.c_char_p, []),
+    "upsnet_abi_version": (c_int, []),
+    "upsnet_roi_align_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "upsnet_roi_align_forward_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P]),
+    "upsnet_fpn_roi_align_forward": (c_int, [P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P]),
+    "upsnet_deform_im2col": (c_int, [P, P, P] + [c_int] * 13 + [P]),
+    "upsnet_mod_deform_im2col": (c_int, [P, P, P, P] + [c_int] * 15 + [P]),
+    "upsnet_deform_conv_forward_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 11 + [P, P, c_int]),
+    "upsnet_deform_conv_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "upsnet_nms_host": (c_int, [P, P, P, c_int, c_int, c_float, c_int]),
+    "upsnet_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "upsnet_nms_batched": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P, P, P]),
+    "upsnet_soft_nms_workspace_bytes": (c_size_t, [c_int]),
+    "upsnet_soft_nms": (c_int, [P, P, P, c_int, c_float, c_float, c_float, c_int, P, P]),
+    "upsnet_proposal_workspace_bytes": (c_size_t, [c_int, P, P, c_int, c_int, c_int]),
+    "upsnet_pyramid_proposals": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "upsnet_mask_roi_capacity": (c_int, [c_int, c_int, c_int]),
+    "upsnet_mask_roi_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "upsnet_mask_roi": (c_int, [P, P, P, P, c_int, P, c_int, P, c_int, c_float, c_float, c_int, P, P, P, P, P, P, P]),
+    "upsnet_mask_removal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "upsnet_mask_removal": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P, P, P, P]),
+    "upsnet_mask_paste": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "upsnet_seg_term": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "upsnet_panoptic_fuse": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, P, P]),
+    "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names declared in include/upsnet_hip.h (used by the CPU-side ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libupsnet_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("upsnet_amd: %s is missing -- build it with `python -m upsnet_amd.build` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("upsnet_amd.%s failed: %s" % (what, lib().upsnet_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Exception("not implemented")  # same behaviour as functions/deform_conv.py:40-41
+
+
+def f32c(t):
+    """fp32 + contiguous (plumbing)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def nhwc(t):
+    """Physical NHWC view of a logical NCHW tensor (plumbing; no copy if already channels_last)."""
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def int_array(vals):
+    return (c_int * len(vals))(*[int(v) for v in vals])
+
+
+def float_array(vals):
+    return (c_float * len(vals))(*[float(v) for v in vals])
+
+
+def ptr_array(tensors):
+    return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])

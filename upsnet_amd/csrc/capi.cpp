@@ -1,0 +1,20 @@
+// capi.cpp -- error reporting + ABI version of libupsnet_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "upsnet_hip.h"
+
+static thread_local char g_err[512] = "";
+
+int ups_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+extern "C" const char *upsnet_last_error(void) { return g_err; }
+extern "C" int upsnet_abi_version(void) { return 1; }

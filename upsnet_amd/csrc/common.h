@@ -1,0 +1,87 @@
+// common.h -- shared helpers for the gfx950 (MI355X / CDNA4) kernels of upsnet_amd.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: the selection ops
+// must reproduce fp32 decisions of the reference bit-for-bit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define UPS_WAVE 64
+
+extern "C" const char *upsnet_last_error(void);
+int ups_set_error(const char *fmt, ...);
+
+#define UPS_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) return ups_set_error(__VA_ARGS__); \
+    } while (0)
+
+#define UPS_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) return ups_set_error("%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+#define UPS_CHECK_HIP(expr)                                                           \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) return ups_set_error("%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int ups_divup(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Monotonic map float -> uint32 (a < b  <=>  key(a) < key(b)); used to build sortable 64-bit keys.
+__host__ __device__ static inline uint32_t ups_float_key(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float ups_key_float(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+// IoU with the "+1" pixel convention (reference: upsnet/nms/nms_kernel.cu:30-38), fp32, no FMA.
+__device__ static inline float ups_iou(float ax1, float ay1, float ax2, float ay2, float bx1, float by1,
+                                       float bx2, float by2)
+{
+    float left = fmaxf(ax1, bx1), right = fminf(ax2, bx2);
+    float top = fmaxf(ay1, by1), bottom = fminf(ay2, by2);
+    float width = fmaxf(right - left + 1.0f, 0.f), height = fmaxf(bottom - top + 1.0f, 0.f);
+    float interS = width * height;
+    float Sa = (ax2 - ax1 + 1.0f) * (ay2 - ay1 + 1.0f);
+    float Sb = (bx2 - bx1 + 1.0f) * (by2 - by1 + 1.0f);
+    return interS / (Sa + Sb - interS);
+}
+
+// Correctly-rounded fp32 exp / log2 via fp64 (the selection ops decode boxes with these so that
+// the CPU oracle and the device agree bit-for-bit).
+__device__ static inline float ups_exp_f32(float x) { return (float)exp((double)x); }
+__device__ static inline float ups_log2_f32(float x) { return (float)log2((double)x); }
+
+// Box decode (reference: upsnet/bbox/bbox_transform.py:290-330) + clip (:45-60), fp32.
+#define UPS_BBOX_XFORM_CLIP 4.135166556742356f /* float32(log(1000/16)) */
+__device__ static inline void ups_decode_clip(float x1, float y1, float x2, float y2, float dx, float dy,
+                                              float dw, float dh, float wx, float wy, float ww, float wh,
+                                              float im_h, float im_w, bool clip, float out[4])
+{
+    float width = x2 - x1 + 1.0f, height = y2 - y1 + 1.0f;
+    float ctr_x = x1 + 0.5f * width, ctr_y = y1 + 0.5f * height;
+    dx = dx / wx;
+    dy = dy / wy;
+    dw = fminf(dw / ww, UPS_BBOX_XFORM_CLIP);
+    dh = fminf(dh / wh, UPS_BBOX_XFORM_CLIP);
+    float pcx = dx * width + ctr_x, pcy = dy * height + ctr_y;
+    float pw = ups_exp_f32(dw) * width, ph = ups_exp_f32(dh) * height;
+    float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph;
+    float ox2 = pcx + 0.5f * pw - 1.0f, oy2 = pcy + 0.5f * ph - 1.0f;
+    if (clip) {
+        float w1 = im_w - 1.0f, h1 = im_h - 1.0f;
+        ox1 = fmaxf(fminf(ox1, w1), 0.f);
+        oy1 = fmaxf(fminf(oy1, h1), 0.f);
+        ox2 = fmaxf(fminf(ox2, w1), 0.f);
+        oy2 = fmaxf(fminf(oy2, h1), 0.f);
+    }
+    out[0] = ox1; out[1] = oy1; out[2] = ox2; out[3] = oy2;
+}

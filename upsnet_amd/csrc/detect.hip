@@ -1,0 +1,231 @@
+// detect.hip -- detection selection (MaskROI) entirely on the device (gfx950).
+//
+// Reference: upsnet/operators/modules/mask_roi.py:36-146 copies rois / deltas / probabilities to the
+// host, decodes in numpy, loops over classes calling gpu_nms (malloc + H2D + D2H each) and builds the
+// result on the host. Here: one launch builds every class's candidate list in ROI order (ordered
+// compaction with wave scans), the batched NMS of nms.hip resolves all classes at once, and one
+// workgroup applies the global top-max_det rule (radix select of the max_det-th largest score, `>=`
+// keep, order preserved) and writes the result, including the reference's dummy ROI when empty.
+#include "common.h"
+#include "sort.h"
+#include "upsnet_hip.h"
+
+int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
+                         const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
+                         int *keep_cnt, void *workspace);
+
+#define DET_T 1024
+
+// exclusive scan of a 0/1 flag over the workgroup; returns offset, total via *total
+__device__ static inline int det_block_scan(int v, int *sh, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(v != 0);
+    const int within = __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0) sh[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < DET_T / 64; ++w) { const int c = sh[w]; if (w < wave) base += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return base + within;
+}
+
+// problem p: class j = p+1 (class-wise) or the single class-agnostic problem.
+__global__ void __launch_bounds__(DET_T)
+mroi_candidates_kernel(const float *__restrict__ rois, const float *__restrict__ delta, const float *__restrict__ prob,
+                       const int num_rois, const int *__restrict__ num_rois_dev, const int C, const float *__restrict__ im_info,
+                       const int class_agnostic, const float score_thresh, const float wx, const float wy, const float ww,
+                       const float wh, const int nmax, float *__restrict__ cboxes, float *__restrict__ cscores,
+                       int *__restrict__ csrc, int *__restrict__ ccls, int *__restrict__ counts, int *__restrict__ status)
+{
+    __shared__ int sh[DET_T / 64];
+    const int p = blockIdx.x;
+    const int N = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
+    const float im_h = im_info[0], im_w = im_info[1];
+    const long total = class_agnostic ? (long)N * (C - 1) : N;
+    int cnt = 0;
+    bool overflow = false;
+    for (long base = 0; base < total; base += DET_T) {
+        const long q = base + threadIdx.x;
+        int r = 0, c = 0;
+        float s = 0.f;
+        bool flag = false;
+        if (q < total) {
+            if (class_agnostic) { r = (int)(q / (C - 1)); c = (int)(q % (C - 1)) + 1; } else { r = (int)q; c = p + 1; }
+            s = prob[(long)r * C + c];
+            flag = s > score_thresh;
+        }
+        int tot;
+        const int pos = cnt + det_block_scan(flag, sh, &tot);
+        if (flag) {
+            if (pos < nmax) {
+                const float *rr = rois + (long)r * 5;
+                const float *d = delta + (long)r * 4 * C + 4 * c;
+                float o[4];
+                ups_decode_clip(rr[1], rr[2], rr[3], rr[4], d[0], d[1], d[2], d[3], wx, wy, ww, wh, im_h, im_w, true, o);
+                float *b = cboxes + ((long)p * nmax + pos) * 4;
+                b[0] = o[0]; b[1] = o[1]; b[2] = o[2]; b[3] = o[3];
+                cscores[(long)p * nmax + pos] = s;
+                csrc[(long)p * nmax + pos] = r;
+                ccls[(long)p * nmax + pos] = c;
+            } else {
+                overflow = true;
+            }
+        }
+        cnt += tot;
+    }
+    if (overflow) atomicOr(status, 1);
+    if (threadIdx.x == 0) counts[p] = min(cnt, nmax);
+}
+
+__global__ void __launch_bounds__(DET_T)
+mroi_finalize_kernel(const int P, const int nmax, const int max_det, const float *__restrict__ cboxes,
+                     const float *__restrict__ cscores, const int *__restrict__ csrc, const int *__restrict__ ccls,
+                     const int *__restrict__ keep_idx, const int *__restrict__ keep_cnt, float *__restrict__ boxes_out,
+                     float *__restrict__ scores_out, int64_t *__restrict__ cls_out, int *__restrict__ src_out,
+                     int *__restrict__ num_out)
+{
+    __shared__ int sh[DET_T / 64];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    if (tid == 0) { int t = 0; for (int p = 0; p < P; ++p) t += keep_cnt[p]; s_total = t; }
+    __syncthreads();
+    const int T = s_total;
+    // ---- image_thresh = sorted(all kept scores)[-max_det]  (mask_roi.py:109-111), via MSB radix select
+    unsigned thr_key = 0;  // keep everything by default
+    if (max_det > 0 && T > max_det) {
+        if (tid == 0) { s_prefix = 0; s_need = (unsigned)max_det; }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += DET_T) hist[i] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (int p = 0; p < P; ++p) {
+                const int kc = keep_cnt[p];
+                for (int i = tid; i < kc; i += DET_T) {
+                    const unsigned k = ups_float_key(cscores[(long)p * nmax + keep_idx[(long)p * nmax + i]]);
+                    if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned need = s_need;
+                int b = 255;
+                for (; b > 0; --b) { if (hist[b] >= need) break; need -= hist[b]; }
+                s_prefix = prefix | ((unsigned)b << shift);
+                s_need = need;
+            }
+            __syncthreads();
+        }
+        thr_key = s_prefix;
+    }
+    // ---- ordered compaction over (class, NMS order)
+    int cnt = 0;
+    for (int p = 0; p < P; ++p) {
+        const int kc = keep_cnt[p];
+        for (int base = 0; base < kc; base += DET_T) {
+            const int i = base + tid;
+            int src = 0;
+            float s = 0.f;
+            bool flag = false;
+            if (i < kc) {
+                src = keep_idx[(long)p * nmax + i];
+                s = cscores[(long)p * nmax + src];
+                flag = ups_float_key(s) >= thr_key;
+            }
+            int tot;
+            const int pos = cnt + det_block_scan(flag, sh, &tot);
+            if (flag) {
+                const float *b = cboxes + ((long)p * nmax + src) * 4;
+                float *o = boxes_out + (long)pos * 5;
+                o[0] = 0.f; o[1] = b[0]; o[2] = b[1]; o[3] = b[2]; o[4] = b[3];
+                scores_out[pos] = s;
+                cls_out[pos] = ccls[(long)p * nmax + src];
+                src_out[pos] = csrc[(long)p * nmax + src];
+            }
+            cnt += tot;
+        }
+    }
+    if (tid == 0) {
+        if (cnt == 0) {  // mask_roi.py:135-141
+            for (int q = 0; q < 5; ++q) boxes_out[q] = 0.f;
+            scores_out[0] = 1.f; cls_out[0] = 0; src_out[0] = 0;
+            cnt = 1;
+        }
+        *num_out = cnt;
+    }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static void mroi_dims(int N, int C, int agn, int *P, int *nmax)
+{
+    if (agn) { *P = 1; long m = (long)N * (C - 1); *nmax = (int)(m < 8192 ? (m < 1 ? 1 : m) : 8192); }
+    else { *P = C - 1; *nmax = N < 1 ? 1 : N; }
+}
+
+extern "C" int upsnet_mask_roi_capacity(int N, int C, int agn)
+{
+    int P, nmax;
+    mroi_dims(N, C, agn, &P, &nmax);
+    return P * nmax;
+}
+
+struct MroiPlan { size_t boxes, scores, src, cls, counts, keep, keepcnt, status, nms, total; };
+static MroiPlan mroi_plan(int P, int nmax)
+{
+    MroiPlan m; size_t o = 0;
+    m.boxes = o; o += al256((size_t)P * nmax * 16);
+    m.scores = o; o += al256((size_t)P * nmax * 4);
+    m.src = o; o += al256((size_t)P * nmax * 4);
+    m.cls = o; o += al256((size_t)P * nmax * 4);
+    m.counts = o; o += al256((size_t)P * 4);
+    m.keep = o; o += al256((size_t)P * nmax * 4);
+    m.keepcnt = o; o += al256((size_t)P * 4);
+    m.status = o; o += 256;
+    m.nms = o; o += upsnet_nms_workspace_bytes(P, nmax);
+    m.total = o + 256;
+    return m;
+}
+
+extern "C" size_t upsnet_mask_roi_workspace_bytes(int N, int C, int agn)
+{
+    int P, nmax;
+    mroi_dims(N, C, agn, &P, &nmax);
+    return mroi_plan(P, nmax).total;
+}
+
+extern "C" int upsnet_mask_roi(void *stream, const float *rois, const float *bbox_delta, const float *cls_prob, int num_rois,
+                               const int *num_rois_dev, int num_classes, const float *im_info, int class_agnostic,
+                               float score_thresh, float nms_thresh, int max_det, const float reg_weights[4],
+                               float *boxes_out, float *scores_out, int64_t *cls_out, int *src_out, int *num_out,
+                               void *workspace)
+{
+    UPS_REQUIRE(rois && bbox_delta && cls_prob && im_info && reg_weights && boxes_out && scores_out && cls_out && src_out &&
+                    num_out && workspace, "mask_roi: null pointer");
+    UPS_REQUIRE(num_rois >= 1 && num_classes >= 2, "mask_roi: need at least one roi and two classes");
+    int P, nmax;
+    mroi_dims(num_rois, num_classes, class_agnostic, &P, &nmax);
+    UPS_REQUIRE(nmax <= 8192, "mask_roi: %d candidates per class exceed the 8192 supported", nmax);
+    const MroiPlan m = mroi_plan(P, nmax);
+    unsigned char *ws = (unsigned char *)workspace;
+    float *cboxes = (float *)(ws + m.boxes), *cscores = (float *)(ws + m.scores);
+    int *csrc = (int *)(ws + m.src), *ccls = (int *)(ws + m.cls), *counts = (int *)(ws + m.counts);
+    int *keep = (int *)(ws + m.keep), *keepcnt = (int *)(ws + m.keepcnt), *status = (int *)(ws + m.status);
+    hipStream_t st = (hipStream_t)stream;
+    UPS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    hipLaunchKernelGGL(mroi_candidates_kernel, dim3(P), dim3(DET_T), 0, st, rois, bbox_delta, cls_prob, num_rois, num_rois_dev,
+                       num_classes, im_info, class_agnostic, score_thresh, reg_weights[0], reg_weights[1], reg_weights[2],
+                       reg_weights[3], nmax, cboxes, cscores, csrc, ccls, counts, status);
+    UPS_CHECK_LAUNCH("mroi_candidates_kernel");
+    int rc = ups_nms_batched_impl(st, cboxes, cscores, counts, nullptr, P, nmax, nms_thresh, 0, keep, keepcnt, ws + m.nms);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mroi_finalize_kernel, dim3(1), dim3(DET_T), 0, st, P, nmax, max_det, cboxes, cscores, csrc, ccls, keep,
+                       keepcnt, boxes_out, scores_out, cls_out, src_out, num_out);
+    UPS_CHECK_LAUNCH("mroi_finalize_kernel");
+    return 0;
+}

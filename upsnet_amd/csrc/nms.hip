@@ -1,0 +1,391 @@
+// nms.hip -- hard / soft NMS for gfx950.
+//
+// Reference: upsnet/nms/gpu_nms.pyx:23-38 (host argsort + _nms), upsnet/nms/nms_kernel.cu:30-150
+// (64x64 IoU bitmask tiles on the GPU, mask copied back, greedy scan on the HOST, cudaMalloc/Free per
+// call), upsnet/nms/cpu_nms.pyx:91-196 (soft-NMS, host only).
+//
+// MI355X design: the whole thing stays on the device and is batched over P independent problems
+// (all RPN levels / all classes at once):
+//   1. nms_sort_kernel  : one workgroup per problem, bitonic sort of unique 64-bit keys
+//                         (score bits << 32 | index) in LDS -> visiting order (score desc, index desc),
+//                         i.e. the pinned meaning of scores.argsort()[::-1].
+//   2. nms_mask_kernel  : 64-lane workgroups = one wavefront per 64x64 tile (upper triangle only),
+//                         column boxes staged in LDS, one u64 suppression word per (row, tile).
+//   3. nms_scan_kernel  : ONE wavefront per problem does the greedy scan: 64 candidates at a time are
+//                         resolved in registers with ctz/readlane on the diagonal tile, then every lane
+//                         ORs its own suppression words for the kept rows (coalesced row reads).
+// Decisions use the reference's fp32 expression order without FMA -> keep lists are bit-exact.
+#include "common.h"
+#include "sort.h"
+#include "upsnet_hip.h"
+
+typedef unsigned long long u64;
+
+__device__ static inline u64 shfl64(u64 v, int src)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// tie_mode 0: equal scores -> higher index first; 1: lower index first.
+__global__ void __launch_bounds__(1024)
+nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ scores, const int *__restrict__ counts,
+                const int nmax, const int M, const int tie_mode, float4 *__restrict__ sorted_boxes,
+                int *__restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *keys = reinterpret_cast<u64 *>(smem_raw);
+    const int p = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
+    const int n = min(counts[p], nmax);
+    for (int i = tid; i < M; i += bd)
+        keys[i] = i < n ? ups_make_key(scores[(long)p * nmax + i], (unsigned)i, tie_mode) : 0ULL;
+    ups_block_sort_desc(keys, M);
+    const float4 *b4 = reinterpret_cast<const float4 *>(boxes) + (long)p * nmax;
+    for (int i = tid; i < n; i += bd) {
+        const int idx = (int)ups_key_index(keys[i], tie_mode);
+        order[(long)p * nmax + i] = idx;
+        sorted_boxes[(long)p * nmax + i] = b4[idx];
+    }
+}
+
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ counts, const int nmax, const int CB,
+                const float thresh, u64 *__restrict__ mask)
+{
+    const int p = blockIdx.z;
+    const int n = min(counts[p], nmax);
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    if (row_start * 64 >= n || col_start * 64 >= n || col_start < row_start) return;
+    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+    __shared__ float4 cb[64];
+    const int tid = threadIdx.x;
+    if (tid < col_size) cb[tid] = sboxes[(long)p * nmax + col_start * 64 + tid];
+    __syncthreads();
+    if (tid < row_size) {
+        const int cur = row_start * 64 + tid;
+        const float4 a = sboxes[(long)p * nmax + cur];
+        u64 t = 0;
+        const int start = (row_start == col_start) ? tid + 1 : 0;
+        for (int i = start; i < col_size; ++i) {
+            const float4 b = cb[i];
+            if (ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w) > thresh) t |= 1ULL << i;
+        }
+        mask[((long)p * nmax + cur) * CB + col_start] = t;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, const int *__restrict__ counts,
+                const uint8_t *__restrict__ pre_removed, const int nmax, const int CB, int *__restrict__ keep_idx,
+                int *__restrict__ keep_cnt)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = min(counts[p], nmax);
+    const int nb = (n + 63) >> 6;
+    const u64 *mp = mask + (long)p * nmax * CB;
+    const int *ord = order ? order + (long)p * nmax : nullptr;
+    u64 remv0 = 0, remv1 = 0;  // suppression words `lane` and `lane + 64`
+    int nkeep = 0;
+    const int w0 = lane, w1 = lane + 64;
+    for (int b = 0; b < nb; ++b) {
+        const u64 cur = shfl64(b < 64 ? remv0 : remv1, b & 63);
+        const int i = b * 64 + lane;
+        const bool valid = i < n;
+        const int oi = valid ? (ord ? ord[i] : i) : 0;
+        const bool pre = valid && pre_removed && pre_removed[(long)p * nmax + oi];
+        const u64 diag = valid ? mp[(long)i * CB + b] : 0;
+        u64 alive = ~cur & __ballot(valid) & ~__ballot(pre);
+        u64 kept = 0;
+        while (alive) {
+            const int t = __builtin_ctzll(alive);
+            kept |= 1ULL << t;
+            alive &= ~shfl64(diag, t);
+            alive &= ~(1ULL << t);
+        }
+        if ((kept >> lane) & 1ULL)
+            keep_idx[(long)p * nmax + nkeep + __builtin_popcountll(kept & ((1ULL << lane) - 1ULL))] = oi;
+        nkeep += __builtin_popcountll(kept);
+        const bool a0 = w0 > b && w0 < nb, a1 = w1 > b && w1 < nb;
+        u64 kk = kept;
+        while (kk) {  // 4 independent row reads in flight per trip
+            long r[4];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (kk) { r[q] = (long)(b * 64 + __builtin_ctzll(kk)) * CB; kk &= kk - 1; cnt = q + 1; } else r[q] = -1;
+            }
+            u64 v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v0[q] = (a0 && q < cnt) ? mp[r[q] + w0] : 0;
+                v1[q] = (a1 && q < cnt) ? mp[r[q] + w1] : 0;
+            }
+            remv0 |= v0[0] | v0[1] | v0[2] | v0[3];
+            remv1 |= v1[0] | v1[1] | v1[2] | v1[3];
+        }
+    }
+    if (lane == 0) keep_cnt[p] = nkeep;
+}
+
+static inline int next_pow2(int v) { int m = 64; while (m < v) m <<= 1; return m; }
+
+struct NmsWs {
+    float4 *sorted_boxes;
+    int *order;
+    u64 *mask;
+};
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static NmsWs nms_carve(void *ws, int P, int nmax)
+{
+    NmsWs w;
+    unsigned char *b = (unsigned char *)ws;
+    w.sorted_boxes = (float4 *)b; b += align256((size_t)P * nmax * sizeof(float4));
+    w.order = (int *)b; b += align256((size_t)P * nmax * sizeof(int));
+    w.mask = (u64 *)b;
+    return w;
+}
+
+extern "C" size_t upsnet_nms_workspace_bytes(int P, int nmax)
+{
+    if (P <= 0 || nmax <= 0) return 256;
+    size_t CB = (nmax + 63) / 64;
+    return align256((size_t)P * nmax * sizeof(float4)) + align256((size_t)P * nmax * sizeof(int)) +
+           align256((size_t)P * nmax * CB * sizeof(u64)) + 256;
+}
+
+// internal: tie_mode-selectable version used by the proposal / detection pipelines
+int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
+                         const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
+                         int *keep_cnt, void *workspace)
+{
+    UPS_REQUIRE(boxes && scores && counts && keep_idx && keep_cnt && workspace, "nms_batched: null pointer");
+    UPS_REQUIRE(P > 0 && nmax > 0, "nms_batched: bad sizes P=%d nmax=%d", P, nmax);
+    UPS_REQUIRE(nmax <= 8192, "nms_batched: nmax=%d exceeds the 8192 boxes per problem supported", nmax);
+    NmsWs w = nms_carve(workspace, P, nmax);
+    const int CB = (nmax + 63) / 64;
+    const int M = next_pow2(nmax);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(M < 1024 ? M : 1024), (size_t)M * sizeof(u64), st, boxes, scores,
+                       counts, nmax, M, tie_mode, w.sorted_boxes, w.order);
+    UPS_CHECK_LAUNCH("nms_sort_kernel");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, w.mask);
+    UPS_CHECK_LAUNCH("nms_mask_kernel");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, w.mask, w.order, counts, pre_removed, nmax, CB, keep_idx,
+                       keep_cnt);
+    UPS_CHECK_LAUNCH("nms_scan_kernel");
+    return 0;
+}
+
+extern "C" int upsnet_nms_batched(void *stream, const float *boxes, const float *scores, const int *counts,
+                                  const uint8_t *pre_removed, int P, int nmax, float thresh, int *keep_idx,
+                                  int *keep_cnt, void *workspace)
+{
+    return ups_nms_batched_impl((hipStream_t)stream, boxes, scores, counts, pre_removed, P, nmax, thresh, 0, keep_idx,
+                                keep_cnt, workspace);
+}
+
+// ---------------------------------------------------------------------------------------------
+// `_nms` drop-in: host pointers, boxes already sorted (gpu_nms.hpp:15).
+__global__ void nms_pack_kernel(const float *__restrict__ boxes, int n, int dim, float4 *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(boxes[(long)i * dim], boxes[(long)i * dim + 1], boxes[(long)i * dim + 2],
+                                    boxes[(long)i * dim + 3]);
+}
+
+extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+                               float thresh, int device_id)
+{
+    UPS_REQUIRE(keep_out && num_out && (boxes_host || boxes_num == 0), "nms_host: null pointer");
+    UPS_REQUIRE(boxes_dim >= 4, "nms_host: boxes_dim must be >= 4");
+    *num_out = 0;
+    if (boxes_num == 0) return 0;
+    UPS_REQUIRE(boxes_num <= 8192, "nms_host: at most 8192 boxes supported (got %d)", boxes_num);
+    int cur = 0;
+    UPS_CHECK_HIP(hipGetDevice(&cur));
+    if (cur != device_id) UPS_CHECK_HIP(hipSetDevice(device_id));
+    const int n = boxes_num, CB = (n + 63) / 64;
+    float *raw = nullptr; float4 *packed = nullptr; u64 *mask = nullptr; int *cnt = nullptr, *keep = nullptr, *kc = nullptr;
+    UPS_CHECK_HIP(hipMalloc(&raw, (size_t)n * boxes_dim * sizeof(float)));
+    UPS_CHECK_HIP(hipMalloc(&packed, (size_t)n * sizeof(float4)));
+    UPS_CHECK_HIP(hipMalloc(&mask, (size_t)n * CB * sizeof(u64)));
+    UPS_CHECK_HIP(hipMalloc(&cnt, sizeof(int)));
+    UPS_CHECK_HIP(hipMalloc(&keep, (size_t)n * sizeof(int)));
+    UPS_CHECK_HIP(hipMalloc(&kc, sizeof(int)));
+    int rc = 0;
+    do {
+        if (hipMemcpy(raw, boxes_host, (size_t)n * boxes_dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = ups_set_error("nms_host: H2D copy failed"); break; }
+        hipLaunchKernelGGL(nms_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, raw, n, boxes_dim, packed);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, mask);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, 0, mask, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
+                           n, CB, keep, kc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rc = ups_set_error("nms_host: launch failed: %s", hipGetErrorString(e)); break; }
+        if (hipMemcpy(num_out, kc, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(keep_out, keep, (size_t)(*num_out) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = ups_set_error("nms_host: D2H copy failed"); break;
+        }
+    } while (0);
+    (void)hipFree(raw); (void)hipFree(packed); (void)hipFree(mask); (void)hipFree(cnt); (void)hipFree(keep); (void)hipFree(kc);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Soft-NMS (cpu_nms.pyx:91-196) as one workgroup: the outer loop is sequential by definition; each
+// trip does a parallel arg-max (first position of the maximum), the swap, a parallel re-score and the
+// reference's "swap with last" compaction restated as: k-th hole (ascending) <- k-th survivor from
+// the end (descending). Off the hot path in the reference (dead code); built for API parity.
+#define SNMS_T 1024
+
+__device__ static inline int block_excl_scan(int v, int *sh_wave, int *total)
+{
+    // exclusive prefix sum over the workgroup (blockDim.x == SNMS_T); returns this thread's offset
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) sh_wave[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        int s = lane < (SNMS_T / 64) ? sh_wave[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(s, d, 64); if (lane >= d) s += y; }
+        if (lane < (SNMS_T / 64)) sh_wave[lane] = s;  // inclusive over waves
+    }
+    __syncthreads();
+    const int base = wave == 0 ? 0 : sh_wave[wave - 1];
+    *total = sh_wave[SNMS_T / 64 - 1];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(SNMS_T)
+soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int n, const float sigma, const float Nt,
+                const float threshold, const int method, int *__restrict__ n_out, float *__restrict__ tmp_box,
+                int64_t *__restrict__ tmp_ind, uint8_t *__restrict__ flag)
+{
+    __shared__ float s_val[SNMS_T / 64];
+    __shared__ int s_pos[SNMS_T / 64];
+    __shared__ int s_scan[SNMS_T / 64];
+    __shared__ int s_maxpos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += SNMS_T) inds[i] = i;
+    __syncthreads();
+    int N = n;
+    for (int i = 0; i < N; ++i) {
+        // ---- arg-max over [i, N): first position holding the maximum score
+        float bv = -INFINITY; int bp = 0x7fffffff;
+        for (int p = i + tid; p < N; p += SNMS_T) { float s = boxes[p * 5 + 4]; if (s > bv) { bv = s; bp = p; } }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            float ov = __shfl_down(bv, d, 64); int op = __shfl_down(bp, d, 64);
+            if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_pos[wave] = bp; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_val[0]; int p = s_pos[0];
+            for (int w = 1; w < SNMS_T / 64; ++w) if (s_val[w] > v || (s_val[w] == v && s_pos[w] < p)) { v = s_val[w]; p = s_pos[w]; }
+            // reference starts from maxpos = i and moves only on a strictly larger score
+            if (!(boxes[i * 5 + 4] < v)) p = i;
+            s_maxpos = p;
+            if (p != i) {
+                for (int k = 0; k < 5; ++k) { float t = boxes[i * 5 + k]; boxes[i * 5 + k] = boxes[p * 5 + k]; boxes[p * 5 + k] = t; }
+                int64_t ti = inds[i]; inds[i] = inds[p]; inds[p] = ti;
+            }
+        }
+        __syncthreads();
+        const float tx1 = boxes[i * 5 + 0], ty1 = boxes[i * 5 + 1], tx2 = boxes[i * 5 + 2], ty2 = boxes[i * 5 + 3];
+        // ---- re-score (i, N) and flag removals
+        for (int p = i + 1 + tid; p < N; p += SNMS_T) {
+            const float x1 = boxes[p * 5 + 0], y1 = boxes[p * 5 + 1], x2 = boxes[p * 5 + 2], y2 = boxes[p * 5 + 3];
+            uint8_t rem = 0;
+            const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
+            const float iw = (fminf(tx2, x2) - fmaxf(tx1, x1) + 1);
+            if (iw > 0) {
+                const float ih = (fminf(ty2, y2) - fmaxf(ty1, y1) + 1);
+                if (ih > 0) {
+                    const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+                    const float ov = iw * ih / ua;
+                    float weight;
+                    if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+                    else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
+                    else weight = ov > Nt ? 0 : 1;
+                    const float ns = weight * boxes[p * 5 + 4];
+                    boxes[p * 5 + 4] = ns;
+                    rem = ns < threshold;
+                }
+            }
+            flag[p] = rem;
+        }
+        __syncthreads();
+        // ---- compaction: survivors keep their slot if < N'; holes below N' take survivors from the end
+        const int len = N - (i + 1);
+        if (len > 0) {
+            int nrem_total = 0;
+            // count removed
+            int local = 0;
+            for (int p = i + 1 + tid; p < N; p += SNMS_T) local += flag[p];
+            (void)block_excl_scan(local, s_scan, &nrem_total);
+            if (nrem_total > 0) {
+                const int Nn = N - nrem_total;
+                // holes: removed positions < Nn, ranked ascending; movers: surviving positions >= Nn, ranked descending.
+                // Both sets have equal size (<= nrem_total). Chunked ranks keep position order across chunks.
+                int hole_base = 0, mover_base = 0;
+                const int chunks = (len + SNMS_T - 1) / SNMS_T;
+                for (int c = 0; c < chunks; ++c) {
+                    const int p = i + 1 + c * SNMS_T + tid;            // ascending walk for holes
+                    const int ish = (p < Nn) && flag[p];
+                    int tot; const int r = block_excl_scan(ish, s_scan, &tot);
+                    if (ish) tmp_ind[hole_base + r] = p;                // hole list (position)
+                    hole_base += tot;
+                }
+                for (int c = 0; c < chunks; ++c) {
+                    const int p = N - 1 - (c * SNMS_T + tid);          // descending walk for movers
+                    const int ism = (p >= Nn) && (p > i) && !flag[p];
+                    int tot; const int r = block_excl_scan(ism, s_scan, &tot);
+                    if (ism) {
+                        for (int k = 0; k < 5; ++k) tmp_box[(mover_base + r) * 5 + k] = boxes[p * 5 + k];
+                        tmp_box[(size_t)n * 5 + mover_base + r] = __builtin_bit_cast(float, (int)p);
+                    }
+                    mover_base += tot;
+                }
+                __syncthreads();
+                for (int q = tid; q < hole_base; q += SNMS_T) {
+                    const int dst = (int)tmp_ind[q];
+                    const int src = __builtin_bit_cast(int, tmp_box[(size_t)n * 5 + q]);
+                    for (int k = 0; k < 5; ++k) boxes[dst * 5 + k] = tmp_box[q * 5 + k];
+                    flag[dst] = 2;  // marks "index must be taken from src"
+                    tmp_ind[n + q] = inds[src];
+                }
+                __syncthreads();
+                for (int q = tid; q < hole_base; q += SNMS_T) inds[(int)tmp_ind[q]] = tmp_ind[n + q];
+                N = Nn;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = N;
+}
+
+extern "C" size_t upsnet_soft_nms_workspace_bytes(int n)
+{
+    return align256((size_t)n * 6 * sizeof(float)) + align256((size_t)n * 2 * sizeof(int64_t)) + align256((size_t)n) + 256;
+}
+
+extern "C" int upsnet_soft_nms(void *stream, float *boxes, int64_t *inds, int n, float sigma, float Nt,
+                                  float threshold, int method, int *n_out, void *workspace)
+{
+    UPS_REQUIRE(boxes && inds && n_out && workspace, "soft_nms: null pointer");
+    UPS_REQUIRE(n >= 0 && n < (1 << 24), "soft_nms: bad n");
+    unsigned char *b = (unsigned char *)workspace;
+    float *tmp_box = (float *)b; b += align256((size_t)n * 6 * sizeof(float));
+    int64_t *tmp_ind = (int64_t *)b; b += align256((size_t)n * 2 * sizeof(int64_t));
+    uint8_t *flag = b;
+    hipLaunchKernelGGL(soft_nms_kernel, dim3(1), dim3(SNMS_T), 0, (hipStream_t)stream, boxes, inds, n, sigma, Nt, threshold,
+                       method, n_out, tmp_box, tmp_ind, flag);
+    UPS_CHECK_LAUNCH("soft_nms_kernel");
+    return 0;
+}

@@ -1,0 +1,527 @@
+// panoptic.hip -- the parameter-free panoptic head on the device (gfx950).
+//
+// Reference (all host/Python): MaskRemoval (upsnet/operators/modules/mask_removal.py:29-93: cv2.resize
+// per instance on the CPU, per-instance H2D copies, an [m,H,W] fp32 memset), SegTerm
+// (upsnet/operators/modules/unary_logits.py:78-105: Python loop + [k,H,W] memset) and the fusion in
+// upsnet/models/resnet_upsnet.py:234-243 (max / cat / argmax over (12+2k) full-resolution planes).
+//
+// Here:
+//  * mask_removal_kernel  : one workgroup per thing class walks that class's instances in global
+//    score order; the 28x28 logits are resampled on the fly (INTER_LINEAR restated), mask_sum and the
+//    overlap with the class occupancy plane are integer workgroup reductions -> decisions bit-exact.
+//  * panoptic_fuse_kernel : ONE pass over fcn_output produces the panoptic (and semantic) label map;
+//    instance logits (SegTerm crop + pasted mask logit) are evaluated per pixel from the box list,
+//    nothing of size [k,H,W] is ever materialised: ~(S*4 + 16) bytes per pixel instead of ~(12+2k)*24.
+//  * mask_paste / seg_term / panoptic_argmax: materialising variants that keep the reference's
+//    module-level API (MaskRemoval returns mask_energy, SegTerm returns seg_inst_energy).
+#include "common.h"
+#include "sort.h"
+#include "upsnet_hip.h"
+
+#define PAN_T 1024
+#define PAN_MAXDIM 4096   // max box side handled by the removal kernel's coefficient tables
+#define PAN_MAXINST 1024  // max instances entering mask removal
+#define PAN_MAXMS 32      // max mask side (28 in every config)
+
+// ---- cv2.resize INTER_LINEAR restated (see oracle/c/upsnet_oracle.c: orc_lin_coef)
+__device__ static inline void pan_lin_coef(int d, int dsize, int ssize, int &s0, int &s1, float &f)
+{
+    const double scale = (double)ssize / (double)dsize;
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+    s0 = sx;
+    s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
+    f = fx;
+}
+
+__device__ static inline float pan_resize_coef(const float *__restrict__ src, int ssize, int x0, int x1, float fx, int y0,
+                                               int y1, float fy)
+{
+    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+    const float r0 = src[y0 * ssize + x0] * a0 + src[y0 * ssize + x1] * a1;
+    const float r1 = src[y1 * ssize + x0] * a0 + src[y1 * ssize + x1] * a1;
+    return r0 * b0 + r1 * b1;
+}
+
+__device__ static inline float pan_resize_at(const float *__restrict__ src, int ssize, int dw, int dh, int dx, int dy)
+{
+    int x0, x1, y0, y1;
+    float fx, fy;
+    pan_lin_coef(dx, dw, ssize, x0, x1, fx);
+    pan_lin_coef(dy, dh, ssize, y0, y1, fy);
+    return pan_resize_coef(src, ssize, x0, x1, fx, y0, y1, fy);
+}
+
+struct PanBox {  // MaskRemoval geometry of one instance (mask_removal.py:60-77)
+    int bx0, by0, w, h, x_0, x_1, y_0, y_1;
+};
+__device__ static inline PanBox pan_box(const float *__restrict__ r4, int H, int W)
+{
+    PanBox b;
+    const int x1 = (int)r4[0], y1 = (int)r4[1], x2 = (int)r4[2], y2 = (int)r4[3];  // astype(int32): truncation
+    b.bx0 = x1; b.by0 = y1;
+    b.w = max(x2 - x1 + 1, 1); b.h = max(y2 - y1 + 1, 1);
+    b.x_0 = max(x1, 0); b.x_1 = min(x2 + 1, W);
+    b.y_0 = max(y1, 0); b.y_1 = min(y2 + 1, H);
+    // python slicing of the h x w mask clamps the stop: local coords stay < (h, w)
+    b.x_1 = min(b.x_1, x1 + b.w); b.y_1 = min(b.y_1, y1 + b.h);
+    return b;
+}
+
+__device__ static inline long pan_block_sum(long v, long *sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned lo = __shfl_down((unsigned)v, d, 64), hi = __shfl_down((unsigned)((unsigned long long)v >> 32), d, 64);
+        v += (long)(((unsigned long long)hi << 32) | lo);
+    }
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;
+}
+
+// grid = num_thing_classes, block = PAN_T
+__global__ void __launch_bounds__(PAN_T)
+mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ prob, const float *__restrict__ logits,
+                    const int64_t *__restrict__ cls_idx, const int m, const int ms, const int H, const int W,
+                    const double fraction_threshold, uint8_t *__restrict__ occupancy, int *__restrict__ sorted_idx,
+                    uint8_t *__restrict__ kept_flag)
+{
+    __shared__ ups_u64 s_keys[PAN_MAXINST];
+    __shared__ float s_logit[PAN_MAXMS * PAN_MAXMS];
+    __shared__ short s_cx0[PAN_MAXDIM], s_cx1[PAN_MAXDIM], s_cy0[PAN_MAXDIM], s_cy1[PAN_MAXDIM];
+    __shared__ float s_fx[PAN_MAXDIM], s_fy[PAN_MAXDIM];
+    __shared__ long s_red[PAN_T / 64];
+    const int tid = threadIdx.x, my_cls = blockIdx.x;
+    const int M = ups_next_pow2(m < 64 ? 64 : m);
+    for (int i = tid; i < M; i += PAN_T) s_keys[i] = i < m ? ups_make_key(prob[i], (unsigned)i, 0) : 0ULL;
+    ups_block_sort_desc(s_keys, M);
+    uint8_t *__restrict__ occ = occupancy + (long)my_cls * H * W;
+    for (int si = 0; si < m; ++si) {
+        const int i = (int)ups_key_index(s_keys[si], 0);
+        if (my_cls == 0 && tid == 0) sorted_idx[si] = i;
+        if ((int)cls_idx[i] - 1 != my_cls) continue;  // uniform
+        const PanBox b = pan_box(rois + (long)i * 4, H, W);
+        const int rx = b.x_1 - b.x_0, ry = b.y_1 - b.y_0;
+        bool keep = false;
+        if (rx > 0 && ry > 0) {
+            __syncthreads();
+            for (int q = tid; q < ms * ms; q += PAN_T) s_logit[q] = logits[(long)i * ms * ms + q];
+            for (int q = tid; q < rx; q += PAN_T) { int a, c; float f; pan_lin_coef(b.x_0 - b.bx0 + q, b.w, ms, a, c, f); s_cx0[q] = (short)a; s_cx1[q] = (short)c; s_fx[q] = f; }
+            for (int q = tid; q < ry; q += PAN_T) { int a, c; float f; pan_lin_coef(b.y_0 - b.by0 + q, b.h, ms, a, c, f); s_cy0[q] = (short)a; s_cy1[q] = (short)c; s_fy[q] = f; }
+            __syncthreads();
+            const long area = (long)rx * ry;
+            long sum = 0, ov = 0;
+            for (long t = tid; t < area; t += PAN_T) {
+                const int yy = (int)(t / rx), xx = (int)(t % rx);
+                const float v = pan_resize_coef(s_logit, ms, s_cx0[xx], s_cx1[xx], s_fx[xx], s_cy0[yy], s_cy1[yy], s_fy[yy]);
+                if (v > 0) {
+                    ++sum;
+                    if (occ[(long)(b.y_0 + yy) * W + b.x_0 + xx] >= 1) ++ov;
+                }
+            }
+            sum = pan_block_sum(sum, s_red);
+            ov = pan_block_sum(ov, s_red);
+            keep = sum > 0 && !((double)ov / (double)sum > fraction_threshold);  // mask_removal.py:82
+            if (keep) {
+                for (long t = tid; t < area; t += PAN_T) {
+                    const int yy = (int)(t / rx), xx = (int)(t % rx);
+                    const float v = pan_resize_coef(s_logit, ms, s_cx0[xx], s_cx1[xx], s_fx[xx], s_cy0[yy], s_cy1[yy], s_fy[yy]);
+                    if (v > 0) occ[(long)(b.y_0 + yy) * W + b.x_0 + xx] += 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) kept_flag[si] = keep ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mask_removal_finalize_kernel(const int64_t *__restrict__ cls_idx, const int m, const int *__restrict__ sorted_idx,
+                             const uint8_t *__restrict__ kept_flag, int64_t *__restrict__ keep_inds, int *__restrict__ num_keep,
+                             int *__restrict__ real_keep)
+{
+    if (threadIdx.x != 0) return;
+    int k = 0;
+    const bool dummy = (m == 1 && cls_idx[0] == 0);  // mask_removal.py:55-57
+    if (!dummy)
+        for (int si = 0; si < m; ++si) if (kept_flag[si]) keep_inds[k++] = sorted_idx[si];
+    if (k == 0) { keep_inds[0] = 0; *num_keep = 1; *real_keep = 0; }  // :90-92
+    else { *num_keep = k; *real_keep = 1; }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t upsnet_mask_removal_workspace_bytes(int m, int ncls, int H, int W)
+{
+    return al256((size_t)(ncls < 1 ? 1 : ncls) * H * W) + al256((size_t)(m < 1 ? 1 : m) * 4) + al256((size_t)(m < 1 ? 1 : m)) + 256;
+}
+
+extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_prob, const float *mask_logit,
+                                   const int64_t *cls_idx, int m, int mask_size, int ncls, int H, int W,
+                                   double fraction_threshold, int64_t *keep_inds, int *num_keep, int *real_keep,
+                                   void *workspace)
+{
+    UPS_REQUIRE(mask_rois && cls_prob && mask_logit && cls_idx && keep_inds && num_keep && real_keep && workspace,
+                "mask_removal: null pointer");
+    UPS_REQUIRE(m >= 1 && m <= PAN_MAXINST, "mask_removal: m must be 1..%d (got %d)", PAN_MAXINST, m);
+    UPS_REQUIRE(mask_size >= 2 && mask_size <= PAN_MAXMS, "mask_removal: mask_size must be 2..%d", PAN_MAXMS);
+    UPS_REQUIRE(ncls >= 1 && H >= 1 && W >= 1 && H <= PAN_MAXDIM && W <= PAN_MAXDIM, "mask_removal: bad class count / image size (max side %d)", PAN_MAXDIM);
+    unsigned char *ws = (unsigned char *)workspace;
+    uint8_t *occ = ws; ws += al256((size_t)ncls * H * W);
+    int *sorted_idx = (int *)ws; ws += al256((size_t)m * 4);
+    uint8_t *kept = ws;
+    hipStream_t st = (hipStream_t)stream;
+    UPS_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)ncls * H * W, st));
+    UPS_CHECK_HIP(hipMemsetAsync(kept, 0, (size_t)m, st));
+    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, mask_logit, cls_idx, m,
+                       mask_size, H, W, fraction_threshold, occ, sorted_idx, kept);
+    UPS_CHECK_LAUNCH("mask_removal_kernel");
+    hipLaunchKernelGGL(mask_removal_finalize_kernel, dim3(1), dim3(64), 0, st, cls_idx, m, sorted_idx, kept, keep_inds, num_keep,
+                       real_keep);
+    UPS_CHECK_LAUNCH("mask_removal_finalize_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// materialisers (module-level API parity)
+__global__ void __launch_bounds__(256)
+mask_paste_kernel(const float *__restrict__ rois, const float *__restrict__ logits, const int64_t *__restrict__ keep_inds,
+                  const int *__restrict__ num_keep, const int *__restrict__ real_keep, const int ms, const int H, const int W,
+                  float *__restrict__ energy)
+{
+    const int j = blockIdx.y;
+    const long hw = (long)H * W;
+    const bool live = j < *num_keep && *real_keep;
+    PanBox b = {};
+    const float *src = logits;
+    if (live) { const long i = keep_inds[j]; b = pan_box(rois + i * 4, H, W); src = logits + i * ms * ms; }
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)blockDim.x * gridDim.x) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        float v = 0.f;
+        if (live && y >= b.y_0 && y < b.y_1 && x >= b.x_0 && x < b.x_1) v = pan_resize_at(src, ms, b.w, b.h, x - b.bx0, y - b.by0);
+        energy[(long)j * hw + p] = v;
+    }
+}
+
+extern "C" int upsnet_mask_paste(void *stream, const float *mask_rois, const float *mask_logit, const int64_t *keep_inds,
+                                 const int *num_keep, const int *real_keep, int kmax, int mask_size, int H, int W,
+                                 float *mask_energy)
+{
+    UPS_REQUIRE(mask_rois && mask_logit && keep_inds && num_keep && real_keep && mask_energy, "mask_paste: null pointer");
+    UPS_REQUIRE(kmax >= 1 && kmax <= 65535, "mask_paste: bad kmax");
+    int gx = ups_divup((long)H * W, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(mask_paste_kernel, dim3(gx, kmax), dim3(256), 0, (hipStream_t)stream, mask_rois, mask_logit, keep_inds,
+                       num_keep, real_keep, mask_size, H, W, mask_energy);
+    UPS_CHECK_LAUNCH("mask_paste_kernel");
+    return 0;
+}
+
+struct SegBox { int y0, y1, x0, x1; };
+__device__ static inline int pan_py_slice(long v, int n) { if (v < 0) { v += n; if (v < 0) v = 0; } if (v > n) v = n; return (int)v; }
+__device__ static inline SegBox pan_seg_box(float bx1, float by1, float bx2, float by2, int H, int W)
+{
+    SegBox s;  // unary_logits.py:99-102: int() truncates, numpy round is half-to-even
+    s.y0 = pan_py_slice((long)by1, H); s.y1 = pan_py_slice((long)(rintf(by2) + 1.0f), H);
+    s.x0 = pan_py_slice((long)bx1, W); s.x1 = pan_py_slice((long)(rintf(bx2) + 1.0f), W);
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+seg_term_kernel(const float *__restrict__ fcn, const int H, const int W, const float *__restrict__ boxes,
+                const int64_t *__restrict__ cls, const int64_t *__restrict__ class_map, float *__restrict__ seg_inst)
+{
+    const int j = blockIdx.y;
+    const long hw = (long)H * W;
+    const int64_t c = cls[j];
+    const SegBox s = pan_seg_box(boxes[j * 4 + 0], boxes[j * 4 + 1], boxes[j * 4 + 2], boxes[j * 4 + 3], H, W);
+    const float *src = fcn + (c != 0 ? class_map[c] : 0) * hw;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)blockDim.x * gridDim.x) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        float v = 0.f;
+        if (c != 0 && y >= s.y0 && y < s.y1 && x >= s.x0 && x < s.x1) v = src[p];
+        seg_inst[(long)j * hw + p] = v;
+    }
+}
+
+extern "C" int upsnet_seg_term(void *stream, const float *fcn_output, int num_seg, int H, int W, const float *boxes,
+                               const int64_t *cls, const int64_t *class_map, int k, float *seg_inst)
+{
+    (void)num_seg;
+    UPS_REQUIRE(fcn_output && boxes && cls && class_map && seg_inst, "seg_term: null pointer");
+    UPS_REQUIRE(k >= 1 && k <= 65535, "seg_term: bad k");
+    int gx = ups_divup((long)H * W, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(seg_term_kernel, dim3(gx, k), dim3(256), 0, (hipStream_t)stream, fcn_output, H, W, boxes, cls, class_map,
+                       seg_inst);
+    UPS_CHECK_LAUNCH("seg_term_kernel");
+    return 0;
+}
+
+// reference-shaped fusion on materialised planes
+__global__ void __launch_bounds__(256)
+panoptic_argmax_kernel(const float *__restrict__ fcn, const int S, const long hw, const int s_stuff,
+                       const float *__restrict__ seg_inst, const float *__restrict__ energy, const int k,
+                       const int enable_void, int64_t *__restrict__ pan)
+{
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)blockDim.x * gridDim.x) {
+        float best = fcn[p];
+        int bi = 0;
+        for (int c = 1; c < s_stuff; ++c) { const float v = fcn[(long)c * hw + p]; if (v > best) { best = v; bi = c; } }
+        if (enable_void) {
+            float mi = seg_inst[p];
+            for (int j = 0; j < k; ++j) {
+                const float si = seg_inst[(long)j * hw + p];
+                const float v = si + energy[(long)j * hw + p];
+                if (v > best) { best = v; bi = s_stuff + j; }
+                if (si > mi) mi = si;
+            }
+            float mt = fcn[(long)s_stuff * hw + p];
+            for (int c = s_stuff + 1; c < S; ++c) { const float v = fcn[(long)c * hw + p]; if (v > mt) mt = v; }
+            const float vd = mt - mi;
+            pan[p] = vd > best ? 255 : bi;
+        } else {
+            // argmax(softmax(x)) restated explicitly (resnet_upsnet.py:242-243)
+            float m = best;
+            for (int j = 0; j < k; ++j) { const float v = seg_inst[(long)j * hw + p] + energy[(long)j * hw + p]; if (v > m) m = v; }
+            float s = 0.f;
+            for (int c = 0; c < s_stuff; ++c) s += ups_exp_f32(fcn[(long)c * hw + p] - m);
+            for (int j = 0; j < k; ++j) s += ups_exp_f32(seg_inst[(long)j * hw + p] + energy[(long)j * hw + p] - m);
+            float bp = ups_exp_f32(fcn[p] - m) / s;
+            bi = 0;
+            for (int c = 1; c < s_stuff; ++c) { const float pr = ups_exp_f32(fcn[(long)c * hw + p] - m) / s; if (pr > bp) { bp = pr; bi = c; } }
+            for (int j = 0; j < k; ++j) {
+                const float pr = ups_exp_f32(seg_inst[(long)j * hw + p] + energy[(long)j * hw + p] - m) / s;
+                if (pr > bp) { bp = pr; bi = s_stuff + j; }
+            }
+            pan[p] = bi;
+        }
+    }
+}
+
+extern "C" int upsnet_panoptic_argmax(void *stream, const float *fcn_output, int num_seg, int H, int W, int num_stuff,
+                                      const float *seg_inst, const float *mask_energy, int k, int enable_void, int64_t *pan_out)
+{
+    UPS_REQUIRE(fcn_output && seg_inst && mask_energy && pan_out, "panoptic_argmax: null pointer");
+    UPS_REQUIRE(k >= 1 && num_stuff >= 1 && num_stuff < num_seg, "panoptic_argmax: bad k / channel split");
+    const long hw = (long)H * W;
+    int gx = ups_divup(hw, 256);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(panoptic_argmax_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, fcn_output, num_seg, hw, num_stuff,
+                       seg_inst, mask_energy, k, enable_void, pan_out);
+    UPS_CHECK_LAUNCH("panoptic_argmax_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused head: one pass over fcn_output
+#define FUSE_MAXK 256
+struct FuseInst {
+    PanBox mb;       // mask paste geometry
+    SegBox sb;       // SegTerm crop
+    int sem_ch;      // fcn channel of the instance class, -1 for the dummy (cls 0)
+    int logit_off;   // offset of the 28x28 logits
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+panoptic_fuse_kernel(const float *__restrict__ fcn, const int S, const int H, const int W, const int s_stuff,
+                     const float *__restrict__ mask_rois, const float *__restrict__ logits, const int64_t *__restrict__ cls_idx,
+                     const int64_t *__restrict__ keep_inds, const int *__restrict__ num_keep, const int *__restrict__ real_keep,
+                     const int ms, const int64_t *__restrict__ class_map, const int enable_void, int64_t *__restrict__ pan,
+                     int64_t *__restrict__ sem)
+{
+    __shared__ FuseInst s_inst[FUSE_MAXK];
+    __shared__ int s_list[FUSE_MAXK];
+    __shared__ int s_nlist;
+    const int k = min(*num_keep, FUSE_MAXK);
+    const bool real = *real_keep != 0;
+    const long hw = (long)H * W;
+    // tile of this workgroup: one image row, 256*VEC consecutive pixels
+    const int tiles_per_row = (W + 256 * VEC - 1) / (256 * VEC);
+    const int y = blockIdx.x / tiles_per_row;
+    const int xt0 = (blockIdx.x % tiles_per_row) * 256 * VEC;
+    const int xt1 = min(xt0 + 256 * VEC, W);
+    if (threadIdx.x == 0) s_nlist = 0;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const long i = keep_inds[j];
+        const float *r = mask_rois + i * 5;
+        FuseInst fi;
+        fi.mb = pan_box(r + 1, H, W);
+        // SegTerm sees mask_rois*4.0 (resnet_upsnet.py:227) times box_scale 1/4 (unary_logits.py:89)
+        const float b0 = (r[1] * 4.0f) * 0.25f, b1 = (r[2] * 4.0f) * 0.25f, b2 = (r[3] * 4.0f) * 0.25f, b3 = (r[4] * 4.0f) * 0.25f;
+        fi.sb = pan_seg_box(b0, b1, b2, b3, H, W);
+        const int64_t c = cls_idx[i];
+        fi.sem_ch = c != 0 ? (int)class_map[c] : -1;
+        fi.logit_off = (int)(i * ms * ms);
+        s_inst[j] = fi;
+    }
+    __syncthreads();
+    // cull: instances that touch this row segment (kept in instance order by a serial pass of thread 0
+    // over <= 256 flags computed in parallel)
+    __shared__ unsigned char s_touch[FUSE_MAXK];
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const FuseInst &fi = s_inst[j];
+        const bool tm = real && y >= fi.mb.y_0 && y < fi.mb.y_1 && fi.mb.x_0 < xt1 && fi.mb.x_1 > xt0;
+        const bool ts = fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && fi.sb.x0 < xt1 && fi.sb.x1 > xt0;
+        s_touch[j] = tm || ts;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int n = 0; for (int j = 0; j < k; ++j) if (s_touch[j]) s_list[n++] = j; s_nlist = n; }
+    __syncthreads();
+    const int nlist = s_nlist;
+
+    const int x0 = xt0 + threadIdx.x * VEC;
+    if (x0 >= W) return;
+    const long p0 = (long)y * W + x0;
+    float v[VEC], best[VEC], tmax[VEC], sbest[VEC];
+    int bi[VEC], sbi[VEC];
+    // ---- stuff channels: running first-max
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { best[q] = 0.f; bi[q] = 0; }
+    for (int c = 0; c < S; ++c) {
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(fcn + (long)c * hw + p0);
+            v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+        } else {
+            v[0] = fcn[(long)c * hw + p0];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            if (c == 0) { best[q] = v[q]; bi[q] = 0; sbest[q] = v[q]; sbi[q] = 0; }
+            else {
+                if (c < s_stuff && v[q] > best[q]) { best[q] = v[q]; bi[q] = c; }
+                if (v[q] > sbest[q]) { sbest[q] = v[q]; sbi[q] = c; }
+            }
+            if (c == s_stuff) tmax[q] = v[q];
+            else if (c > s_stuff && v[q] > tmax[q]) tmax[q] = v[q];
+        }
+    }
+    // ---- instance channels in order; untouched instances contribute logit 0 (and seg_inst 0)
+    float mi[VEC];
+    bool any_zero_before[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { mi[q] = 0.f; any_zero_before[q] = false; }
+    // mi starts from seg_inst of instance 0; instances not in the list have seg_inst == 0. Since k >= 1 the
+    // maximum over all k planes is max(0 if any plane is 0 here, listed values). Track it exactly:
+    float mi_listed[VEC];
+    int n_nonzero_planes[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { mi_listed[q] = -INFINITY; n_nonzero_planes[q] = 0; }
+    int li = 0;
+    for (int j = 0; j < k; ++j) {
+        const bool listed = li < nlist && s_list[li] == j;
+        if (listed) ++li;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int x = x0 + q;
+            float si = 0.f, mk = 0.f;
+            bool inseg = false;
+            if (listed && x < W) {
+                const FuseInst &fi = s_inst[j];
+                if (fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && x >= fi.sb.x0 && x < fi.sb.x1) {
+                    si = fcn[(long)fi.sem_ch * hw + (long)y * W + x];
+                    inseg = true;
+                }
+                if (real && y >= fi.mb.y_0 && y < fi.mb.y_1 && x >= fi.mb.x_0 && x < fi.mb.x_1)
+                    mk = pan_resize_at(logits + fi.logit_off, ms, fi.mb.w, fi.mb.h, x - fi.mb.bx0, y - fi.mb.by0);
+            }
+            const float inst = si + mk;
+            if (inst > best[q]) { best[q] = inst; bi[q] = s_stuff + j; }
+            if (inseg) { if (si > mi_listed[q]) mi_listed[q] = si; ++n_nonzero_planes[q]; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        // max_j seg_inst_j: planes where the pixel is outside the SegTerm crop hold exactly 0
+        float m = mi_listed[q];
+        if (n_nonzero_planes[q] < k) m = fmaxf(m, 0.f);
+        mi[q] = m;
+        (void)any_zero_before[q];
+    }
+    if (!enable_void) {
+        // argmax(softmax(.)) variant: recompute with explicit softmax (rare path: keep_fraction >= 1)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int x = x0 + q;
+            if (x >= W) continue;
+            const long p = (long)y * W + x;
+            float m = best[q];
+            float s = 0.f;
+            for (int c = 0; c < s_stuff; ++c) s += ups_exp_f32(fcn[(long)c * hw + p] - m);
+            int lj = 0;
+            for (int j = 0; j < k; ++j) {
+                const bool listed = lj < nlist && s_list[lj] == j;
+                if (listed) ++lj;
+                float si = 0.f, mk = 0.f;
+                if (listed) {
+                    const FuseInst &fi = s_inst[j];
+                    if (fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && x >= fi.sb.x0 && x < fi.sb.x1) si = fcn[(long)fi.sem_ch * hw + p];
+                    if (real && y >= fi.mb.y_0 && y < fi.mb.y_1 && x >= fi.mb.x_0 && x < fi.mb.x_1)
+                        mk = pan_resize_at(logits + fi.logit_off, ms, fi.mb.w, fi.mb.h, x - fi.mb.bx0, y - fi.mb.by0);
+                }
+                s += ups_exp_f32(si + mk - m);
+            }
+            float bp = ups_exp_f32(fcn[p] - m) / s;
+            int b2 = 0;
+            for (int c = 1; c < s_stuff; ++c) { const float pr = ups_exp_f32(fcn[(long)c * hw + p] - m) / s; if (pr > bp) { bp = pr; b2 = c; } }
+            lj = 0;
+            for (int j = 0; j < k; ++j) {
+                const bool listed = lj < nlist && s_list[lj] == j;
+                if (listed) ++lj;
+                float si = 0.f, mk = 0.f;
+                if (listed) {
+                    const FuseInst &fi = s_inst[j];
+                    if (fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && x >= fi.sb.x0 && x < fi.sb.x1) si = fcn[(long)fi.sem_ch * hw + p];
+                    if (real && y >= fi.mb.y_0 && y < fi.mb.y_1 && x >= fi.mb.x_0 && x < fi.mb.x_1)
+                        mk = pan_resize_at(logits + fi.logit_off, ms, fi.mb.w, fi.mb.h, x - fi.mb.bx0, y - fi.mb.by0);
+                }
+                const float pr = ups_exp_f32(si + mk - m) / s;
+                if (pr > bp) { bp = pr; b2 = s_stuff + j; }
+            }
+            bi[q] = b2;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const int x = x0 + q;
+        if (x >= W) continue;
+        int64_t lab = bi[q];
+        if (enable_void) { const float vd = tmax[q] - mi[q]; if (vd > best[q]) lab = 255; }
+        pan[(long)y * W + x] = lab;
+        if (sem) sem[(long)y * W + x] = sbi[q];
+    }
+}
+
+extern "C" int upsnet_panoptic_fuse(void *stream, const float *fcn_output, int num_seg, int H, int W, int num_stuff,
+                                    const float *mask_rois, const float *mask_logit, const int64_t *cls_idx,
+                                    const int64_t *keep_inds, const int *num_keep, const int *real_keep, int kmax,
+                                    int mask_size, const int64_t *class_map, int enable_void, int64_t *pan_out,
+                                    int64_t *sem_out)
+{
+    UPS_REQUIRE(fcn_output && mask_rois && mask_logit && cls_idx && keep_inds && num_keep && real_keep && class_map && pan_out,
+                "panoptic_fuse: null pointer");
+    UPS_REQUIRE(num_stuff >= 1 && num_stuff < num_seg, "panoptic_fuse: bad channel split %d/%d", num_stuff, num_seg);
+    UPS_REQUIRE(kmax >= 1 && kmax <= FUSE_MAXK, "panoptic_fuse: at most %d instances supported (got %d)", FUSE_MAXK, kmax);
+    UPS_REQUIRE(mask_size >= 2 && mask_size <= PAN_MAXMS, "panoptic_fuse: bad mask size");
+    hipStream_t st = (hipStream_t)stream;
+    if ((W & 3) == 0 && (((uintptr_t)fcn_output) & 15) == 0) {
+        const int tiles = ((W + 1023) / 1024) * H;
+        hipLaunchKernelGGL(panoptic_fuse_kernel<4>, dim3(tiles), dim3(256), 0, st, fcn_output, num_seg, H, W, num_stuff, mask_rois,
+                           mask_logit, cls_idx, keep_inds, num_keep, real_keep, mask_size, class_map, enable_void, pan_out, sem_out);
+    } else {
+        const int tiles = ((W + 255) / 256) * H;
+        hipLaunchKernelGGL(panoptic_fuse_kernel<1>, dim3(tiles), dim3(256), 0, st, fcn_output, num_seg, H, W, num_stuff, mask_rois,
+                           mask_logit, cls_idx, keep_inds, num_keep, real_keep, mask_size, class_map, enable_void, pan_out, sem_out);
+    }
+    UPS_CHECK_LAUNCH("panoptic_fuse_kernel");
+    return 0;
+}

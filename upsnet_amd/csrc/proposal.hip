@@ -1,0 +1,288 @@
+// proposal.hip -- RPN proposal generation entirely on the device (gfx950).
+//
+// Reference: upsnet/operators/functions/pyramid_proposal.py:62-222 copies every level's scores and
+// deltas to the host (10.5 MB / image), runs numpy top-k / decode / clip there and calls gpu_nms five
+// times with a malloc + H2D + D2H each; modules/pyramid_proposal.py:61-67 then re-sorts on the GPU.
+//
+// Here: (1) prop_key_kernel turns every anchor score into a unique sortable 64-bit key in the
+// reference's (h, w, a) enumeration order; (2) a tournament of LDS bitonic sorts (8192-key chunks,
+// each emits its top-k) reduces every level to its sorted top pre_nms_top_n -- rule (ii) of the
+// oracle: (score desc, anchor index asc); (3) prop_decode_kernel applies bbox_transform + clip_boxes
+// to the survivors only; (4) the batched NMS of nms.hip handles all levels at once; (5)
+// prop_merge_kernel concatenates the kept boxes per level and ranks them (score desc, concatenation
+// index asc). No host synchronisation anywhere.
+#include "common.h"
+#include "sort.h"
+#include "upsnet_hip.h"
+
+#define PROP_CH 8192  // keys per tournament chunk (64 KiB of LDS)
+#define PROP_MAXLEV 8
+
+int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
+                         const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
+                         int *keep_cnt, void *workspace);
+
+struct PropLevels {
+    const float *cls[PROP_MAXLEV];
+    const float *box[PROP_MAXLEV];
+    int H[PROP_MAXLEV], W[PROP_MAXLEV], stride[PROP_MAXLEV];
+    int n[PROP_MAXLEV];        // anchors per level
+    long key_off[PROP_MAXLEV]; // offset of the level's key segment
+    float anchors[PROP_MAXLEV][4][4]; // up to 4 anchors per cell
+    int nlev, A;
+};
+
+// scores [A,H,W] (NCHW) -> keys at (h*W + w)*A + a
+__global__ void __launch_bounds__(256)
+prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys)
+{
+    const int l = blockIdx.y;
+    const int n = lv.n[l], A = lv.A;
+    const long hw = (long)lv.H[l] * lv.W[l];
+    const float *__restrict__ s = lv.cls[l];
+    ups_u64 *__restrict__ out = keys + lv.key_off[l];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)blockDim.x * gridDim.x) {
+        const int a = (int)(i / hw);
+        const long pix = i % hw;
+        const unsigned idx = (unsigned)(pix * A + a);
+        out[idx] = ups_make_key(s[i], idx, 1);
+    }
+}
+
+struct PropStage {
+    long in_off[PROP_MAXLEV], out_off[PROP_MAXLEV];
+    int n_in[PROP_MAXLEV];
+    int chunk_start[PROP_MAXLEV + 1];
+    int nlev, k;
+};
+
+// one workgroup per chunk: sort <= PROP_CH keys, write the top k (zero-padded)
+__global__ void __launch_bounds__(1024)
+prop_topk_stage_kernel(const PropStage st, const ups_u64 *__restrict__ in, ups_u64 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);
+    int l = 0;
+    for (int q = 1; q < st.nlev; ++q) if ((int)blockIdx.x >= st.chunk_start[q]) l = q;
+    const int chunk = blockIdx.x - st.chunk_start[l];
+    const long base = (long)chunk * PROP_CH;
+    const int cn = (int)min((long)PROP_CH, (long)st.n_in[l] - base);
+    const int M = ups_next_pow2(cn < 64 ? 64 : cn);
+    const ups_u64 *__restrict__ src = in + st.in_off[l] + base;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) keys[i] = i < cn ? src[i] : 0ULL;
+    ups_block_sort_desc(keys, M);
+    ups_u64 *__restrict__ dst = out + st.out_off[l] + (long)chunk * st.k;
+    for (int i = threadIdx.x; i < st.k; i += blockDim.x) dst[i] = i < cn ? keys[i] : 0ULL;
+}
+
+// bbox_transform + clip_boxes + _filter_boxes on each level's sorted top-k keys (found via lv.key_off)
+__global__ void __launch_bounds__(256)
+prop_decode_kernel(const PropLevels lv, const ups_u64 *keys, int pre_n, const float *im_info, float min_size,
+                       float *boxes, float *scores, uint8_t *pre_removed, int *counts)
+{
+    const int l = blockIdx.y;
+    const int cnt = min(pre_n, lv.n[l]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[l] = cnt;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pre_n) return;
+    float *b = boxes + ((long)l * pre_n + i) * 4;
+    if (i >= cnt) {
+        b[0] = b[1] = b[2] = b[3] = 0.f;
+        scores[(long)l * pre_n + i] = 0.f;
+        pre_removed[(long)l * pre_n + i] = 1;
+        return;
+    }
+    const ups_u64 key = keys[lv.key_off[l] + i];
+    const unsigned idx = ups_key_index(key, 1);
+    const int A = lv.A, W = lv.W[l];
+    const int a = idx % A;
+    const int pix = idx / A;
+    const int h = pix / W, w = pix % W;
+    const long hw = (long)lv.H[l] * W;
+    const float sx = (float)(w * lv.stride[l]), sy = (float)(h * lv.stride[l]);
+    const float ax1 = lv.anchors[l][a][0] + sx, ay1 = lv.anchors[l][a][1] + sy;
+    const float ax2 = lv.anchors[l][a][2] + sx, ay2 = lv.anchors[l][a][3] + sy;
+    const float *__restrict__ d = lv.box[l] + (long)(a * 4) * hw + pix;
+    float o[4];
+    ups_decode_clip(ax1, ay1, ax2, ay2, d[0], d[hw], d[2 * hw], d[3 * hw], 1.f, 1.f, 1.f, 1.f, im_info[0], im_info[1],
+                    true, o);
+    b[0] = o[0]; b[1] = o[1]; b[2] = o[2]; b[3] = o[3];
+    scores[(long)l * pre_n + i] = ups_key_score(key);
+    const float ms = min_size * im_info[2];
+    const float ws = o[2] - o[0] + 1.0f, hs = o[3] - o[1] + 1.0f;
+    pre_removed[(long)l * pre_n + i] = !((ws >= ms) && (hs >= ms));
+}
+
+// single workgroup: concatenate per-level kept boxes (<= post_n each), rank by (score desc, concat idx asc)
+__global__ void __launch_bounds__(1024)
+prop_merge_kernel(const int nlev, const int pre_n, const int post_n, const float *__restrict__ boxes,
+                  const float *__restrict__ scores, const int *__restrict__ keep_idx, const int *__restrict__ keep_cnt,
+                  float *__restrict__ rois_out, float *__restrict__ scores_out, int *__restrict__ num_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);
+    __shared__ int s_start[PROP_MAXLEV + 1];
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int l = 0; l < nlev; ++l) { s_start[l] = t; t += min(keep_cnt[l], post_n); }
+        s_start[nlev] = t;
+    }
+    __syncthreads();
+    const int total = s_start[nlev];
+    const int M = ups_next_pow2(total < 64 ? 64 : total);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        ups_u64 k = 0;
+        if (i < total) {
+            int l = 0;
+            for (int q = 1; q < nlev; ++q) if (i >= s_start[q]) l = q;
+            const int src = keep_idx[(long)l * pre_n + (i - s_start[l])];
+            k = ups_make_key(scores[(long)l * pre_n + src], (unsigned)i, 1);
+        }
+        keys[i] = k;
+    }
+    ups_block_sort_desc(keys, M);
+    const int nout = min(total, post_n);
+    for (int i = threadIdx.x; i < post_n; i += blockDim.x) {
+        float *r = rois_out + (long)i * 5;
+        if (i < nout) {
+            const int ci = (int)ups_key_index(keys[i], 1);
+            int l = 0;
+            for (int q = 1; q < nlev; ++q) if (ci >= s_start[q]) l = q;
+            const int src = keep_idx[(long)l * pre_n + (ci - s_start[l])];
+            const float *b = boxes + ((long)l * pre_n + src) * 4;
+            r[0] = 0.f; r[1] = b[0]; r[2] = b[1]; r[3] = b[2]; r[4] = b[3];
+            scores_out[i] = scores[(long)l * pre_n + src];
+        } else {
+            r[0] = r[1] = r[2] = r[3] = r[4] = 0.f;
+            scores_out[i] = 0.f;
+        }
+    }
+    if (threadIdx.x == 0) *num_out = nout;
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct PropPlan {
+    long key_total;      // keys per ping-pong buffer
+    size_t off_keys0, off_keys1, off_boxes, off_scores, off_pre, off_counts, off_keep, off_keepcnt, off_nms, total;
+};
+
+static PropPlan prop_plan(int nlev, const int *H, const int *W, int A, int pre_n)
+{
+    PropPlan p;
+    long tot = 0;
+    for (int l = 0; l < nlev; ++l) {
+        long n = (long)H[l] * W[l] * A;
+        long chunks = (n + PROP_CH - 1) / PROP_CH;
+        long need = n > chunks * pre_n ? n : chunks * pre_n;
+        tot += need + pre_n;
+    }
+    p.key_total = tot;
+    size_t o = 0;
+    p.off_keys0 = o; o += al256((size_t)tot * 8);
+    p.off_keys1 = o; o += al256((size_t)tot * 8);
+    p.off_boxes = o; o += al256((size_t)nlev * pre_n * 16);
+    p.off_scores = o; o += al256((size_t)nlev * pre_n * 4);
+    p.off_pre = o; o += al256((size_t)nlev * pre_n);
+    p.off_counts = o; o += 256;
+    p.off_keep = o; o += al256((size_t)nlev * pre_n * 4);
+    p.off_keepcnt = o; o += 256;
+    p.off_nms = o; o += upsnet_nms_workspace_bytes(nlev, pre_n);
+    p.total = o + 256;
+    return p;
+}
+
+extern "C" size_t upsnet_proposal_workspace_bytes(int nlev, const int *heights, const int *widths, int num_anchors,
+                                                  int pre_nms_top_n, int post_nms_top_n)
+{
+    (void)post_nms_top_n;
+    if (nlev <= 0 || nlev > PROP_MAXLEV || !heights || !widths) return 0;
+    return prop_plan(nlev, heights, widths, num_anchors, pre_nms_top_n).total;
+}
+
+extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                        const int *heights, const int *widths, const int *strides, const float *anchors,
+                                        int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
+                                        float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace)
+{
+    UPS_REQUIRE(nlev >= 1 && nlev <= PROP_MAXLEV, "pyramid_proposals: nlev must be 1..%d", PROP_MAXLEV);
+    UPS_REQUIRE(cls_prob && bbox_pred && heights && widths && strides && anchors && im_info && rois_out && scores_out &&
+                    num_out && workspace, "pyramid_proposals: null pointer");
+    UPS_REQUIRE(num_anchors >= 1 && num_anchors <= 4, "pyramid_proposals: 1..4 anchors per cell supported (got %d)", num_anchors);
+    UPS_REQUIRE(pre_n >= 1 && pre_n <= PROP_CH, "pyramid_proposals: pre_nms_top_n must be 1..%d", PROP_CH);
+    UPS_REQUIRE(post_n >= 1 && (long)nlev * (post_n < pre_n ? post_n : pre_n) <= PROP_CH,
+                "pyramid_proposals: nlev*post_nms_top_n must be <= %d", PROP_CH);
+    hipStream_t st = (hipStream_t)stream;
+    const PropPlan plan = prop_plan(nlev, heights, widths, num_anchors, pre_n);
+    unsigned char *ws = (unsigned char *)workspace;
+    ups_u64 *kbuf[2] = {(ups_u64 *)(ws + plan.off_keys0), (ups_u64 *)(ws + plan.off_keys1)};
+    float *boxes = (float *)(ws + plan.off_boxes);
+    float *scores = (float *)(ws + plan.off_scores);
+    uint8_t *pre_removed = ws + plan.off_pre;
+    int *counts = (int *)(ws + plan.off_counts);
+    int *keep_idx = (int *)(ws + plan.off_keep);
+    int *keep_cnt = (int *)(ws + plan.off_keepcnt);
+    void *nms_ws = ws + plan.off_nms;
+
+    PropLevels lv;
+    lv.nlev = nlev; lv.A = num_anchors;
+    long seg_off[PROP_MAXLEV];
+    long off = 0;
+    int maxn = 0;
+    for (int l = 0; l < nlev; ++l) {
+        UPS_REQUIRE(cls_prob[l] && bbox_pred[l] && heights[l] > 0 && widths[l] > 0, "pyramid_proposals: bad level %d", l);
+        lv.cls[l] = cls_prob[l]; lv.box[l] = bbox_pred[l];
+        lv.H[l] = heights[l]; lv.W[l] = widths[l]; lv.stride[l] = strides[l];
+        lv.n[l] = heights[l] * widths[l] * num_anchors;
+        for (int a = 0; a < num_anchors; ++a)
+            for (int q = 0; q < 4; ++q) lv.anchors[l][a][q] = anchors[((long)l * num_anchors + a) * 4 + q];
+        long n = lv.n[l];
+        long chunks = (n + PROP_CH - 1) / PROP_CH;
+        long need = n > chunks * pre_n ? n : chunks * pre_n;
+        seg_off[l] = off;
+        lv.key_off[l] = off;
+        off += need + pre_n;
+        if (lv.n[l] > maxn) maxn = lv.n[l];
+    }
+    int gx = (maxn + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(prop_key_kernel, dim3(gx, nlev), dim3(256), 0, st, lv, kbuf[0]);
+    UPS_CHECK_LAUNCH("prop_key_kernel");
+
+    // tournament: repeat until every level is a single sorted chunk of k = pre_n keys
+    int cur = 0;
+    int n_in[PROP_MAXLEV];
+    for (int l = 0; l < nlev; ++l) n_in[l] = lv.n[l];
+    for (int iter = 0; iter < 8; ++iter) {
+        PropStage sg;
+        sg.nlev = nlev; sg.k = pre_n;
+        int chunks_total = 0;
+        bool more = false;
+        for (int l = 0; l < nlev; ++l) {
+            sg.in_off[l] = seg_off[l]; sg.out_off[l] = seg_off[l];
+            sg.n_in[l] = n_in[l];
+            sg.chunk_start[l] = chunks_total;
+            int c = (n_in[l] + PROP_CH - 1) / PROP_CH;
+            chunks_total += c;
+            n_in[l] = c * pre_n;
+            if (c > 1) more = true;
+        }
+        sg.chunk_start[nlev] = chunks_total;
+        hipLaunchKernelGGL(prop_topk_stage_kernel, dim3(chunks_total), dim3(1024), (size_t)PROP_CH * 8, st, sg, kbuf[cur],
+                           kbuf[cur ^ 1]);
+        UPS_CHECK_LAUNCH("prop_topk_stage_kernel");
+        cur ^= 1;
+        if (!more) break;
+    }
+    // after the last stage every level holds exactly one chunk: pre_n sorted keys at seg_off[l]
+    hipLaunchKernelGGL(prop_decode_kernel, dim3((pre_n + 255) / 256, nlev), dim3(256), 0, st, lv, kbuf[cur], pre_n, im_info,
+                       min_size, boxes, scores, pre_removed, counts);
+    UPS_CHECK_LAUNCH("prop_decode_kernel");
+    int rc = ups_nms_batched_impl(st, boxes, scores, counts, pre_removed, nlev, pre_n, nms_thresh, 0, keep_idx, keep_cnt, nms_ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(prop_merge_kernel, dim3(1), dim3(1024), (size_t)PROP_CH * 8, st, nlev, pre_n, post_n, boxes, scores,
+                       keep_idx, keep_cnt, rois_out, scores_out, num_out);
+    UPS_CHECK_LAUNCH("prop_merge_kernel");
+    return 0;
+}
+

@@ -1,0 +1,275 @@
+// roi_align.hip -- ROIAlign forward for gfx950.
+//
+//  * upsnet_roi_align_forward      : NCHW drop-in for the reference launcher
+//                                    (upsnet/operators/src/roi_align_cuda.cpp:26-30, kernel
+//                                    roi_align_kernel.cu:163-235).
+//  * upsnet_fpn_roi_align_forward  : the MI355X-native path. One launch for all four FPN levels,
+//                                    FPN level chosen on device (fpn_roi_align.py:36-38), features
+//                                    NHWC so each bilinear tap of a (roi, bin) is ONE contiguous
+//                                    C-vector: a wave reads a tap as 64 x float4 = 1 KiB, fully
+//                                    coalesced, output NHWC [N, PH, PW, C] written the same way.
+//
+// Arithmetic is the reference's, per channel, in fp32 without FMA contraction: every output value is
+// bit-identical to the CPU oracle.
+#include "common.h"
+#include "upsnet_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// shared: per-sample bilinear setup (roi_align_kernel.cu:43-95), returns false for "empty" samples
+struct RoiTap {
+    int y_low, y_high, x_low, x_high;
+    float w1, w2, w3, w4;
+};
+
+__device__ static inline bool roi_tap(int height, int width, float y, float x, RoiTap &t)
+{
+    if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return false;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+    if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+    float ly = y - (float)y_low, lx = x - (float)x_low;
+    float hy = 1.0f - ly, hx = 1.0f - lx;
+    t.y_low = y_low; t.y_high = y_high; t.x_low = x_low; t.x_high = x_high;
+    t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
+    return true;
+}
+
+__device__ static inline float roi_blend(const RoiTap &t, float v1, float v2, float v3, float v4)
+{
+    float val = t.w1 * v1;
+    val = val + t.w2 * v2;
+    val = val + t.w3 * v3;
+    val = val + t.w4 * v4;
+    return val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW drop-in: one thread per output element (n, c, ph, pw), pw fastest.
+__global__ void __launch_bounds__(256)
+roi_align_nchw_kernel(const long nthreads, const float *__restrict__ feat, const float spatial_scale,
+                      const int channels, const int height, const int width, const int pooled_h,
+                      const int pooled_w, const int sampling_ratio, const float *__restrict__ rois,
+                      float *__restrict__ out)
+{
+    for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+         index += (long)blockDim.x * gridDim.x) {
+        int pw = index % pooled_w;
+        int ph = (index / pooled_w) % pooled_h;
+        int c = (index / pooled_w / pooled_h) % channels;
+        int n = index / pooled_w / pooled_h / channels;
+        const float *r = rois + (long)n * 5;
+        int roi_batch_ind = (int)roundf(r[0]);
+        float roi_start_w = r[1] * spatial_scale, roi_start_h = r[2] * spatial_scale;
+        float roi_end_w = r[3] * spatial_scale, roi_end_h = r[4] * spatial_scale;
+        float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+        float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+        float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+        const float *plane = feat + ((long)roi_batch_ind * channels + c) * height * width;
+        int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+        int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+        const float count = (float)(grid_h * grid_w);
+        float acc = 0.f;
+        for (int iy = 0; iy < grid_h; ++iy) {
+            const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+                const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+                RoiTap t;
+                float val = 0.f;
+                if (roi_tap(height, width, y, x, t))
+                    val = roi_blend(t, plane[t.y_low * width + t.x_low], plane[t.y_low * width + t.x_high],
+                                    plane[t.y_high * width + t.x_low], plane[t.y_high * width + t.x_high]);
+                acc += val;
+            }
+        }
+        out[index] = acc / count;
+    }
+}
+
+extern "C" int upsnet_roi_align_forward(void *stream, const float *bottom_data, float spatial_scale,
+                                        int num_rois, int height, int width, int channels,
+                                        int pooled_height, int pooled_width, int sampling_ratio,
+                                        const float *bottom_rois, float *top_data)
+{
+    UPS_REQUIRE(bottom_data && bottom_rois && top_data, "roi_align_forward: null pointer");
+    UPS_REQUIRE(num_rois >= 0 && channels > 0 && height > 0 && width > 0 && pooled_height > 0 && pooled_width > 0,
+                "roi_align_forward: bad shape");
+    long n = (long)num_rois * channels * pooled_height * pooled_width;
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, bottom_data,
+                       spatial_scale, channels, height, width, pooled_height, pooled_width, sampling_ratio,
+                       bottom_rois, top_data);
+    UPS_CHECK_LAUNCH("roi_align_nchw_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FPN level (fpn_roi_align.py:36-38): floor(2 + log2(sqrt(w*h)/224 + 1e-6)) clipped to [0,3], fp32.
+__device__ static inline int fpn_level_of(float x1, float y1, float x2, float y2)
+{
+    float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
+    float s = sqrtf(w * h) / 224.0f + 1e-6f;
+    float l = floorf(2.0f + ups_log2_f32(s));
+    l = fminf(fmaxf(l, 0.f), 3.f);
+    return (int)l;
+}
+
+struct FpnFeat {
+    const float *ptr[4];
+    int h[4], w[4];
+    float scale[4];
+};
+
+// One wave per (roi, ph, pw) bin; lanes span channels in float4 groups. NHWC in, NHWC out.
+__global__ void __launch_bounds__(256)
+fpn_roi_align_nhwc_kernel(const FpnFeat ft, const int channels, const float *__restrict__ rois,
+                          const int num_rois, const int *__restrict__ num_rois_dev, const int pooled_h,
+                          const int pooled_w, const int sampling_ratio, float *__restrict__ out,
+                          int *__restrict__ levels_out)
+{
+    const int lane = threadIdx.x & 63;
+    const long bin = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
+    if (bin >= (long)num_rois * pooled_h * pooled_w) return;
+    const int pw = bin % pooled_w;
+    const int ph = (bin / pooled_w) % pooled_h;
+    const int n = bin / ((long)pooled_w * pooled_h);
+    const int c4n = channels >> 2;
+    float4 *o4 = reinterpret_cast<float4 *>(out + bin * channels);
+    if (n >= nvalid) {  // padded tail of a fixed-size roi buffer: defined output (zeros)
+        for (int c4 = lane; c4 < c4n; c4 += 64) o4[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float *r = rois + (long)n * 5;
+    const float rx1 = r[1], ry1 = r[2], rx2 = r[3], ry2 = r[4];
+    const int lvl = fpn_level_of(rx1, ry1, rx2, ry2);
+    if (levels_out && ph == 0 && pw == 0 && lane == 0) levels_out[n] = lvl;
+    const float spatial_scale = ft.scale[lvl];
+    const int height = ft.h[lvl], width = ft.w[lvl];
+    const float4 *feat = reinterpret_cast<const float4 *>(ft.ptr[lvl]);
+
+    const float roi_start_w = rx1 * spatial_scale, roi_start_h = ry1 * spatial_scale;
+    const float roi_end_w = rx2 * spatial_scale, roi_end_h = ry2 * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+    const float count = (float)(grid_h * grid_w);
+
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = 0; iy < grid_h; ++iy) {
+            const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+                const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+                RoiTap t;
+                if (roi_tap(height, width, y, x, t)) {
+                    const float4 v1 = feat[((long)t.y_low * width + t.x_low) * c4n + c4];
+                    const float4 v2 = feat[((long)t.y_low * width + t.x_high) * c4n + c4];
+                    const float4 v3 = feat[((long)t.y_high * width + t.x_low) * c4n + c4];
+                    const float4 v4 = feat[((long)t.y_high * width + t.x_high) * c4n + c4];
+                    acc.x += roi_blend(t, v1.x, v2.x, v3.x, v4.x);
+                    acc.y += roi_blend(t, v1.y, v2.y, v3.y, v4.y);
+                    acc.z += roi_blend(t, v1.z, v2.z, v3.z, v4.z);
+                    acc.w += roi_blend(t, v1.w, v2.w, v3.w, v4.w);
+                } else {
+                    acc.x += 0.f; acc.y += 0.f; acc.z += 0.f; acc.w += 0.f;
+                }
+            }
+        }
+        acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+        o4[c4] = acc;
+    }
+}
+
+extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
+                                            const int feat_w[4], const float spatial_scale[4], int channels,
+                                            const float *rois, int num_rois, const int *num_rois_dev,
+                                            int pooled_height, int pooled_width, int sampling_ratio,
+                                            float *out_nhwc, int *levels_out)
+{
+    UPS_REQUIRE(feat_nhwc && rois && out_nhwc, "fpn_roi_align_forward: null pointer");
+    UPS_REQUIRE(channels > 0 && (channels & 3) == 0, "fpn_roi_align_forward: channels must be a multiple of 4 (got %d)", channels);
+    UPS_REQUIRE(num_rois >= 0 && pooled_height > 0 && pooled_width > 0, "fpn_roi_align_forward: bad shape");
+    if (num_rois == 0) return 0;
+    FpnFeat ft;
+    for (int i = 0; i < 4; ++i) {
+        UPS_REQUIRE(feat_nhwc[i] && feat_h[i] > 0 && feat_w[i] > 0, "fpn_roi_align_forward: bad level %d", i);
+        ft.ptr[i] = feat_nhwc[i]; ft.h[i] = feat_h[i]; ft.w[i] = feat_w[i]; ft.scale[i] = spatial_scale[i];
+    }
+    long bins = (long)num_rois * pooled_height * pooled_width;
+    int blocks = (int)((bins + 3) / 4);
+    hipLaunchKernelGGL(fpn_roi_align_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ft, channels,
+                       rois, num_rois, num_rois_dev, pooled_height, pooled_width, sampling_ratio, out_nhwc, levels_out);
+    UPS_CHECK_LAUNCH("fpn_roi_align_nhwc_kernel");
+    return 0;
+}
+
+// Single-level NHWC variant (RoIAlign module on channels_last features): same kernel, level forced.
+__global__ void __launch_bounds__(256)
+roi_align_nhwc_kernel(const float *__restrict__ feat_, const int channels, const int height, const int width,
+                      const float spatial_scale, const float *__restrict__ rois, const int num_rois,
+                      const int pooled_h, const int pooled_w, const int sampling_ratio, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long bin = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (bin >= (long)num_rois * pooled_h * pooled_w) return;
+    const int pw = bin % pooled_w;
+    const int ph = (bin / pooled_w) % pooled_h;
+    const int n = bin / ((long)pooled_w * pooled_h);
+    const int c4n = channels >> 2;
+    const float *r = rois + (long)n * 5;
+    const int roi_batch_ind = (int)roundf(r[0]);
+    const float4 *feat = reinterpret_cast<const float4 *>(feat_ + (long)roi_batch_ind * height * width * channels);
+    const float roi_start_w = r[1] * spatial_scale, roi_start_h = r[2] * spatial_scale;
+    const float roi_end_w = r[3] * spatial_scale, roi_end_h = r[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+    const float count = (float)(grid_h * grid_w);
+    float4 *o4 = reinterpret_cast<float4 *>(out + bin * channels);
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = 0; iy < grid_h; ++iy) {
+            const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+                const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+                RoiTap t;
+                if (roi_tap(height, width, y, x, t)) {
+                    const float4 v1 = feat[((long)t.y_low * width + t.x_low) * c4n + c4];
+                    const float4 v2 = feat[((long)t.y_low * width + t.x_high) * c4n + c4];
+                    const float4 v3 = feat[((long)t.y_high * width + t.x_low) * c4n + c4];
+                    const float4 v4 = feat[((long)t.y_high * width + t.x_high) * c4n + c4];
+                    acc.x += roi_blend(t, v1.x, v2.x, v3.x, v4.x);
+                    acc.y += roi_blend(t, v1.y, v2.y, v3.y, v4.y);
+                    acc.z += roi_blend(t, v1.z, v2.z, v3.z, v4.z);
+                    acc.w += roi_blend(t, v1.w, v2.w, v3.w, v4.w);
+                }
+            }
+        }
+        acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+        o4[c4] = acc;
+    }
+}
+
+extern "C" int upsnet_roi_align_forward_nhwc(void *stream, const float *feat_nhwc, int batch, int height, int width,
+                                             int channels, float spatial_scale, const float *rois, int num_rois,
+                                             int pooled_height, int pooled_width, int sampling_ratio, float *out_nhwc)
+{
+    (void)batch;
+    UPS_REQUIRE(feat_nhwc && rois && out_nhwc, "roi_align_forward_nhwc: null pointer");
+    UPS_REQUIRE(channels > 0 && (channels & 3) == 0, "roi_align_forward_nhwc: channels must be a multiple of 4 (got %d)", channels);
+    if (num_rois == 0) return 0;
+    long bins = (long)num_rois * pooled_height * pooled_width;
+    int blocks = (int)((bins + 3) / 4);
+    hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feat_nhwc, channels,
+                       height, width, spatial_scale, rois, num_rois, pooled_height, pooled_width, sampling_ratio, out_nhwc);
+    UPS_CHECK_LAUNCH("roi_align_nhwc_kernel");
+    return 0;
+}

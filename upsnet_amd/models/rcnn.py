@@ -1,0 +1,84 @@
+"""Box head and mask head (upsnet/models/rcnn.py:34-146). with_norm='none' only (every shipped config).
+
+MI355X notes: FPNRoIAlign delivers channels-last pooled features straight from the kernel. The box head
+consumes them without a transpose by using fc6's weight re-laid-out once to the (ph, pw, c) flatten
+order (same dot products, different summation order); the mask head's convolutions take channels-last.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..config.config import config
+from ..operators.modules.fpn_roi_align import FPNRoIAlign
+from ..operators.modules.roialign import RoIAlign
+
+
+class MaskBranch(nn.Module):
+
+    def __init__(self, num_classes, dim_in=256, dim_hidden=256, with_norm='none'):
+        super(MaskBranch, self).__init__()
+        assert with_norm == 'none'
+        self.roi_pooling = FPNRoIAlign(config.network.mask_size // 2, config.network.mask_size // 2,
+                                       [1.0 / 4, 1.0 / 8, 1.0 / 16, 1.0 / 32], channels_last=True)
+        self.mask_conv1 = nn.Sequential(nn.Conv2d(dim_in, dim_hidden, 3, 1, 1), nn.ReLU(inplace=True))
+        self.mask_conv2 = nn.Sequential(nn.Conv2d(dim_hidden, dim_hidden, 3, 1, 1), nn.ReLU(inplace=True))
+        self.mask_conv3 = nn.Sequential(nn.Conv2d(dim_hidden, dim_hidden, 3, 1, 1), nn.ReLU(inplace=True))
+        self.mask_conv4 = nn.Sequential(nn.Conv2d(dim_hidden, dim_hidden, 3, 1, 1), nn.ReLU(inplace=True))
+        self.mask_deconv1 = nn.Sequential(nn.ConvTranspose2d(dim_hidden, dim_hidden, 2, 2, 0), nn.ReLU(inplace=True))
+        self.mask_score = nn.Conv2d(dim_hidden, num_classes, 1)
+        self.initialize()
+
+    def initialize(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode='fan_in')
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def forward(self, feat, rois):
+        x = self.roi_pooling(feat, rois)
+        x = self.mask_conv4(self.mask_conv3(self.mask_conv2(self.mask_conv1(x))))
+        return self.mask_score(self.mask_deconv1(x))
+
+
+class RCNN(nn.Module):
+
+    def __init__(self, num_classes, num_reg_classes, pool_size=7, dim_in=256, dim_hidden=1024, with_fpn_pooling=True,
+                 with_dpooling=False, with_adaptive_pooling=False, with_heavier_head=False, with_norm='none'):
+        super(RCNN, self).__init__()
+        assert with_norm == 'none' and with_fpn_pooling
+        self.pool_size, self.dim_in = pool_size, dim_in
+        self.roi_pooling = FPNRoIAlign(pool_size, pool_size, [1.0 / 4, 1.0 / 8, 1.0 / 16, 1.0 / 32], channels_last=True)
+        self.fc6 = nn.Sequential(nn.Linear((pool_size ** 2) * dim_in, dim_hidden), nn.ReLU(inplace=True))
+        self.fc7 = nn.Sequential(nn.Linear(dim_hidden, dim_hidden), nn.ReLU(inplace=True))
+        self.cls_score = nn.Linear(dim_hidden, num_classes)
+        self.bbox_pred = nn.Linear(dim_hidden, num_reg_classes * 4)
+        self._fc6_nhwc = None
+        self.initialize()
+
+    def initialize(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_uniform_(m.weight.data, a=1)
+                if m.bias is not None:
+                    m.bias.data.fill_(0)
+        nn.init.normal_(self.cls_score.weight.data, 0, 0.01)
+        self.cls_score.bias.data.fill_(0)
+        nn.init.normal_(self.bbox_pred.weight.data, 0, 0.001)
+        self.bbox_pred.bias.data.fill_(0)
+
+    def _fc6_weight_nhwc(self):
+        w = self.fc6[0].weight
+        key = (w.data_ptr(), w._version)
+        if self._fc6_nhwc is None or self._fc6_nhwc[0] != key:
+            p = self.pool_size
+            wp = w.detach().view(-1, self.dim_in, p, p).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+            self._fc6_nhwc = (key, wp)
+        return self._fc6_nhwc[1]
+
+    def forward(self, feat, rois, num_rois_dev=None):
+        pool_feat = self.roi_pooling(feat, rois, num_rois_dev)            # channels_last [N,C,7,7]
+        flat = pool_feat.permute(0, 2, 3, 1).reshape(pool_feat.size(0), -1)  # a view: physical (ph,pw,c) order
+        fc6 = F.relu(F.linear(flat, self._fc6_weight_nhwc(), self.fc6[0].bias), inplace=True)
+        fc7 = self.fc7(fc6)
+        return {'cls_score': self.cls_score(fc7), 'bbox_pred': self.bbox_pred(fc7), 'fc_feat': fc7}

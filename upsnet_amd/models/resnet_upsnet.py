@@ -1,0 +1,193 @@
+"""UPSNet (ResNet-FPN + RPN + box/mask heads + deformable FCN head + parameter-free panoptic head),
+inference branch of upsnet/models/resnet_upsnet.py:88-248 for the MI355X.
+
+`forward(data, label=None)` takes the reference's input dict ({'data': [1,3,H,W] fp32 BGR minus pixel
+means, 'im_info': [[H, W, scale]]}) and returns the reference's result dict (cls_probs, pred_boxes,
+mask_probs, fcn_outputs, cls_inds, panoptic_cls_inds, panoptic_cls_probs, panoptic_outputs).
+
+Two execution styles produce identical results:
+  * pipeline='fused' (default): proposals, detection selection, mask removal and the panoptic fusion
+    are device pipelines with fixed-size buffers + device-side counts; the host reads two counters
+    once (to size the mask-head batch) and nothing of size [k,H,W] is materialised.
+  * pipeline='modules': the reference's module-by-module dataflow (PyramidProposal -> ... ->
+    MaskRemoval -> SegTerm -> cat/argmax) through the drop-in modules, materialising what the
+    reference materialises. Used by the parity tests.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..config.config import config
+from ..operators.modules.mask_removal import MaskRemoval
+from ..operators.modules.mask_roi import MaskROI
+from ..operators.modules.pyramid_proposal import PyramidProposal
+from ..operators.modules.unary_logits import SegTerm
+from .fcn import FCNHead
+from .fpn import FPN
+from .rcnn import RCNN, MaskBranch
+from .resnet import ResNetBackbone, fold_frozen_bn, resnet_rcnn
+from .rpn import RPN
+
+
+class resnet_upsnet(resnet_rcnn):
+
+    def __init__(self, backbone_depth, pipeline='fused'):
+        super(resnet_upsnet, self).__init__()
+        self.pipeline = pipeline
+        self.num_classes = config.dataset.num_classes
+        self.num_seg_classes = config.dataset.num_seg_classes
+        self.num_reg_classes = (2 if config.network.cls_agnostic_bbox_reg else config.dataset.num_classes)
+
+        self.resnet_backbone = ResNetBackbone(backbone_depth)
+        self.fpn = FPN(feature_dim=config.network.fpn_feature_dim, with_norm=config.network.fpn_with_norm,
+                       upsample_method=config.network.fpn_upsample_method)
+        self.rpn = RPN(num_anchors=config.network.num_anchors, input_dim=config.network.fpn_feature_dim)
+        self.rcnn = RCNN(self.num_classes, self.num_reg_classes, dim_in=config.network.fpn_feature_dim,
+                         with_norm=config.network.rcnn_with_norm)
+        self.mask_branch = MaskBranch(self.num_classes, dim_in=config.network.fpn_feature_dim,
+                                      with_norm=config.network.rcnn_with_norm)
+        self.fcn_head = FCNHead(config.network.fpn_feature_dim, self.num_seg_classes,
+                                num_layers=config.network.fcn_num_layers, with_norm=config.network.fcn_with_norm,
+                                upsample_rate=4)
+        self.mask_roi = MaskROI(clip_boxes=True, bbox_class_agnostic=False, top_n=config.test.max_det,
+                                num_classes=self.num_classes, score_thresh=config.test.score_thresh)
+        self.enable_void = config.train.panoptic_box_keep_fraction < 1
+        self.mask_roi_panoptic = MaskROI(clip_boxes=True, bbox_class_agnostic=False, top_n=config.test.max_det,
+                                         num_classes=self.num_classes, nms_thresh=0.5, class_agnostic=True,
+                                         score_thresh=config.test.panoptic_score_thresh)
+        self.mask_removal = MaskRemoval(fraction_threshold=0.3)
+        self.seg_term = SegTerm(config.dataset.num_seg_classes)
+        self.pyramid_proposal = PyramidProposal(
+            feat_stride=config.network.rpn_feat_stride, scales=config.network.anchor_scales,
+            ratios=config.network.anchor_ratios, rpn_pre_nms_top_n=config.test.rpn_pre_nms_top_n,
+            rpn_post_nms_top_n=config.test.rpn_post_nms_top_n, threshold=config.test.rpn_nms_thresh,
+            rpn_min_size=config.test.rpn_min_size, individual_proposals=config.train.rpn_individual_proposals)
+
+    # ------------------------------------------------------------------ inference preparation
+    def prepare_inference(self, channels_last=True, fold_bn=True):
+        """eval(), freeze, optionally fold frozen BN and switch activations/weights to channels-last."""
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+        if fold_bn:
+            fold_frozen_bn(self)
+        if channels_last:
+            self.to(memory_format=torch.channels_last)
+        self._channels_last = channels_last
+        return self
+
+    # ------------------------------------------------------------------ shared trunk
+    def _trunk(self, data):
+        x = data['data']
+        if getattr(self, '_channels_last', False):
+            x = x.contiguous(memory_format=torch.channels_last)
+        res2, res3, res4, res5 = self.resnet_backbone(x)
+        pyramid = self.fpn(res2, res3, res4, res5)
+        rpn_cls_prob, rpn_bbox_pred = [], []
+        for feat in pyramid:
+            _, bbox_pred, cls_prob = self.rpn(feat)
+            rpn_cls_prob.append(cls_prob)
+            rpn_bbox_pred.append(bbox_pred)
+        return pyramid, rpn_cls_prob, rpn_bbox_pred
+
+    def forward(self, data, label=None):
+        if label is not None:
+            raise NotImplementedError("upsnet_amd implements the inference branch (label=None) only")
+        if self.pipeline == 'modules':
+            return self._forward_modules(data)
+        return self._forward_fused(data)
+
+    # ------------------------------------------------------------------ MI355X pipeline
+    def _forward_fused(self, data):
+        pyramid, rpn_cls_prob, rpn_bbox_pred = self._trunk(data)
+        feats = list(pyramid[:4])
+        im_info = data['im_info']
+        rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
+        fcn_output = self.fcn_head(*feats)['fcn_output']
+
+        rcnn_output = self.rcnn(feats, rois, n_rois)
+        cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
+        bbox_pred = rcnn_output['bbox_pred']
+
+        # both detection selections are launched back to back; ONE host read of the two counters
+        det_boxes, det_scores, det_cls, _, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
+        pan_boxes, pan_scores, pan_cls, _, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
+        n_det, n_pan = torch.cat([det_num, pan_num]).tolist()
+        det_boxes, det_scores, det_cls = det_boxes[:n_det], det_scores[:n_det], det_cls[:n_det]
+        pan_boxes, pan_scores, pan_cls = pan_boxes[:n_pan], pan_scores[:n_pan], pan_cls[:n_pan]
+
+        # one mask-head pass over both ROI sets (same weights)
+        mask_score = self.mask_branch(feats, torch.cat([det_boxes, pan_boxes], 0))
+        mask_prob = torch.sigmoid(mask_score[:n_det])
+        ms = config.network.mask_size
+        pan_logit = mask_score[n_det:].gather(1, pan_cls.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+
+        H, W = fcn_output.shape[2:]
+        keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
+        num_stuff = self.num_seg_classes - (self.num_classes - 1)
+        if n_pan > 256:  # beyond the fused kernel's instance table: reference-shaped materialising path
+            panoptic, sem = self._materialised_head(fcn_output, pan_boxes, pan_logit, pan_cls, keep, num_keep, real_keep)
+        else:
+            panoptic, sem = ops.panoptic_fuse(fcn_output, num_stuff, pan_boxes, pan_logit, pan_cls, keep, num_keep,
+                                              real_keep, self.seg_term.class_map.to(fcn_output.device), self.enable_void)
+        k = int(num_keep.item())
+        keep = keep[:k]
+        return {
+            'cls_probs': det_scores, 'pred_boxes': det_boxes, 'mask_probs': mask_prob, 'fcn_outputs': sem,
+            'cls_inds': det_cls, 'panoptic_cls_inds': pan_cls[keep], 'panoptic_cls_probs': pan_scores[keep],
+            'panoptic_outputs': panoptic,
+        }
+
+    def _materialised_head(self, fcn_output, pan_boxes, pan_logit, pan_cls, keep, num_keep, real_keep):
+        H, W = fcn_output.shape[2:]
+        k = int(num_keep.item())
+        energy = ops.mask_paste(pan_boxes[:, 1:], pan_logit, keep, num_keep, real_keep, k, (H, W))
+        kk = keep[:k]
+        _, seg_inst = self.seg_term(pan_cls[kk], fcn_output, pan_boxes[kk] * 4.0)
+        num_stuff = self.num_seg_classes - (self.num_classes - 1)
+        pan = ops.panoptic_argmax(fcn_output, num_stuff, seg_inst, energy, self.enable_void)
+        return pan, torch.max(fcn_output, dim=1)[1]
+
+    # ------------------------------------------------------------------ reference-shaped dataflow
+    def _forward_modules(self, data):
+        pyramid, rpn_cls_prob, rpn_bbox_pred = self._trunk(data)
+        feats = list(pyramid[:4])
+        im_info = data['im_info']
+        rois, _ = self.pyramid_proposal(rpn_cls_prob, rpn_bbox_pred, im_info)
+        fcn_output = self.fcn_head(*feats)
+        rcnn_output = self.rcnn(feats, rois)
+        cls_score, bbox_pred = rcnn_output['cls_score'], rcnn_output['bbox_pred']
+        cls_prob = F.softmax(cls_score, dim=1)
+
+        cls_prob_all, mask_rois, cls_idx = self.mask_roi(rois, bbox_pred, cls_prob, im_info)
+        mask_score = self.mask_branch(feats, mask_rois)
+        mask_prob = torch.sigmoid(mask_score)
+        results = {
+            'cls_probs': cls_prob_all, 'pred_boxes': mask_rois, 'mask_probs': mask_prob,
+            'fcn_outputs': torch.max(fcn_output['fcn_output'], dim=1)[1], 'cls_inds': cls_idx,
+        }
+        cls_prob, mask_rois, cls_idx = self.mask_roi_panoptic(rois, bbox_pred, cls_prob, im_info)
+        mask_score = self.mask_branch(feats, mask_rois)
+        ms = config.network.mask_size
+        mask_score = mask_score.gather(1, cls_idx.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+
+        keep_inds, mask_logits = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx,
+                                                   fcn_output['fcn_output'].shape[2:])
+        mask_rois = mask_rois[keep_inds]
+        cls_idx = cls_idx[keep_inds]
+        cls_prob = cls_prob[keep_inds]
+        seg_logits, seg_inst_logits = self.seg_term(cls_idx, fcn_output['fcn_output'], mask_rois * 4.0)
+        results.update({'panoptic_cls_inds': cls_idx, 'panoptic_cls_probs': cls_prob})
+        num_stuff = self.num_seg_classes - (self.num_classes - 1)
+        results['panoptic_outputs'] = ops.panoptic_argmax(fcn_output['fcn_output'], num_stuff, seg_inst_logits,
+                                                          mask_logits, self.enable_void)
+        return results
+
+
+def resnet_101_upsnet(**kw):
+    return resnet_upsnet([3, 4, 23, 3], **kw)
+
+
+def resnet_50_upsnet(**kw):
+    return resnet_upsnet([3, 4, 6, 3], **kw)

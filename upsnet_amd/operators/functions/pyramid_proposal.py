@@ -1,0 +1,61 @@
+"""PyramidProposalFunction with the reference's surface
+(upsnet/operators/functions/pyramid_proposal.py:24-222): constructed with the proposal parameters,
+called with 5 cls_prob + 5 bbox_pred tensors + im_info; returns (rois [K,5], scores [K]).
+
+The reference does all of this in numpy on the host; here the whole op is one device pipeline
+(csrc/proposal.hip). `forward_padded` is the sync-free form used by the model (fixed-size outputs
+plus a device-side count); `forward` slices to the exact K like the reference (one tiny D2H).
+"""
+import numpy as np
+import torch
+
+from ... import ops
+from ...rpn.generate_anchors import generate_anchors
+
+
+class PyramidProposalFunction(object):
+    def __init__(self, feat_stride, scales, ratios, rpn_pre_nms_top_n, rpn_post_nms_top_n, threshold, rpn_min_size,
+                 individual_proposals=False, batch_idx=0, use_softnms=False, crowd_gt_roi=None):
+        self.feat_stride = [int(s) for s in feat_stride]
+        self.scales = np.array(scales)
+        self.ratios = np.array(ratios)
+        self.num_anchors = len(self.scales) * len(self.ratios)
+        self.rpn_pre_nms_top_n = rpn_pre_nms_top_n
+        self.rpn_post_nms_top_n = rpn_post_nms_top_n
+        self.threshold = threshold
+        self.rpn_min_size = rpn_min_size
+        self.individual_proposals = individual_proposals
+        self.batch_idx = batch_idx
+        if not individual_proposals:
+            raise NotImplementedError("only rpn_individual_proposals=True (every shipped config) is implemented")
+        if use_softnms:
+            raise NotImplementedError("use_softnms is unreachable in the reference (soft_nms_wrapper undefined)")
+        if crowd_gt_roi is not None:
+            raise NotImplementedError("crowd_gt_roi is a training-time input")
+        self.anchors = np.stack([generate_anchors(stride=s, sizes=self.scales * s, aspect_ratios=self.ratios)
+                                 for s in self.feat_stride]).astype(np.float32)  # [L,A,4]
+
+    def forward_padded(self, cls_probs, bbox_preds, im_info):
+        """im_info: device float tensor [3]. Returns (rois [post,5], scores [post], num int32[1]) on device."""
+        if cls_probs[0].shape[0] > 1:
+            raise ValueError("Sorry, multiple images each device is not implemented")
+        rois, scores, num = ops.pyramid_proposals(cls_probs, bbox_preds, im_info, self.anchors, self.feat_stride,
+                                                  self.rpn_pre_nms_top_n, self.rpn_post_nms_top_n, self.threshold,
+                                                  self.rpn_min_size)
+        if self.batch_idx:
+            rois[:, 0] = float(self.batch_idx)
+        return rois, scores, num
+
+    def forward(self, cls_prob_p2, cls_prob_p3, cls_prob_p4, cls_prob_p5, cls_prob_p6, bbox_pred_p2, bbox_pred_p3,
+                bbox_pred_p4, bbox_pred_p5, bbox_pred_p6, im_info):
+        dev = cls_prob_p2.device
+        if not cls_prob_p2.is_cuda:
+            raise Exception('not implemented')
+        im = torch.as_tensor(np.asarray(im_info, dtype=np.float32).reshape(-1) if not isinstance(im_info, torch.Tensor)
+                             else im_info.float().reshape(-1)).to(dev)
+        rois, scores, num = self.forward_padded([cls_prob_p2, cls_prob_p3, cls_prob_p4, cls_prob_p5, cls_prob_p6],
+                                                [bbox_pred_p2, bbox_pred_p3, bbox_pred_p4, bbox_pred_p5, bbox_pred_p6], im)
+        k = int(num.item())
+        return rois[:k], scores[:k]
+
+    __call__ = forward

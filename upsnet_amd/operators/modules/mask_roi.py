@@ -1,0 +1,45 @@
+"""MaskROI (upsnet/operators/modules/mask_roi.py:23-146): detection selection on the device.
+
+forward(rois, bbox_delta, cls_prob, im_info) -> (scores [n], boxes [n,5], cls_idx [n] int64).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...config.config import config
+
+
+class MaskROI(nn.Module):
+
+    def __init__(self, clip_boxes, bbox_class_agnostic, top_n, num_classes, nms_thresh=None, class_agnostic=False,
+                 score_thresh=None):
+        super(MaskROI, self).__init__()
+        if not clip_boxes:
+            raise NotImplementedError("clip_boxes=False is never used by the reference models")
+        self.clip_boxes = clip_boxes
+        self.bbox_class_agnostic = bbox_class_agnostic
+        self.top_n = top_n
+        self.num_classes = num_classes
+        self.nms_thresh = nms_thresh if nms_thresh is not None else config.test.nms_thresh
+        self.class_agnostic = class_agnostic
+        self.nms_classes = num_classes if not class_agnostic else 2
+        self.score_thresh = score_thresh if score_thresh is not None else config.test.score_thresh
+
+    def forward_padded(self, bottom_rois, bbox_delta, cls_prob, im_info, num_rois_dev=None):
+        """Sync-free variant: fixed-capacity (boxes, scores, cls_idx, src_roi, num) device tensors."""
+        dev = bottom_rois.device
+        if isinstance(im_info, torch.Tensor):
+            im = im_info.float().reshape(-1)[:3].to(dev)
+        else:
+            im = torch.from_numpy(np.asarray(im_info, dtype=np.float32).reshape(-1)[:3].copy()).to(dev, non_blocking=True)
+        return ops.mask_roi(bottom_rois.detach(), bbox_delta.detach(), cls_prob.detach(), im, self.class_agnostic,
+                            self.score_thresh, self.nms_thresh, config.test.max_det, config.network.bbox_reg_weights,
+                            num_rois_dev)
+
+    def forward(self, bottom_rois, bbox_delta, cls_prob, im_info, nms=True, cls_score=None, cls_label=None):
+        if cls_score is not None or cls_label is not None:
+            raise NotImplementedError("cls_score / cls_label are training-time inputs")
+        boxes, scores, cls, src, num = self.forward_padded(bottom_rois, bbox_delta, cls_prob, im_info)
+        n = int(num.item())
+        return scores[:n], boxes[:n], cls[:n]

@@ -1,0 +1,47 @@
+"""PyramidProposal module (upsnet/operators/modules/pyramid_proposal.py:23-67).
+
+forward(cls_prob_list, bbox_pred_list, im_info[B,3]) -> (rois [K,5], scores [K]), K <= rpn_post_nms_top_n,
+ranked by score. The per-level NMS, the concatenation and the final ranking all happen on the device.
+"""
+import numpy as np
+import torch
+from torch.nn.modules.module import Module
+
+from ..functions.pyramid_proposal import PyramidProposalFunction
+
+
+class PyramidProposal(Module):
+    def __init__(self, feat_stride, scales, ratios, rpn_pre_nms_top_n, rpn_post_nms_top_n, threshold, rpn_min_size,
+                 individual_proposals=False, use_softnms=False):
+        super(PyramidProposal, self).__init__()
+        self.feat_stride = feat_stride
+        self.scales = scales
+        self.ratios = ratios
+        self.rpn_pre_nms_top_n = rpn_pre_nms_top_n
+        self.rpn_post_nms_top_n = rpn_post_nms_top_n
+        self.threshold = threshold
+        self.rpn_min_size = rpn_min_size
+        self.individual_proposals = individual_proposals
+        self.use_softnms = use_softnms
+        self._fn = PyramidProposalFunction(feat_stride, scales, ratios, rpn_pre_nms_top_n, rpn_post_nms_top_n, threshold,
+                                           rpn_min_size, individual_proposals, 0, use_softnms, None)
+
+    def _im_info_dev(self, im_info, dev):
+        if isinstance(im_info, torch.Tensor):
+            t = im_info.float().reshape(-1, 3)
+        else:
+            t = torch.from_numpy(np.asarray(im_info, dtype=np.float32).reshape(-1, 3))
+        if t.shape[0] != 1:
+            raise ValueError("Sorry, multiple images each device is not implemented")
+        return t[0].to(dev, non_blocking=True)
+
+    def forward_padded(self, cls_prob, bbox_pred, im_info):
+        """Sync-free variant: (rois [post,5], scores [post], num int32[1]) all on device."""
+        return self._fn.forward_padded(list(cls_prob), list(bbox_pred), self._im_info_dev(im_info, cls_prob[0].device))
+
+    def forward(self, cls_prob, bbox_pred, im_info, roidb=None):
+        if roidb is not None:
+            raise NotImplementedError("roidb (crowd filtering) is a training-time input")
+        rois, scores, num = self.forward_padded(cls_prob, bbox_pred, im_info)
+        k = int(num.item())
+        return rois[:k], scores[:k]

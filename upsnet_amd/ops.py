@@ -1,0 +1,337 @@
+"""Functional wrappers over the C ABI (tensor plumbing only: allocation, layout views, stream).
+
+Every function here launches hand-written HIP kernels from libupsnet_hip.so on the current torch
+stream. Nothing falls back to PyTorch/CPU; non-CUDA inputs raise (as the reference's Functions do,
+functions/deform_conv.py:40-41, functions/roialign.py:34-35).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, f32c, float_array, int_array, lib, nhwc, ptr, ptr_array, require_cuda, stream
+
+
+# bench.py sets PROFILE['enabled'] to bracket the dominant kernel with events on the launch stream
+PROFILE = {'enabled': False, 'events': []}
+
+
+def _ws(nbytes, device):
+    return torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- ROIAlign
+def roi_align_nchw(features, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=2):
+    """Drop-in for roi_align_cuda.roi_align_forward (NCHW in, [N,C,PH,PW] out)."""
+    require_cuda(features, rois)
+    features, rois = f32c(features), f32c(rois)
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise RuntimeError("rois must be [N,5]")
+    B, C, H, W = features.shape
+    N = rois.shape[0]
+    out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=features.device)
+    check(lib().upsnet_roi_align_forward(stream(), ptr(features), float(spatial_scale), N, H, W, C, int(pooled_h),
+                                         int(pooled_w), int(sampling_ratio), ptr(rois), ptr(out)), "roi_align_forward")
+    return out
+
+
+def roi_align_nhwc(features, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=2):
+    """ROIAlign on channels-last features; returns a channels_last [N,C,PH,PW] tensor."""
+    require_cuda(features, rois)
+    features, rois = nhwc(features.float()), f32c(rois)
+    B, C, H, W = features.shape
+    N = rois.shape[0]
+    out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=features.device,
+                      memory_format=torch.channels_last)
+    check(lib().upsnet_roi_align_forward_nhwc(stream(), ptr(features), B, H, W, C, float(spatial_scale), ptr(rois), N,
+                                              int(pooled_h), int(pooled_w), int(sampling_ratio), ptr(out)),
+          "roi_align_forward_nhwc")
+    return out
+
+
+def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=2, num_rois_dev=None,
+                  return_levels=False):
+    """FPNRoIAlign.forward on device: feats = 4 logical-NCHW tensors (batch 1), rois [N,5].
+
+    Returns a channels_last [N,C,PH,PW] tensor in the original ROI order."""
+    require_cuda(rois, *feats)
+    assert len(feats) == 4 and len(spatial_scale) == 4
+    feats = [nhwc(f.float()) for f in feats]
+    rois = f32c(rois)
+    C = feats[0].shape[1]
+    for f in feats:
+        if f.shape[0] != 1 or f.shape[1] != C:
+            raise RuntimeError("fpn_roi_align: batch 1 and equal channel counts required")
+    N = rois.shape[0]
+    dev = rois.device
+    out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    levels = torch.empty((max(N, 1),), dtype=torch.int32, device=dev) if return_levels else None
+    check(lib().upsnet_fpn_roi_align_forward(stream(), ptr_array(feats), int_array([f.shape[2] for f in feats]),
+                                             int_array([f.shape[3] for f in feats]), float_array(spatial_scale), C,
+                                             ptr(rois), N, ptr(num_rois_dev), int(pooled_h), int(pooled_w),
+                                             int(sampling_ratio), ptr(out), ptr(levels)), "fpn_roi_align_forward")
+    return (out, levels[:N]) if return_levels else out
+
+
+# ----------------------------------------------------------------------------- deformable conv
+def out_hw(H, W, k, pad, stride, dil):
+    return ((H + 2 * pad[0] - dil[0] * (k[0] - 1) - 1) // stride[0] + 1,
+            (W + 2 * pad[1] - dil[1] * (k[1] - 1) - 1) // stride[1] + 1)
+
+
+def deform_im2col(data_im, data_offset, im_shape, col_shape, kernel_shape, pad, stride, dilation, parallel_imgs,
+                  deformable_group, data_col):
+    """Drop-in for deform_conv_cuda.deform_im2col (deform_conv_cuda.cpp:49-68); fills data_col in place."""
+    require_cuda(data_im, data_offset, data_col)
+    assert data_im.is_contiguous() and data_offset.is_contiguous() and data_col.is_contiguous()
+    check(lib().upsnet_deform_im2col(stream(), ptr(data_im), ptr(data_offset), int(im_shape[1]), int(im_shape[2]),
+                                     int(im_shape[3]), int(kernel_shape[0]), int(kernel_shape[1]), int(pad[0]), int(pad[1]),
+                                     int(stride[0]), int(stride[1]), int(dilation[0]), int(dilation[1]), int(parallel_imgs),
+                                     int(deformable_group), ptr(data_col)), "deform_im2col")
+    return 1
+
+
+def mod_deform_im2col(data_im, data_offset, data_mask, im_shape, col_shape, kernel_shape, pad, stride, dilation,
+                      deformable_group, data_col):
+    """Drop-in for mod_deform_conv_cuda.mod_deform_im2col (mod_deform_conv_cuda.cpp:51-74), batch 1."""
+    require_cuda(data_im, data_offset, data_mask, data_col)
+    assert data_im.is_contiguous() and data_offset.is_contiguous() and data_mask.is_contiguous()
+    check(lib().upsnet_mod_deform_im2col(stream(), ptr(data_im), ptr(data_offset), ptr(data_mask), 1, int(im_shape[1]),
+                                         int(im_shape[2]), int(im_shape[3]), int(col_shape[1]), int(col_shape[2]),
+                                         int(kernel_shape[0]), int(kernel_shape[1]), int(pad[0]), int(pad[1]),
+                                         int(stride[0]), int(stride[1]), int(dilation[0]), int(dilation[1]),
+                                         int(deformable_group), ptr(data_col)), "mod_deform_im2col")
+    return 1
+
+
+def pack_dcn_weight(weight):
+    """[Cout,Cin,kh,kw] -> [kh*kw*Cin, Cout] (tap-major rows) for the fused kernel."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cout, Cin, kh, kw = weight.shape
+    wp = torch.empty((kh * kw * Cin, Cout), dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_deform_conv_pack_weight(stream(), ptr(weight), Cout, Cin, kh, kw, ptr(wp)), "deform_conv_pack_weight")
+    return wp
+
+
+def fused_dcn_supported(cin, cout, deformable_groups, groups):
+    return groups == 1 and deformable_groups == 1 and cin % 32 == 0 and cout in (32, 64, 128, 256)
+
+
+def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, dil, masks=None, relu=False):
+    """Fused deformable conv over up to 4 maps sharing weights. xs/offsets/masks: lists of logical NCHW
+    tensors with batch 1; returns channels_last outputs [1,Cout,Ho,Wo]."""
+    require_cuda(wpack, *xs)
+    n = len(xs)
+    assert 1 <= n <= 4 and len(offsets) == n
+    xs = [nhwc(x.float()) for x in xs]
+    offsets = [nhwc(o.float()) for o in offsets]
+    if masks is not None:
+        masks = [nhwc(m.float()) for m in masks]
+    outs = []
+    for x, o in zip(xs, offsets):
+        if x.shape[0] != 1 or x.shape[1] != cin:
+            raise RuntimeError("deform_conv_fused: batch 1 / Cin mismatch")
+        Ho, Wo = out_hw(x.shape[2], x.shape[3], ksize, pad, stride, dil)
+        if tuple(o.shape) != (1, 2 * ksize[0] * ksize[1], Ho, Wo):
+            raise RuntimeError("deform_conv_fused: offset shape %s != %s" % (tuple(o.shape), (1, 2 * ksize[0] * ksize[1], Ho, Wo)))
+        outs.append(torch.empty((1, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last))
+    b = None if bias is None else f32c(bias)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_deform_conv_forward_nhwc(stream(), n, ptr_array(xs), ptr_array(offsets),
+                                                ptr_array(masks) if masks is not None else None, ptr_array(outs),
+                                                int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
+                                                int(cin), int(cout), ksize[0], ksize[1], pad[0], pad[1], stride[0], stride[1],
+                                                dil[0], dil[1], 1, ptr(wpack), ptr(b), int(bool(relu))),
+          "deform_conv_forward_nhwc")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('dcn_fused', ev0, ev1))
+    return outs
+
+
+# ----------------------------------------------------------------------------- NMS
+def nms_host(sorted_dets, thresh, device_id=0):
+    """`_nms` drop-in: numpy float32 [N,>=4] sorted by score -> kept indices (numpy int32)."""
+    d = np.ascontiguousarray(sorted_dets, dtype=np.float32)
+    n = d.shape[0]
+    keep = np.zeros((max(n, 1),), np.int32)
+    num = np.zeros((1,), np.int32)
+    check(lib().upsnet_nms_host(keep.ctypes.data_as(_lib.c_void_p), num.ctypes.data_as(_lib.c_void_p),
+                                d.ctypes.data_as(_lib.c_void_p), n, d.shape[1] if d.ndim == 2 else 5, float(thresh),
+                                int(device_id)), "nms_host")
+    return keep[:int(num[0])]
+
+
+def nms_batched(boxes, scores, counts, thresh, pre_removed=None):
+    """boxes [P,nmax,4], scores [P,nmax], counts [P] int32 (device) -> keep_idx [P,nmax] int32, keep_cnt [P]."""
+    require_cuda(boxes, scores, counts)
+    boxes, scores = f32c(boxes), f32c(scores)
+    counts = counts.to(torch.int32).contiguous()
+    Pn, nmax = scores.shape
+    dev = boxes.device
+    keep = torch.empty((Pn, nmax), dtype=torch.int32, device=dev)
+    cnt = torch.empty((Pn,), dtype=torch.int32, device=dev)
+    ws = _ws(lib().upsnet_nms_workspace_bytes(Pn, nmax), dev)
+    pr = None if pre_removed is None else pre_removed.to(torch.uint8).contiguous()
+    check(lib().upsnet_nms_batched(stream(), ptr(boxes), ptr(scores), ptr(counts), ptr(pr), Pn, nmax, float(thresh),
+                                   ptr(keep), ptr(cnt), ptr(ws)), "nms_batched")
+    return keep, cnt
+
+
+def gpu_nms(dets, thresh):
+    """gpu_nms (gpu_nms.pyx:23-38) on a device tensor [N,5]; returns a device int64 tensor of kept indices
+    (visiting order). One tiny D2H (the count) to size the result."""
+    require_cuda(dets)
+    dets = f32c(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=dets.device)
+    counts = torch.full((1,), n, dtype=torch.int32, device=dets.device)
+    keep, cnt = nms_batched(dets[None, :, :4], dets[None, :, 4], counts, thresh)
+    return keep[0, :int(cnt.item())].long()
+
+
+def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """cpu_soft_nms semantics on device: returns (boxes', inds[:N'])."""
+    require_cuda(boxes)
+    b = f32c(boxes).clone()
+    n = b.shape[0]
+    inds = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    if n:
+        ws = _ws(lib().upsnet_soft_nms_workspace_bytes(n), b.device)
+        check(lib().upsnet_soft_nms(stream(), ptr(b), ptr(inds), n, float(sigma), float(Nt), float(threshold), int(method),
+                                    ptr(n_out), ptr(ws)), "soft_nms")
+    return b, inds[:int(n_out.item())]
+
+
+# ----------------------------------------------------------------------------- proposals
+def pyramid_proposals(cls_probs, bbox_preds, im_info, anchors, strides, pre_nms_top_n, post_nms_top_n, nms_thresh,
+                      min_size):
+    """Device-side PyramidProposal. cls_probs[l] [1,A,H,W], bbox_preds[l] [1,4A,H,W]; im_info device [3].
+    Returns fixed-size (rois [post,5], scores [post], num device int32)."""
+    require_cuda(im_info, *cls_probs)
+    L = len(cls_probs)
+    cls_probs = [f32c(c) for c in cls_probs]
+    bbox_preds = [f32c(b) for b in bbox_preds]
+    A = cls_probs[0].shape[1]
+    Hs = [c.shape[2] for c in cls_probs]
+    Ws = [c.shape[3] for c in cls_probs]
+    for c, b in zip(cls_probs, bbox_preds):
+        if c.shape[0] != 1 or b.shape[1] != 4 * A:
+            raise ValueError("Sorry, multiple images each device is not implemented")  # pyramid_proposal.py:47-49
+    dev = im_info.device
+    hs, ws_ = int_array(Hs), int_array(Ws)
+    nbytes = lib().upsnet_proposal_workspace_bytes(L, hs, ws_, A, int(pre_nms_top_n), int(post_nms_top_n))
+    if nbytes == 0:
+        raise RuntimeError("pyramid_proposals: unsupported level count")
+    ws = _ws(nbytes, dev)
+    rois = torch.empty((post_nms_top_n, 5), dtype=torch.float32, device=dev)
+    scores = torch.empty((post_nms_top_n,), dtype=torch.float32, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    anc = float_array(np.asarray(anchors, np.float32).reshape(-1).tolist())
+    check(lib().upsnet_pyramid_proposals(stream(), L, ptr_array(cls_probs), ptr_array(bbox_preds), hs, ws_,
+                                         int_array(strides), anc, A, ptr(f32c(im_info)), int(pre_nms_top_n),
+                                         int(post_nms_top_n), float(nms_thresh), float(min_size), ptr(rois), ptr(scores),
+                                         ptr(num), ptr(ws)), "pyramid_proposals")
+    return rois, scores, num
+
+
+# ----------------------------------------------------------------------------- detection selection
+def mask_roi(rois, bbox_delta, cls_prob, im_info, class_agnostic, score_thresh, nms_thresh, max_det, reg_weights,
+             num_rois_dev=None):
+    """Device-side MaskROI: returns fixed-capacity (boxes [cap,5], scores [cap], cls [cap] int64, src [cap] int32,
+    num device int32)."""
+    require_cuda(rois, bbox_delta, cls_prob, im_info)
+    rois, bbox_delta, cls_prob = f32c(rois), f32c(bbox_delta), f32c(cls_prob)
+    N, C = cls_prob.shape
+    dev = rois.device
+    cap = lib().upsnet_mask_roi_capacity(N, C, int(class_agnostic))
+    boxes = torch.empty((cap, 5), dtype=torch.float32, device=dev)
+    scores = torch.empty((cap,), dtype=torch.float32, device=dev)
+    cls = torch.empty((cap,), dtype=torch.int64, device=dev)
+    src = torch.empty((cap,), dtype=torch.int32, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = _ws(lib().upsnet_mask_roi_workspace_bytes(N, C, int(class_agnostic)), dev)
+    check(lib().upsnet_mask_roi(stream(), ptr(rois), ptr(bbox_delta), ptr(cls_prob), N, ptr(num_rois_dev), C,
+                                ptr(f32c(im_info.reshape(-1))), int(class_agnostic), float(score_thresh), float(nms_thresh),
+                                int(max_det), float_array(reg_weights), ptr(boxes), ptr(scores), ptr(cls), ptr(src),
+                                ptr(num), ptr(ws)), "mask_roi")
+    return boxes, scores, cls, src, num
+
+
+# ----------------------------------------------------------------------------- panoptic head
+def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, im_shape, fraction_threshold=0.3):
+    """Device-side MaskRemoval selection. Returns (keep_inds [m] int64, num_keep, real_keep) device tensors."""
+    require_cuda(mask_rois4, cls_prob, mask_logit, cls_idx)
+    mask_rois4, cls_prob = f32c(mask_rois4), f32c(cls_prob).reshape(-1)
+    m = mask_rois4.shape[0]
+    mask_logit = f32c(mask_logit).reshape(m, -1)
+    ms = int(round(mask_logit.shape[1] ** 0.5))
+    cls_idx = cls_idx.to(torch.int64).contiguous().reshape(-1)
+    H, W = int(im_shape[0]), int(im_shape[1])
+    dev = mask_rois4.device
+    keep = torch.zeros((m,), dtype=torch.int64, device=dev)
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    real = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = _ws(lib().upsnet_mask_removal_workspace_bytes(m, num_thing_classes, H, W), dev)
+    check(lib().upsnet_mask_removal(stream(), ptr(mask_rois4), ptr(cls_prob), ptr(mask_logit), ptr(cls_idx), m, ms,
+                                    int(num_thing_classes), H, W, float(fraction_threshold), ptr(keep), ptr(num), ptr(real),
+                                    ptr(ws)), "mask_removal")
+    return keep, num, real
+
+
+def mask_paste(mask_rois4, mask_logit, keep, num, real, k, im_shape):
+    require_cuda(mask_rois4, mask_logit)
+    mask_rois4 = f32c(mask_rois4)
+    m = mask_rois4.shape[0]
+    mask_logit = f32c(mask_logit).reshape(m, -1)
+    ms = int(round(mask_logit.shape[1] ** 0.5))
+    H, W = int(im_shape[0]), int(im_shape[1])
+    out = torch.empty((1, k, H, W), dtype=torch.float32, device=mask_rois4.device)
+    check(lib().upsnet_mask_paste(stream(), ptr(mask_rois4), ptr(mask_logit), ptr(keep), ptr(num), ptr(real), int(k), ms, H, W,
+                                  ptr(out)), "mask_paste")
+    return out
+
+
+def seg_term(fcn_output, boxes4, cls, class_map):
+    require_cuda(fcn_output, boxes4, cls, class_map)
+    fcn = f32c(fcn_output)
+    _, S, H, W = fcn.shape
+    boxes4 = f32c(boxes4)
+    k = boxes4.shape[0]
+    out = torch.empty((1, k, H, W), dtype=torch.float32, device=fcn.device)
+    check(lib().upsnet_seg_term(stream(), ptr(fcn), S, H, W, ptr(boxes4), ptr(cls.to(torch.int64).contiguous()),
+                                ptr(class_map), k, ptr(out)), "seg_term")
+    return out
+
+
+def panoptic_argmax(fcn_output, num_stuff, seg_inst, mask_energy, enable_void=True):
+    require_cuda(fcn_output, seg_inst, mask_energy)
+    fcn, seg_inst, mask_energy = f32c(fcn_output), f32c(seg_inst), f32c(mask_energy)
+    _, S, H, W = fcn.shape
+    k = seg_inst.shape[1]
+    pan = torch.empty((1, H, W), dtype=torch.int64, device=fcn.device)
+    check(lib().upsnet_panoptic_argmax(stream(), ptr(fcn), S, H, W, int(num_stuff), ptr(seg_inst), ptr(mask_energy), k,
+                                       int(bool(enable_void)), ptr(pan)), "panoptic_argmax")
+    return pan
+
+
+def panoptic_fuse(fcn_output, num_stuff, mask_rois5, mask_logit, cls_idx, keep, num, real, class_map, enable_void=True,
+                  want_sem=True):
+    """Fused head: returns (panoptic [1,H,W] int64, semantic argmax [1,H,W] int64 or None)."""
+    require_cuda(fcn_output, mask_rois5, mask_logit, cls_idx)
+    fcn = f32c(fcn_output)
+    _, S, H, W = fcn.shape
+    mask_rois5 = f32c(mask_rois5)
+    m = mask_rois5.shape[0]
+    mask_logit = f32c(mask_logit).reshape(m, -1)
+    ms = int(round(mask_logit.shape[1] ** 0.5))
+    pan = torch.empty((1, H, W), dtype=torch.int64, device=fcn.device)
+    sem = torch.empty((1, H, W), dtype=torch.int64, device=fcn.device) if want_sem else None
+    check(lib().upsnet_panoptic_fuse(stream(), ptr(fcn), S, H, W, int(num_stuff), ptr(mask_rois5), ptr(mask_logit),
+                                     ptr(cls_idx.to(torch.int64).contiguous()), ptr(keep), ptr(num), ptr(real), int(min(m, 256)),
+                                     ms, ptr(class_map), int(bool(enable_void)), ptr(pan), ptr(sem)), "panoptic_fuse")
+    return pan, sem

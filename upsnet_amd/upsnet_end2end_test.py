@@ -1,0 +1,123 @@
+"""Inference driver: the MI355X counterpart of upsnet/upsnet_end2end_test.py:155-312.
+
+The reference builds the model once, wraps it in a single-process threaded DataParallel that re-broadcasts
+every parameter on every forward (lib/utils/data_parallel.py:103-125), feeds ONE image per GPU per
+iteration, times `forward + torch.cuda.synchronize()` as `net_time` (skipping the first 10 iterations,
+upsnet_end2end_test.py:244-252) and leaves the outputs on their GPUs.
+
+Here: one PROCESS per GPU (torchrun), weights built/loaded once per rank, image i goes to rank
+i mod world_size (independent units, no data-path collective), the same net_time window per image, and
+ONE RCCL all_gather of the small per-image results (uint8 label maps + counters) after the loop.
+Datasets, cv2 post-processing and PQ evaluation are out of scope;
+inputs are the synthetic images of upsnet_amd.synthetic.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .config.config import CITYSCAPES_R50, COCO_R101_DCN, config, update_config_dict
+from .synthetic import build_model, make_image
+from .utils.timer import Timer
+
+WORKLOADS = {
+    # name: (config preset, unpadded H, W, cls_gain)
+    'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 60.0),
+    'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 60.0),
+}
+
+
+def init_distributed():
+    """torchrun environment -> (rank, world, device). Backend nccl == RCCL on ROCm; gloo for CPU tests."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl' if use_cuda else 'gloo', rank=rank, world_size=world)
+    return rank, world, (torch.device('cuda', local) if use_cuda else torch.device('cpu'))
+
+
+def shard_indices(num_images, rank, world):
+    """image i -> rank i mod world (the reference's one-image-per-GPU round robin)."""
+    return list(range(rank, num_images, world))
+
+
+def gather_results(local, world, device):
+    """One all_gather of fixed-size per-image records: local = list of (image_id, label_map uint8 [H,W], n_inst).
+    Returns on every rank a dict image_id -> (label_map, n_inst). Ranks may hold different counts: pad."""
+    if world == 1:
+        return {i: (lab, n) for i, lab, n in local}
+    counts = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    mx = int(max(c.item() for c in all_counts))
+    H, W = local[0][1].shape if local else (1, 1)
+    labs = torch.zeros((mx, H, W), dtype=torch.uint8, device=device)
+    meta = torch.full((mx, 2), -1, dtype=torch.int64, device=device)
+    for j, (i, lab, n) in enumerate(local):
+        labs[j] = lab.to(device)
+        meta[j, 0], meta[j, 1] = i, n
+    g_labs = [torch.zeros_like(labs) for _ in range(world)]
+    g_meta = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(g_labs, labs)
+    dist.all_gather(g_meta, meta)
+    out = {}
+    for r in range(world):
+        for j in range(mx):
+            i = int(g_meta[r][j, 0])
+            if i >= 0:
+                out[i] = (g_labs[r][j], int(g_meta[r][j, 1]))
+    return out
+
+
+def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, seed=0, pipeline='fused', gather=True,
+                on_step=None):
+    """Run `steps` timed images per rank (after `warmup` untimed ones). Returns a dict with the whole-job
+    wall time (max over ranks, barrier + sync bracketed), per-image net_time samples and the gathered results."""
+    rank, world, device = init_distributed()
+    preset, H, W, gain = WORKLOADS[workload]
+    update_config_dict(preset)
+    model = build_model(cls_gain=gain, device=device, pipeline=pipeline)
+    # each rank owns its images: image id = step * world + rank, seeded by id
+    my_ids = [s * world + rank for s in range(steps)]
+    pool = [make_image(H, W, seed=seed + j, device=device) for j in range(4)]  # 4 distinct images resident in HBM
+
+    def get(i):
+        return pool[i % 4]
+
+    net_timer = Timer()
+    outs = []
+    with torch.no_grad():
+        for w in range(warmup):
+            model(get(w))
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s, i in enumerate(my_ids):
+            net_timer.tic()
+            out = model(get(i))
+            torch.cuda.synchronize(device)
+            net_timer.toc()
+            outs.append((i, out['panoptic_outputs'][0].to(torch.uint8), int(out['panoptic_cls_inds'].numel())))
+            if on_step is not None:
+                on_step(s, out)
+        results = gather_results(outs, world, device) if gather else None
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return dict(rank=rank, world=world, elapsed=float(t.item()), net_times=list(net_timer.samples), results=results,
+                last_out=out, model=model, image=get(my_ids[-1]), H=H, W=W)
