@@ -70,6 +70,45 @@ def forward_oracle(model, data):
     return dict(n_rois=K, n_det=n_det, n_inst=int(head['k']), taps=taps)
 
 
+def check_taps(taps, enable_void=True):
+    """Stage-by-stage parity on the tensors recorded during ONE product forward (model.taps):
+    every custom-op stage is recomputed by the oracle from the recorded inputs of that stage and compared
+    with the recorded outputs. Library convolutions / GEMMs are not re-executed, so their run-to-run
+    non-determinism (MIOpen / hipBLASLt) cannot leak into the comparison.
+    Returns a dict name -> bool (all must be True) plus counters."""
+    cfg = _cfg()
+    C, S = cfg.dataset.num_classes, cfg.dataset.num_seg_classes
+    im_info = np.asarray(taps['im_info'], np.float32).reshape(-1, 3)
+    res = {}
+    # 1. proposals
+    rois, scores = oops.pyramid_proposal([_np(t) for t in taps['rpn_cls_prob']], [_np(t) for t in taps['rpn_bbox_pred']],
+                                         im_info[0], cfg.network.rpn_feat_stride, cfg.network.anchor_scales,
+                                         cfg.network.anchor_ratios, cfg.test.rpn_pre_nms_top_n, cfg.test.rpn_post_nms_top_n,
+                                         cfg.test.rpn_nms_thresh, cfg.test.rpn_min_size)
+    n = int(taps['n_rois'].item()) if isinstance(taps['n_rois'], torch.Tensor) else int(taps['n_rois'])
+    got_rois = _np(taps['rois'])[:n]
+    res['proposals'] = (n == rois.shape[0]) and np.array_equal(got_rois, rois)
+    # 2. detection selection (both variants) from the recorded box-head outputs
+    cls_prob, bbox_pred = _np(taps['cls_prob'])[:n], _np(taps['bbox_pred'])[:n]
+    ds, db, dc = oops.mask_roi(got_rois, bbox_pred, cls_prob, im_info, C, cfg.test.nms_thresh, cfg.test.score_thresh,
+                               cfg.test.max_det, False, cfg.network.bbox_reg_weights)
+    ps, pb, pc = oops.mask_roi(got_rois, bbox_pred, cls_prob, im_info, C, 0.5, cfg.test.panoptic_score_thresh,
+                               cfg.test.max_det, True, cfg.network.bbox_reg_weights)
+    res['mask_roi'] = (np.array_equal(_np(taps['det_boxes']), db) and np.array_equal(_np(taps['det_scores']), ds) and
+                       np.array_equal(taps['det_cls'].cpu().numpy(), dc))
+    res['mask_roi_panoptic'] = (np.array_equal(_np(taps['pan_boxes']), pb) and np.array_equal(_np(taps['pan_scores']), ps) and
+                                np.array_equal(taps['pan_cls'].cpu().numpy(), pc))
+    # 3. panoptic head from the recorded mask logits / semantic logits
+    head = oops.panoptic_head(_np(taps['fcn_output']), _np(taps['pan_boxes']), _np(taps['pan_scores']), _np(taps['pan_logit']),
+                              taps['pan_cls'].cpu().numpy(), S, C, enable_void=enable_void)
+    res['mask_removal'] = np.array_equal(taps['keep'].cpu().numpy(), head['keep_inds'])
+    res['panoptic'] = np.array_equal(taps['panoptic'].cpu().numpy()[0], head['panoptic'])
+    res['semantic'] = np.array_equal(taps['sem'].cpu().numpy()[0], head['sem'])
+    res['counts'] = dict(n_rois=n, n_det=int(db.shape[0]), n_pan=int(pb.shape[0]), n_inst=int(head['k']),
+                         label_mismatch=int((taps['panoptic'].cpu().numpy()[0] != head['panoptic']).sum()))
+    return res
+
+
 # ----------------------------------------------------------------------------- pure CPU forward
 def _dcn_cpu(layer, x, relu=True):
     """DeformConvWithOffset on the host: torch-CPU offset conv + oracle im2col + GEMM."""

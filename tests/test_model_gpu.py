@@ -1,5 +1,11 @@
-"""End-to-end GPU tests: the fused MI355X pipeline vs the reference-shaped module dataflow, and the
-whole forward vs the oracle composite on a small synthetic image."""
+"""End-to-end GPU tests on seeded synthetic weights + image.
+
+Library convolutions / GEMMs (MIOpen, hipBLASLt) are not bit-repeatable run to run on this stack, so the
+end-to-end parity claim is made stage-wise on the tensors recorded during ONE forward (model.taps): every
+custom-op stage must reproduce the oracle bit-for-bit from that stage's recorded inputs
+(oracle.forward.check_taps). Both execution styles (fused MI355X pipeline / reference-shaped modules) are
+checked this way, which also proves them equivalent.
+"""
 import numpy as np
 import pytest
 import torch
@@ -12,45 +18,63 @@ def setup():
     from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
     update_config_dict(CITYSCAPES_R50)
     from upsnet_amd.synthetic import build_model, make_image
-    model = build_model(cls_gain=60.0)
+    model = build_model(cls_gain=0.3)
     data = make_image(256, 512, seed=0, device='cuda')
     return model, data
 
 
-def test_fused_equals_modules(setup):
+@pytest.mark.parametrize("pipeline", ["fused", "modules"])
+def test_stagewise_parity(setup, pipeline):
+    from oracle.forward import check_taps
     model, data = setup
-    with torch.no_grad():
-        model.pipeline = 'fused'
-        a = model(data)
-        model.pipeline = 'modules'
-        b = model(data)
-        model.pipeline = 'fused'
-    for k in ('cls_probs', 'pred_boxes', 'cls_inds', 'panoptic_cls_inds', 'panoptic_cls_probs', 'fcn_outputs', 'panoptic_outputs'):
-        assert torch.equal(a[k], b[k]), k
-    np.testing.assert_allclose(a['mask_probs'].cpu().numpy(), b['mask_probs'].cpu().numpy(), rtol=1e-4, atol=1e-5)
-
-
-def test_forward_vs_oracle_composite(setup):
-    from oracle.forward import forward_oracle
-    model, data = setup
+    model.pipeline = pipeline
+    model.taps = {}
     with torch.no_grad():
         out = model(data)
-    ref = forward_oracle(model, data)
-    # identical conv backend is not available on the CPU: compare through the tolerance-free stages by
-    # feeding the oracle the device's conv outputs (forward_oracle(..., taps=...)) -- see oracle/forward.py
-    assert ref['n_rois'] > 0
-    taps = ref['taps']
-    assert np.array_equal(out['pred_boxes'].cpu().numpy(), taps['pred_boxes'])
-    assert np.array_equal(out['cls_inds'].cpu().numpy(), taps['cls_inds'])
-    assert np.array_equal(out['panoptic_cls_inds'].cpu().numpy(), taps['panoptic_cls_inds'])
-    assert np.array_equal(out['fcn_outputs'].cpu().numpy()[0], taps['fcn_outputs'])
-    assert np.array_equal(out['panoptic_outputs'].cpu().numpy()[0], taps['panoptic_outputs'])
+    taps, model.taps, model.pipeline = model.taps, None, 'fused'
+    res = check_taps(taps, enable_void=model.enable_void)
+    counts = res.pop('counts')
+    assert all(res.values()), (res, counts)
+    assert counts['n_rois'] > 100 and counts['n_det'] >= 1 and counts['n_inst'] >= 2, counts
+    # result dict is consistent with the recorded stages
+    assert torch.equal(out['pred_boxes'], taps['det_boxes']) and torch.equal(out['panoptic_outputs'], taps['panoptic'])
+    assert torch.equal(out['panoptic_cls_inds'], taps['pan_cls'][taps['keep']])
+    assert out['mask_probs'].shape == (counts['n_det'], 9, 28, 28)
+    assert out['panoptic_outputs'].dtype == torch.int64 and out['panoptic_outputs'].shape == (1, 256, 512)
 
 
-def test_repeatable(setup):
-    model, data = setup
+def test_full_size_stagewise_parity():
+    """The benchmark configuration itself: 1024x2048, label map bit-identical to the oracle."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.synthetic import build_model, make_image
+    model = build_model(cls_gain=0.3)
+    data = make_image(1024, 2048, seed=1, device='cuda')
+    model.taps = {}
     with torch.no_grad():
-        a = model(data)
-        b = model(data)
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
+        model(data)
+    res = check_taps(model.taps, enable_void=True)
+    counts = res.pop('counts')
+    assert all(res.values()), (res, counts)
+    assert counts['label_mismatch'] == 0 and counts['n_inst'] >= 5, counts
+
+
+def test_custom_ops_bit_repeatable(setup):
+    """Forward kernels have one writer per output and no atomics on data: same inputs -> same bits."""
+    from upsnet_amd import ops
+    model, data = setup
+    model.taps = {}
+    with torch.no_grad():
+        model(data)
+        t, model.taps = model.taps, None
+        for _ in range(3):
+            r, s, n = model.pyramid_proposal.forward_padded(t['rpn_cls_prob'], t['rpn_bbox_pred'], t['im_info'])
+            assert torch.equal(r, t['rois']) and int(n.item()) == int(t['n_rois'].item())
+            b, sc, c, _, num = model.mask_roi_panoptic.forward_padded(t['rois'], t['bbox_pred'], t['cls_prob'], t['im_info'], t['n_rois'])
+            k = int(num.item())
+            assert torch.equal(b[:k], t['pan_boxes']) and torch.equal(c[:k], t['pan_cls'])
+            keep, nk, real = model.mask_removal.select(t['pan_boxes'][:, 1:], t['pan_scores'], t['pan_logit'], t['pan_cls'], t['fcn_output'].shape[2:])
+            pan, sem = ops.panoptic_fuse(t['fcn_output'], 11, t['pan_boxes'], t['pan_logit'], t['pan_cls'], keep, nk, real,
+                                         model.seg_term.class_map, True)
+            assert torch.equal(pan, t['panoptic']) and torch.equal(sem, t['sem'])

@@ -62,7 +62,7 @@ def test_reference_roi_align(ref, ref_fma):
         r = _ref_roi(ref, feat, rois, ph, 0.25)
         assert np.array_equal(r, oracle.roi_align_forward(feat, rois, ph, ph, 0.25))          # oracle == reference kernel
         assert np.array_equal(r, U.roi_align_nchw(cu(feat), cu(rois), ph, ph, 0.25).cpu().numpy())  # ours == reference kernel
-        np.testing.assert_allclose(_ref_roi(ref_fma, feat, rois, ph, 0.25), r, rtol=0, atol=1e-5)  # FMA build: ulp-level
+        np.testing.assert_allclose(_ref_roi(ref_fma, feat, rois, ph, 0.25), r, rtol=0, atol=1e-4)  # FMA build (nvcc default): within the 1e-4 logit tolerance
 
 
 def _ref_im2col(lib, im, off, k, pad, stride, dil, dg, mask=None):
@@ -98,7 +98,7 @@ def test_reference_deform_im2col(ref, ref_fma, C, H, W, pad, stride, dil, dg):
         else:
             U.mod_deform_im2col(cu(im), cu(off), cu(mk), (1, C, H, W), r.shape, (k, k), (pad, pad), (stride, stride), (dil, dil), dg, col)
         assert np.array_equal(col.cpu().numpy(), r)
-        np.testing.assert_allclose(_ref_im2col(ref_fma, im, off, k, pad, stride, dil, dg, mk), r, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(_ref_im2col(ref_fma, im, off, k, pad, stride, dil, dg, mk), r, rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("n", [1, 64, 65, 500, 1000, 2000])

@@ -35,6 +35,7 @@ class resnet_upsnet(resnet_rcnn):
     def __init__(self, backbone_depth, pipeline='fused'):
         super(resnet_upsnet, self).__init__()
         self.pipeline = pipeline
+        self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
         self.num_classes = config.dataset.num_classes
         self.num_seg_classes = config.dataset.num_seg_classes
         self.num_reg_classes = (2 if config.network.cls_agnostic_bbox_reg else config.dataset.num_classes)
@@ -91,6 +92,10 @@ class resnet_upsnet(resnet_rcnn):
             rpn_bbox_pred.append(bbox_pred)
         return pyramid, rpn_cls_prob, rpn_bbox_pred
 
+    def _tap(self, **kw):
+        if self.taps is not None:
+            self.taps.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+
     def forward(self, data, label=None):
         if label is not None:
             raise NotImplementedError("upsnet_amd implements the inference branch (label=None) only")
@@ -109,6 +114,8 @@ class resnet_upsnet(resnet_rcnn):
         rcnn_output = self.rcnn(feats, rois, n_rois)
         cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
         bbox_pred = rcnn_output['bbox_pred']
+        self._tap(rpn_cls_prob=[t.detach().clone() for t in rpn_cls_prob], rpn_bbox_pred=[t.detach().clone() for t in rpn_bbox_pred],
+                  im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred, fcn_output=fcn_output)
 
         # both detection selections are launched back to back; ONE host read of the two counters
         det_boxes, det_scores, det_cls, _, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
@@ -123,6 +130,8 @@ class resnet_upsnet(resnet_rcnn):
         ms = config.network.mask_size
         pan_logit = mask_score[n_det:].gather(1, pan_cls.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
 
+        self._tap(det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls, pan_boxes=pan_boxes, pan_scores=pan_scores,
+                  pan_cls=pan_cls, pan_logit=pan_logit)
         H, W = fcn_output.shape[2:]
         keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
@@ -133,6 +142,7 @@ class resnet_upsnet(resnet_rcnn):
                                               real_keep, self.seg_term.class_map.to(fcn_output.device), self.enable_void)
         k = int(num_keep.item())
         keep = keep[:k]
+        self._tap(keep=keep, panoptic=panoptic, sem=sem)
         return {
             'cls_probs': det_scores, 'pred_boxes': det_boxes, 'mask_probs': mask_prob, 'fcn_outputs': sem,
             'cls_inds': det_cls, 'panoptic_cls_inds': pan_cls[keep], 'panoptic_cls_probs': pan_scores[keep],
@@ -159,6 +169,9 @@ class resnet_upsnet(resnet_rcnn):
         rcnn_output = self.rcnn(feats, rois)
         cls_score, bbox_pred = rcnn_output['cls_score'], rcnn_output['bbox_pred']
         cls_prob = F.softmax(cls_score, dim=1)
+        self._tap(rpn_cls_prob=[t.detach().clone() for t in rpn_cls_prob], rpn_bbox_pred=[t.detach().clone() for t in rpn_bbox_pred],
+                  im_info=im_info, rois=rois, n_rois=rois.shape[0], cls_prob=cls_prob, bbox_pred=bbox_pred,
+                  fcn_output=fcn_output['fcn_output'])
 
         cls_prob_all, mask_rois, cls_idx = self.mask_roi(rois, bbox_pred, cls_prob, im_info)
         mask_score = self.mask_branch(feats, mask_rois)
@@ -171,6 +184,8 @@ class resnet_upsnet(resnet_rcnn):
         mask_score = self.mask_branch(feats, mask_rois)
         ms = config.network.mask_size
         mask_score = mask_score.gather(1, cls_idx.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+        self._tap(det_boxes=results['pred_boxes'], det_scores=results['cls_probs'], det_cls=results['cls_inds'],
+                  pan_boxes=mask_rois, pan_scores=cls_prob, pan_cls=cls_idx, pan_logit=mask_score)
 
         keep_inds, mask_logits = self.mask_removal(mask_rois[:, 1:], cls_prob, mask_score, cls_idx,
                                                    fcn_output['fcn_output'].shape[2:])
@@ -182,6 +197,7 @@ class resnet_upsnet(resnet_rcnn):
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
         results['panoptic_outputs'] = ops.panoptic_argmax(fcn_output['fcn_output'], num_stuff, seg_inst_logits,
                                                           mask_logits, self.enable_void)
+        self._tap(keep=keep_inds, panoptic=results['panoptic_outputs'], sem=results['fcn_outputs'])
         return results
 
 

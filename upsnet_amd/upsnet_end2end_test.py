@@ -24,8 +24,8 @@ from .utils.timer import Timer
 
 WORKLOADS = {
     # name: (config preset, unpadded H, W, cls_gain)
-    'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 60.0),
-    'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 60.0),
+    'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 0.3),
+    'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 0.3),
 }
 
 
