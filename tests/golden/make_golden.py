@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Generate golden vectors by IMPORTING THE REFERENCE's own Python modules from /root/reference.
+
+Run here (the build container, where /root/reference exists):   python tests/golden/make_golden.py
+The .npz fixtures it writes are committed; tests/test_golden_cpu.py replays them against the oracle
+(CPU) and tests/test_golden_gpu.py against the HIP ops (GPU box, where /root/reference does not exist).
+
+The reference cannot be imported as-is, so this script supplies, in-process only:
+  * numpy aliases removed in numpy>=1.24 (np.float, np.int), an `easydict` stand-in;
+  * torch plumbing no-ops for a CPU-only run (Tensor.cuda / pin_memory / device arguments of .to());
+  * stand-ins for the COMPILED pieces that do not exist here: upsnet.nms.{gpu_nms,cpu_nms} and
+    upsnet.bbox.bbox (Cython), upsnet.operators._ext.roi_align (CUDA ext), cv2. The stand-ins for the
+    natives call the oracle's C functions (themselves pinned against the reference's .cu kernels on the
+    GPU, tests/test_ref_kernels_gpu.py), so what these fixtures pin is the reference's PYTHON glue:
+    generate_anchors, bbox_transform, clip_boxes, py_nms, PyramidProposalFunction.forward,
+    PyramidProposal.forward's final ranking, FPNRoIAlign's level assignment + reordering,
+    MaskROI.forward, MaskRemoval.forward, SegTerm.forward. cv2.resize is replaced by the oracle's
+    INTER_LINEAR restatement (parity unpinned for that one formula).
+Inputs avoid exactly tied scores where the reference relies on numpy's unstable argsort / argpartition.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import oracle  # noqa: E402
+from oracle import ops as oops  # noqa: E402
+
+# ------------------------------------------------------------------ compatibility shims (this process only)
+np.float = float
+np.int = int
+
+
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, EasyDict):
+            v = EasyDict(v)
+        super().__setitem__(k, v)
+        super().__setattr__(k, v)
+
+    __setitem__ = __setattr__
+
+
+def _module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_module("easydict", EasyDict=EasyDict)
+_module("cv2", resize=lambda src, dsize: oracle.resize_bilinear(np.asarray(src, np.float32), dsize[0], dsize[1]))
+_module("upsnet.bbox.bbox", bbox_overlaps=lambda a, b: np.zeros((a.shape[0], b.shape[0])))
+_module("upsnet.nms.gpu_nms", gpu_nms=lambda dets, thresh, device_id=0: oops.gpu_nms(dets, thresh).tolist())
+_module("upsnet.nms.cpu_nms", cpu_nms=lambda dets, thresh: oops.gpu_nms(dets, thresh).tolist(),
+        cpu_soft_nms=lambda boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0: oracle.soft_nms(boxes, sigma, Nt, threshold, method))
+_module("upsnet.operators._ext", __path__=[])
+_module("upsnet.operators._ext.roi_align", roi_align_cuda=None)
+
+_orig_to = torch.Tensor.to
+
+
+def _to(self, *args, **kw):
+    args = [a for a in args if isinstance(a, torch.dtype)]
+    kw = {k: v for k, v in kw.items() if k == "dtype"}
+    return _orig_to(self, *args, **kw) if (args or kw) else self
+
+
+torch.Tensor.to = _to
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.Tensor.pin_memory = lambda self, *a, **k: self
+torch.Tensor.get_device = lambda self: 0
+
+from upsnet.config.config import config  # noqa: E402
+
+config.dataset = EasyDict(num_classes=9, num_seg_classes=19)
+config.network.has_fpn = True
+
+from upsnet.bbox.bbox_transform import bbox_transform, clip_boxes  # noqa: E402
+from upsnet.nms.nms import py_nms  # noqa: E402
+from upsnet.operators.functions.pyramid_proposal import PyramidProposalFunction  # noqa: E402
+from upsnet.operators.modules import fpn_roi_align as ref_fpn  # noqa: E402
+from upsnet.operators.modules.mask_removal import MaskRemoval  # noqa: E402
+from upsnet.operators.modules.mask_roi import MaskROI  # noqa: E402
+from upsnet.operators.modules.unary_logits import SegTerm  # noqa: E402
+from upsnet.rpn.generate_anchors import generate_anchors  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import gen_dets, gen_rois  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: np.asarray(v).shape for k, v in arrays.items()})
+
+
+def distinct_scores(rng, shape, lo=0.0, hi=1.0):
+    """float32 scores without exact duplicates (the reference's unstable sorts make ties implementation-defined)."""
+    n = int(np.prod(shape))
+    s = np.sort(rng.uniform(lo, hi, 4 * n).astype(np.float32))
+    s = np.unique(s)
+    assert len(s) >= n
+    return rng.permutation(s)[:n].reshape(shape).astype(np.float32)
+
+
+def main():
+    rng = np.random.default_rng(20260924)
+
+    # ---- anchors (rpn/generate_anchors.py:50-76)
+    strides = (4, 8, 16, 32, 64)
+    save("anchors", **{"s%d" % s: generate_anchors(stride=s, sizes=np.array((8,)) * s, aspect_ratios=np.array((0.5, 1, 2))) for s in strides})
+
+    # ---- bbox_transform + clip_boxes (bbox/bbox_transform.py:290-330, 45-60)
+    boxes = gen_rois(rng, 64, 600, 900)[:, 1:]
+    deltas = rng.normal(0, 0.6, size=(64, 36)).astype(np.float32)
+    deltas[0, 2::4] = 9.0  # hits the log(1000/16) clamp
+    out = bbox_transform(boxes, deltas, (10., 10., 5., 5.))
+    clipped = clip_boxes(out.copy(), np.array([600, 900], np.float32))
+    save("bbox_transform", boxes=boxes, deltas=deltas, decoded=out, clipped=clipped)
+
+    # ---- py_nms (nms/nms.py:48-85)
+    d = gen_dets(rng, 300, ties=False)
+    d[:, 4] = distinct_scores(rng, (300,))
+    save("py_nms", dets=d, keep05=np.array(py_nms(d, 0.5), np.int64), keep07=np.array(py_nms(d, 0.7), np.int64))
+
+    # ---- PyramidProposalFunction.forward (functions/pyramid_proposal.py:41-222) + module ranking (:61-67)
+    H, W = 96, 160
+    cls, box = [], []
+    for s in strides:
+        h, w = max(H // s, 1), max(W // s, 1)
+        cls.append(distinct_scores(rng, (1, 3, h, w), 0.001, 0.999))
+        box.append(rng.normal(0, 0.4, size=(1, 12, h, w)).astype(np.float32))
+    im_info = np.array([H - 2, W - 3, 1.0], np.float32)
+    fn = PyramidProposalFunction.__new__(PyramidProposalFunction)
+    fn.feat_stride, fn.scales, fn.ratios, fn.num_anchors = strides, np.array((8,)), np.array((0.5, 1, 2)), 3
+    fn.rpn_pre_nms_top_n, fn.rpn_post_nms_top_n, fn.threshold, fn.rpn_min_size = 200, 100, 0.7, 0
+    fn.individual_proposals, fn.batch_idx, fn.use_softnms, fn.crowd_gt_roi = True, 0, False, None
+    rois, scores = PyramidProposalFunction.forward(fn, *[torch.from_numpy(c) for c in cls], *[torch.from_numpy(b) for b in box],
+                                                   torch.from_numpy(im_info))
+    _, idx = torch.sort(-scores, 0)  # modules/pyramid_proposal.py:63-64
+    idx = idx[:100]
+    save("pyramid_proposal", im_info=im_info, rois=rois[idx].numpy(), scores=scores[idx].numpy(),
+         **{"cls%d" % i: c for i, c in enumerate(cls)}, **{"box%d" % i: b for i, b in enumerate(box)})
+
+    # ---- FPNRoIAlign (modules/fpn_roi_align.py:32-62): level assignment, dummy ROIs, reordering
+    class _RoiFn(object):
+        def __init__(self, ph, pw, scale):
+            self.ph, self.pw, self.scale = ph, pw, scale
+
+        def __call__(self, feat, rois):
+            return torch.from_numpy(oracle.roi_align_forward(feat.numpy(), rois.numpy(), self.ph, self.pw, self.scale))
+
+    ref_fpn.RoIAlignFunction = _RoiFn
+    feats = [rng.normal(size=(1, 8, 64 // s, 96 // s)).astype(np.float32) for s in (1, 2, 4, 8)]
+    rois = gen_rois(rng, 40, 256, 384, 6, 230)
+    rois[0] = [0, 0, 0, 111, 111]
+    rois[1] = [0, 0, 0, 223, 223]
+    small = rois[(rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]) < 100 * 100][:12]  # one empty level -> dummy ROI path
+    for tag, r in (("all", rois), ("small", small)):
+        m = ref_fpn.FPNRoIAlign(7, 7, [1 / 4., 1 / 8., 1 / 16., 1 / 32.])
+        m.roi_pooling = _RoiFn
+        out = m([torch.from_numpy(f) for f in feats], torch.from_numpy(r))
+        save("fpn_roi_align_" + tag, rois=r, out=out.numpy(), **{"feat%d" % i: f for i, f in enumerate(feats)})
+
+    # ---- MaskROI.forward (modules/mask_roi.py:36-146), both variants + the empty case
+    N, C = 120, 9
+    rois = gen_rois(rng, N, 300, 500, 8, 200)
+    rois[N // 2:] = rois[:N - N // 2] + np.hstack([np.zeros((N - N // 2, 1)), rng.normal(0, 3, (N - N // 2, 4))]).astype(np.float32)
+    delta = rng.normal(0, 0.5, size=(N, 4 * C)).astype(np.float32)
+    logit = rng.normal(0, 2.5, size=(N, C))
+    prob = np.exp(logit - logit.max(1, keepdims=True))
+    prob = (prob / prob.sum(1, keepdims=True)).astype(np.float32)
+    im_info2 = np.array([[300, 500, 1.0]], np.float32)
+    for tag, agn, thr in (("det", False, 0.05), ("pan", True, 0.6), ("empty", True, 0.9999)):
+        m = MaskROI(clip_boxes=True, bbox_class_agnostic=False, top_n=100, num_classes=C, nms_thresh=0.5, class_agnostic=agn,
+                    score_thresh=thr)
+        s, b, c = m(torch.from_numpy(rois), torch.from_numpy(delta), torch.from_numpy(prob), im_info2)
+        save("mask_roi_" + tag, rois=rois, delta=delta, prob=prob, im_info=im_info2, scores=s.numpy(), boxes=b.numpy(), cls=c.numpy(),
+             agn=np.array(agn), thr=np.array(thr, np.float32))
+
+    # ---- MaskRemoval.forward + SegTerm.forward (modules/mask_removal.py:29-93, unary_logits.py:78-105)
+    m_, Hh, Ww = 36, 72, 120
+    mrois = gen_rois(rng, m_, Hh, Ww, 8, 70)[:, 1:]
+    mrois += rng.uniform(-0.9, 0.9, size=mrois.shape).astype(np.float32)
+    mrois = np.maximum(mrois, 0).astype(np.float32)
+    mprob = distinct_scores(rng, (m_,), 0.6, 1.0)
+    mlogit = rng.normal(0.3, 2.0, size=(m_, 1, 28, 28)).astype(np.float32)
+    mcls = rng.integers(1, 9, size=m_).astype(np.int64)
+    keep, energy = MaskRemoval(0.3)(torch.from_numpy(mrois), torch.from_numpy(mprob), torch.from_numpy(mlogit), torch.from_numpy(mcls), (Hh, Ww))
+    fcn = rng.normal(0, 3, size=(1, 19, Hh, Ww)).astype(np.float32)
+    rois5 = np.hstack([np.zeros((m_, 1), np.float32), mrois])[keep.numpy()]
+    seg, inst = SegTerm(19)(torch.from_numpy(mcls[keep.numpy()]), torch.from_numpy(fcn), torch.from_numpy(rois5) * 4.0)
+    # fusion exactly as resnet_upsnet.py:234-240 (enable_void) and :242-243
+    seg_t, inst_t, en_t, fcn_t = seg, inst, energy, torch.from_numpy(fcn)
+    void = torch.max(fcn_t[:, 11:, ...], dim=1, keepdim=True)[0] - torch.max(inst_t, dim=1, keepdim=True)[0]
+    logits = torch.cat([seg_t, inst_t + en_t, void], dim=1)
+    pan = torch.max(logits, dim=1)[1]
+    pan[pan == logits.shape[1] - 1] = 255
+    pan_sm = torch.max(torch.softmax(torch.cat([seg_t, inst_t + en_t], dim=1), dim=1), dim=1)[1]
+    save("panoptic_head", rois=mrois, prob=mprob, logit=mlogit, cls=mcls, fcn=fcn, keep=keep.numpy(), energy=energy.numpy(),
+         seg_inst=inst.numpy(), pan_void=pan.numpy(), pan_softmax=pan_sm.numpy())
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference tree is only available in the build container"
+    main()

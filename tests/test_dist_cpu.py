@@ -1,0 +1,50 @@
+"""CPU: the N>1 path (one process per GPU, image i -> rank i mod N, one gather at the end) with two gloo ranks."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from upsnet_amd.upsnet_end2end_test import gather_results, init_distributed, shard_indices
+    r, w, dev = init_distributed()
+    assert (r, w) == (rank, world) and dist.get_backend() == 'gloo'
+    ids = shard_indices(7, rank, world)           # uneven: rank 0 gets 4 images, rank 1 gets 3
+    local = [(i, torch.full((6, 10), i, dtype=torch.uint8), 10 + i) for i in ids]
+    out = gather_results(local, world, dev)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)     # max-over-ranks timing reduction used by the bench
+    q.put((rank, sorted(out.keys()), [int(out[i][0][0, 0]) for i in sorted(out)], [out[i][1] for i in sorted(out)], float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, keys, vals, ninst, tmax in res:
+        assert keys == list(range(7)) and vals == list(range(7)) and ninst == [10 + i for i in range(7)]
+        assert tmax == 2.0
+
+
+def test_shard_indices_cover_exactly_once():
+    from upsnet_amd.upsnet_end2end_test import shard_indices
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 7, 64):
+            got = sorted(sum([shard_indices(n, r, world) for r in range(world)], []))
+            assert got == list(range(n))

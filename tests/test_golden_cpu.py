@@ -1,0 +1,75 @@
+"""CPU: the oracle vs golden vectors produced by the reference's own Python modules
+(tests/golden/make_golden.py, run where /root/reference exists; fixtures committed)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ops as oops
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def test_anchors():
+    g = load("anchors")
+    for s in (4, 8, 16, 32, 64):
+        assert np.array_equal(oops.generate_anchors(s, (8 * s,), (0.5, 1, 2)), g["s%d" % s])
+
+
+def test_bbox_transform_and_clip():
+    g = load("bbox_transform")
+    dec = oops.bbox_transform(g["boxes"], g["deltas"], (10., 10., 5., 5.))
+    # numpy>=2 promotes np.minimum(dw, np.float64) to float64 inside the reference (NEP 50); the 2018-era
+    # numpy it was written for stayed in fp32 -> ulp-level differences only
+    np.testing.assert_allclose(dec, g["decoded"], rtol=2e-6, atol=2e-4)
+    assert np.array_equal(oops.clip_boxes(g["decoded"], (600, 900)), g["clipped"])
+
+
+def test_py_nms():
+    g = load("py_nms")
+    assert np.array_equal(oops.gpu_nms(g["dets"], 0.5), g["keep05"])
+    assert np.array_equal(oops.gpu_nms(g["dets"], 0.7), g["keep07"])
+    assert np.array_equal(oops.py_nms(g["dets"], 0.5), g["keep05"])
+
+
+def test_pyramid_proposal():
+    g = load("pyramid_proposal")
+    rois, scores = oops.pyramid_proposal([g["cls%d" % i] for i in range(5)], [g["box%d" % i] for i in range(5)], g["im_info"],
+                                         pre_nms_top_n=200, post_nms_top_n=100, nms_thresh=0.7)
+    assert np.array_equal(scores, g["scores"])       # selection + ranking identical
+    np.testing.assert_allclose(rois, g["rois"], rtol=0, atol=2e-4)  # decode ulp (NEP 50, see above)
+
+
+@pytest.mark.parametrize("tag", ["all", "small"])
+def test_fpn_roi_align(tag):
+    g = load("fpn_roi_align_" + tag)
+    out = oops.fpn_roi_align([g["feat%d" % i] for i in range(4)], g["rois"], 7, 7)
+    assert np.array_equal(out, g["out"])
+
+
+@pytest.mark.parametrize("tag", ["det", "pan", "empty"])
+def test_mask_roi(tag):
+    g = load("mask_roi_" + tag)
+    s, b, c = oops.mask_roi(g["rois"], g["delta"], g["prob"], g["im_info"], 9, 0.5, float(g["thr"]), 100, bool(g["agn"]))
+    assert np.array_equal(c, g["cls"]) and np.array_equal(s, g["scores"])
+    np.testing.assert_allclose(b, g["boxes"], rtol=0, atol=2e-4)
+
+
+def test_panoptic_head():
+    g = load("panoptic_head")
+    keep, energy = oops.mask_removal(g["rois"], g["prob"], g["logit"], g["cls"], (72, 120))
+    assert 0 < len(keep) < len(g["cls"])
+    assert np.array_equal(keep, g["keep"]) and np.array_equal(energy, g["energy"])
+    rois5 = np.hstack([np.zeros((len(g["rois"]), 1), np.float32), g["rois"]])[keep]
+    seg, inst = oops.seg_term(g["cls"][keep], g["fcn"], rois5 * np.float32(4.0), 19, 9)
+    assert np.array_equal(inst, g["seg_inst"])
+    pan, _ = oracle.panoptic_fuse(g["fcn"][0], 11, inst[0], energy[0], True)
+    assert np.array_equal(pan, g["pan_void"][0])
+    pan2, _ = oracle.panoptic_fuse(g["fcn"][0], 11, inst[0], energy[0], False)
+    # argmax(softmax(x)) through torch's own softmax: allow the (rare) rounding-tie pixels, report them
+    assert (pan2 != g["pan_softmax"][0]).mean() < 1e-3

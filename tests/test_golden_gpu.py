@@ -1,0 +1,72 @@
+"""GPU: the HIP ops vs the committed golden vectors produced by the reference's own Python modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_py_nms_golden():
+    from upsnet_amd.nms.nms import gpu_nms_wrapper
+    g = load("py_nms")
+    assert gpu_nms_wrapper(0.5, 0)(g["dets"]) == g["keep05"].tolist()
+    assert gpu_nms_wrapper(0.7, 0)(g["dets"]) == g["keep07"].tolist()
+
+
+def test_pyramid_proposal_golden():
+    from upsnet_amd.operators.modules.pyramid_proposal import PyramidProposal
+    g = load("pyramid_proposal")
+    pp = PyramidProposal((4, 8, 16, 32, 64), (8,), (0.5, 1, 2), 200, 100, 0.7, 0, individual_proposals=True)
+    rois, scores = pp([cu(g["cls%d" % i]) for i in range(5)], [cu(g["box%d" % i]) for i in range(5)], g["im_info"][None])
+    assert np.array_equal(scores.cpu().numpy(), g["scores"])
+    np.testing.assert_allclose(rois.cpu().numpy(), g["rois"], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["all", "small"])
+def test_fpn_roi_align_golden(tag):
+    from upsnet_amd.operators.modules.fpn_roi_align import FPNRoIAlign
+    g = load("fpn_roi_align_" + tag)
+    m = FPNRoIAlign(7, 7, [1 / 4., 1 / 8., 1 / 16., 1 / 32.])
+    out = m([cu(g["feat%d" % i]) for i in range(4)], cu(g["rois"]))
+    assert out.is_contiguous() and np.array_equal(out.cpu().numpy(), g["out"])
+
+
+@pytest.mark.parametrize("tag", ["det", "pan", "empty"])
+def test_mask_roi_golden(tag):
+    from upsnet_amd.operators.modules.mask_roi import MaskROI
+    g = load("mask_roi_" + tag)
+    m = MaskROI(True, False, 100, 9, nms_thresh=0.5, class_agnostic=bool(g["agn"]), score_thresh=float(g["thr"]))
+    s, b, c = m(cu(g["rois"]), cu(g["delta"]), cu(g["prob"]), g["im_info"])
+    assert np.array_equal(c.cpu().numpy(), g["cls"]) and np.array_equal(s.cpu().numpy(), g["scores"])
+    np.testing.assert_allclose(b.cpu().numpy(), g["boxes"], rtol=0, atol=2e-4)
+
+
+def test_panoptic_head_golden():
+    from upsnet_amd import ops
+    from upsnet_amd.operators.modules.mask_removal import MaskRemoval
+    from upsnet_amd.operators.modules.unary_logits import SegTerm
+    g = load("panoptic_head")
+    rois, prob, logit, cls, fcn = cu(g["rois"]), cu(g["prob"]), cu(g["logit"]), cu(g["cls"]), cu(g["fcn"])
+    keep, energy = MaskRemoval(0.3)(rois, prob, logit, cls, (72, 120))
+    assert np.array_equal(keep.cpu().numpy(), g["keep"]) and np.array_equal(energy.cpu().numpy(), g["energy"])
+    rois5 = torch.cat([torch.zeros(len(rois), 1, device='cuda'), rois], 1)
+    seg, inst = SegTerm(19)(cls[keep], fcn, rois5[keep] * 4.0)
+    assert np.array_equal(inst.cpu().numpy(), g["seg_inst"])
+    assert np.array_equal(ops.panoptic_argmax(fcn, 11, inst, energy, True).cpu().numpy(), g["pan_void"])
+    k, n, r = ops.mask_removal(rois, prob, logit, cls, 8, (72, 120))
+    cmap = SegTerm(19).class_map.cuda()
+    pan, _ = ops.panoptic_fuse(fcn, 11, rois5, logit, cls, k, n, r, cmap, True)
+    assert np.array_equal(pan.cpu().numpy(), g["pan_void"])
+    pan_sm, _ = ops.panoptic_fuse(fcn, 11, rois5, logit, cls, k, n, r, cmap, False)
+    assert (pan_sm.cpu().numpy() != g["pan_softmax"]).mean() < 1e-3

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the product (no kernels): config, anchors, synthetic inputs, model structure,
+state-dict key names (the checkpoint contract with the reference), BN folding, fc6 weight re-layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(autouse=True)
+def _cfg():
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+
+
+def test_product_anchors_match_reference_golden():
+    from upsnet_amd.rpn.generate_anchors import generate_anchors
+    g = np.load(os.path.join(G, "anchors.npz"))
+    for s in (4, 8, 16, 32, 64):
+        assert np.array_equal(generate_anchors(s, (8 * s,), (0.5, 1, 2)), g["s%d" % s])
+
+
+def test_product_bbox_helpers_match_golden():
+    from upsnet_amd.bbox.bbox_transform import bbox_transform, clip_boxes
+    g = np.load(os.path.join(G, "bbox_transform.npz"))
+    np.testing.assert_allclose(bbox_transform(g["boxes"], g["deltas"], (10., 10., 5., 5.)), g["decoded"], rtol=2e-6, atol=2e-4)
+    assert np.array_equal(clip_boxes(g["decoded"].copy(), (600, 900)), g["clipped"])
+
+
+def test_config_yaml_roundtrip(tmp_path):
+    from upsnet_amd.config.config import config, update_config
+    p = tmp_path / "exp.yaml"
+    p.write_text("symbol: resnet_101_upsnet\ndataset:\n  num_classes: 81\n  num_seg_classes: 133\nnetwork:\n  fcn_num_layers: 3\n  fpn_with_gap: true\ntest:\n  rpn_post_nms_top_n: 300\n")
+    update_config(str(p))
+    assert config.symbol == 'resnet_101_upsnet' and config.dataset.num_seg_classes == 133
+    assert config.network.fpn_with_gap is True and config.test.rpn_post_nms_top_n == 300
+    assert config.test.rpn_nms_thresh == 0.7 and config.network.bbox_reg_weights == (10., 10., 5., 5.)
+
+
+def test_synthetic_image_contract():
+    from upsnet_amd.synthetic import make_image
+    d = make_image(800, 1333, seed=0)
+    assert d['data'].shape == (1, 3, 800, 1344) and d['data'].dtype == torch.float32
+    assert np.array_equal(d['im_info'], np.array([[800, 1333, 1.0]], np.float32))
+    assert not d['data'][:, :, :, 1333:].any()
+    px = d['data'][0, :, 0, 0] + torch.tensor([102.9801, 115.9465, 122.7717])
+    assert torch.allclose(px, px.round(), atol=1e-4)
+    assert torch.equal(make_image(64, 64, seed=3)['data'], make_image(64, 64, seed=3)['data'])
+
+
+def test_model_structure_and_checkpoint_keys():
+    from upsnet_amd.models.resnet_upsnet import resnet_50_upsnet
+    m = resnet_50_upsnet()
+    keys = set(m.state_dict().keys())
+    # key names the reference checkpoints use (SURVEY.md section 5 "Checkpoint / resume")
+    for k in ['resnet_backbone.conv1.conv1.weight', 'resnet_backbone.conv1.bn1.running_var',
+              'resnet_backbone.res2.layers.0.downsample.0.weight', 'resnet_backbone.res2.layers.0.downsample.1.running_mean',
+              'resnet_backbone.res3.layers.3.conv2.weight', 'resnet_backbone.res4.layers.5.bn3.bias', 'resnet_backbone.res5.layers.2.conv3.weight',
+              'fpn.fpn_p5_1x1.weight', 'fpn.fpn_p2.bias', 'rpn.conv_proposal.0.weight', 'rpn.cls_score.weight', 'rpn.bbox_pred.bias',
+              'rcnn.fc6.0.weight', 'rcnn.fc7.0.bias', 'rcnn.cls_score.weight', 'rcnn.bbox_pred.weight',
+              'mask_branch.mask_conv1.0.weight', 'mask_branch.mask_conv4.0.bias', 'mask_branch.mask_deconv1.0.weight', 'mask_branch.mask_score.weight',
+              'fcn_head.fcn_subnet.conv.0.0.conv_offset.weight', 'fcn_head.fcn_subnet.conv.0.0.conv.weight', 'fcn_head.fcn_subnet.conv.1.0.conv.bias',
+              'fcn_head.score.weight']:
+        assert k in keys, k
+    assert m.state_dict()['rcnn.fc6.0.weight'].shape == (1024, 12544)
+    assert m.state_dict()['fcn_head.fcn_subnet.conv.0.0.conv.weight'].shape == (128, 256, 3, 3)
+    assert m.state_dict()['fcn_head.fcn_subnet.conv.1.0.conv.weight'].shape == (128, 128, 3, 3)
+    assert m.state_dict()['rcnn.cls_score.weight'].shape == (9, 1024) and m.state_dict()['fcn_head.score.weight'].shape == (19, 512, 1, 1)
+    n_blocks = [len(getattr(m.resnet_backbone, 'res%d' % i).layers) for i in (2, 3, 4, 5)]
+    assert n_blocks == [3, 4, 6, 3]
+    assert m.resnet_backbone.res3.layers[0].conv1.stride == (2, 2)   # caffe-style: stride on the first 1x1
+    assert not m.fcn_head.fcn_subnet.conv[0][0].conv_offset.weight.any()  # zero-init offsets as the reference
+    # tolerant loader with torchvision-style names
+    sd = {'conv1.weight': torch.ones(64, 3, 7, 7), 'layer1.0.conv1.weight': torch.full((64, 64, 1, 1), 2.0), 'module.bogus': torch.zeros(1)}
+    with pytest.warns(UserWarning):
+        m.load_state_dict(sd)
+    assert float(m.resnet_backbone.conv1.conv1.weight.mean()) == 1.0 and float(m.resnet_backbone.res2.layers[0].conv1.weight.mean()) == 2.0
+
+
+def test_dcn_backbone_config():
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN
+    update_config_dict(COCO_R101_DCN)
+    from upsnet_amd.models.resnet import ResNetBackbone, DCNBottleneck
+    b = ResNetBackbone([3, 4, 23, 3])
+    assert all(isinstance(l, DCNBottleneck) for l in b.res3.layers) and all(isinstance(l, DCNBottleneck) for l in b.res5.layers)
+    assert not any(isinstance(l, DCNBottleneck) for l in b.res2.layers)
+    assert 'res4.layers.22.conv2_offset.weight' in b.state_dict()
+
+
+def test_fold_frozen_bn_is_exact_reparameterisation():
+    from upsnet_amd.models.resnet import Bottleneck, fold_frozen_bn
+    import torch.nn as nn
+    torch.manual_seed(0)
+    ds = nn.Sequential(nn.Conv2d(16, 32, 1, bias=False), nn.BatchNorm2d(32))
+    blk = Bottleneck(16, 8, downsample=ds).eval()
+    for bn in (blk.bn1, blk.bn2, blk.bn3, ds[1]):
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(2, 16, 9, 9)
+    with torch.no_grad():
+        y0 = blk(x.clone())
+        y1 = fold_frozen_bn(blk)(x.clone())
+    assert isinstance(blk.bn1, nn.Identity)
+    torch.testing.assert_close(y0, y1, rtol=1e-4, atol=1e-5)
+
+
+def test_fc6_weight_relayout_matches_nchw_flatten():
+    from upsnet_amd.models.rcnn import RCNN
+    torch.manual_seed(1)
+    r = RCNN(9, 9, dim_in=8, dim_hidden=16)
+    pooled = torch.randn(5, 8, 7, 7)
+    ref = torch.nn.functional.linear(pooled.reshape(5, -1), r.fc6[0].weight, r.fc6[0].bias)
+    nhwc = pooled.contiguous(memory_format=torch.channels_last)
+    got = torch.nn.functional.linear(nhwc.permute(0, 2, 3, 1).reshape(5, -1), r._fc6_weight_nhwc(), r.fc6[0].bias)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)

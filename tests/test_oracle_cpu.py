@@ -1,0 +1,150 @@
+"""CPU: the oracle against independent restatements and domain properties (small sizes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import ops as oops
+from conftest import gen_dets, gen_rois
+
+
+def test_nms_c_scan_equals_vectorised_py_nms_incl_ties():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 64, 65, 257, 1000):
+        d = gen_dets(rng, n) if n else np.zeros((0, 5), np.float32)
+        for t in (0.3, 0.5, 0.7):
+            assert np.array_equal(oops.gpu_nms(d, t), oops.py_nms(d, t))
+
+
+def test_nms_properties():
+    rng = np.random.default_rng(1)
+    d = gen_dets(rng, 500)
+    keep = oops.gpu_nms(d, 0.5)
+    assert len(set(keep.tolist())) == len(keep)
+    assert np.all(np.diff(d[keep, 4]) <= 0)                       # visiting order = descending score
+    assert sorted(oops.gpu_nms(d[keep], 0.5).tolist()) == list(range(len(keep)))  # idempotent (as a set: tied scores are re-visited in reverse)
+    # tie rule (i): equal scores are visited higher-index first
+    t = np.array([[0, 0, 10, 10, .5], [100, 100, 110, 110, .5], [200, 200, 210, 210, .5]], np.float32)
+    assert oops.gpu_nms(t, 0.5).tolist() == [2, 1, 0]
+
+
+def test_roi_align_matches_independent_numpy():
+    rng = np.random.default_rng(2)
+    feat = rng.normal(size=(1, 3, 12, 15)).astype(np.float32)
+    rois = gen_rois(rng, 6, 48, 60, 4, 40)
+    out = oracle.roi_align_forward(feat, rois, 3, 3, 0.25)
+
+    def bil(p, y, x):
+        H, W = p.shape
+        if y < -1 or y > H or x < -1 or x > W:
+            return 0.0
+        y, x = max(y, 0.0), max(x, 0.0)
+        y0, x0 = int(y), int(x)
+        if y0 >= H - 1:
+            y0 = y1 = H - 1; y = float(y0)
+        else:
+            y1 = y0 + 1
+        if x0 >= W - 1:
+            x0 = x1 = W - 1; x = float(x0)
+        else:
+            x1 = x0 + 1
+        ly, lx = y - y0, x - x0
+        return (1 - ly) * (1 - lx) * p[y0, x0] + (1 - ly) * lx * p[y0, x1] + ly * (1 - lx) * p[y1, x0] + ly * lx * p[y1, x1]
+
+    for n, r in enumerate(rois):
+        x1, y1, x2, y2 = [float(v) * 0.25 for v in r[1:]]
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        for c in range(3):
+            for ph in range(3):
+                for pw in range(3):
+                    acc = 0.0
+                    for iy in range(2):
+                        for ix in range(2):
+                            acc += bil(feat[0, c].astype(np.float64), y1 + ph * rh / 3 + (iy + .5) * rh / 3 / 2, x1 + pw * rw / 3 + (ix + .5) * rw / 3 / 2)
+                    assert abs(acc / 4 - out[n, c, ph, pw]) < 1e-4
+
+
+def test_deform_im2col_zero_offset_is_unfold_and_dcn_is_conv():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(6, 9, 11)).astype(np.float32)
+    for pad, stride, dil in ((1, 1, 1), (2, 1, 2), (1, 2, 1)):
+        Ho = (9 + 2 * pad - (dil * 2 + 1)) // stride + 1
+        Wo = (11 + 2 * pad - (dil * 2 + 1)) // stride + 1
+        col = oracle.deform_im2col(x, np.zeros((18, Ho, Wo), np.float32), (3, 3), (pad, pad), (stride, stride), (dil, dil))
+        ref = F.unfold(torch.from_numpy(x)[None], 3, dilation=dil, padding=pad, stride=stride)[0].numpy().reshape(54, Ho, Wo)
+        assert np.array_equal(col, ref)
+    # integer offsets shift the sampling grid exactly
+    off = np.zeros((18, 9, 11), np.float32)
+    off[0::2] = 1.0
+    col = oracle.deform_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1))
+    ref = F.unfold(F.pad(torch.from_numpy(x)[None], (1, 1, 0, 2)), 3, padding=0)[0].numpy().reshape(54, 9, 11)  # window rows h..h+2
+    assert np.array_equal(col, ref)
+    # v2: mask scales linearly
+    m = rng.uniform(0, 2, size=(9, 9, 11)).astype(np.float32)
+    off = rng.normal(size=(18, 9, 11)).astype(np.float32)
+    a = oracle.deform_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1))
+    b = oracle.deform_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1), mask=m)
+    assert np.array_equal(b, a * np.tile(m, (6, 1, 1)).reshape(6, 9, 9, 11).reshape(54, 9, 11))
+
+
+def test_soft_nms_properties():
+    rng = np.random.default_rng(4)
+    d = gen_dets(rng, 150)
+    for method in (0, 1, 2):
+        b, inds = oracle.soft_nms(d, 0.5, 0.3, 0.001, method)
+        assert len(set(inds.tolist())) == len(inds) and len(inds) <= len(d)
+        assert np.array_equal(b[:len(inds), :4], d[inds, :4])          # boxes travel with their indices
+        assert np.all(b[:len(inds), 4] <= d[inds, 4] + 1e-7)            # scores only decay
+    # method 0 with threshold just above 0 == hard NMS keep set (as a set)
+    b, inds = oracle.soft_nms(d, 0.5, 0.3, 1e-9, 0)
+    assert set(inds.tolist()) == set(oops.gpu_nms(d, 0.3).tolist())
+
+
+def test_resize_restates_torch_bilinear_for_integer_upscales():
+    rng = np.random.default_rng(5)
+    src = rng.normal(size=(28, 28)).astype(np.float32)
+    for s in (2, 3, 4):
+        ours = oracle.resize_bilinear(src, 28 * s, 28 * s)
+        ref = F.interpolate(torch.from_numpy(src)[None, None], scale_factor=s, mode='bilinear', align_corners=False)[0, 0].numpy()
+        np.testing.assert_allclose(ours, ref, rtol=0, atol=2e-5)   # same half-pixel-centre, edge-clamped formula (different op order)
+    assert np.array_equal(oracle.resize_bilinear(src, 28, 28), src)
+    one = oracle.resize_bilinear(src, 1, 1)
+    assert one.shape == (1, 1)
+
+
+def test_fuse_c_equals_literal_numpy_and_labels_in_range():
+    rng = np.random.default_rng(6)
+    S, H, W, k = 19, 24, 40, 6
+    fcn = rng.normal(0, 3, (S, H, W)).astype(np.float32)
+    si = (rng.normal(0, 2, (k, H, W)) * (rng.uniform(size=(k, H, W)) > 0.6)).astype(np.float32)
+    me = (rng.normal(0, 2, (k, H, W)) * (rng.uniform(size=(k, H, W)) > 0.5)).astype(np.float32)
+    for void in (True, False):
+        p, sem = oracle.panoptic_fuse(fcn, 11, si, me, void)
+        assert np.array_equal(p, oops.panoptic_fuse_numpy(fcn, si, me, 11, void))
+        assert np.array_equal(sem, fcn.argmax(0))
+        ok = (p < 11 + k) | (p == 255) if void else (p < 11 + k)
+        assert ok.all()
+
+
+def test_fpn_level_thresholds():
+    # level = #{t in (0.5, 1, 2): sqrt(wh)/224 + 1e-6 >= t}: exact at the power-of-two boundaries
+    sides = np.array([10, 111, 112, 113, 223, 224, 225, 447, 448, 449, 2000], np.float32)
+    rois = np.stack([np.zeros_like(sides), np.zeros_like(sides), np.zeros_like(sides), sides - 1, sides - 1], 1)
+    x = sides / np.float32(224) + np.float32(1e-6)
+    want = (x >= 0.5).astype(int) + (x >= 1).astype(int) + (x >= 2).astype(int)
+    assert oops.fpn_level(rois).tolist() == want.tolist()
+
+
+def test_mask_roi_invariants():
+    rng = np.random.default_rng(7)
+    N, C = 200, 9
+    rois = gen_rois(rng, N, 300, 500)
+    delta = rng.normal(0, 0.3, (N, 36)).astype(np.float32)
+    prob = rng.dirichlet(np.ones(C) * 0.3, N).astype(np.float32)
+    s, b, c = oops.mask_roi(rois, delta, prob, np.array([[300, 500, 1]], np.float32), C, 0.5, 0.05, 100, False)
+    assert len(s) >= 100 or len(s) == len(c)
+    assert np.all(np.diff(c) >= 0)                         # class-major output order
+    assert (b[:, 1:] >= 0).all() and (b[:, 3] <= 499).all() and (b[:, 4] <= 299).all() and not b[:, 0].any()
+    s2, b2, c2 = oops.mask_roi(rois, delta, prob * 0, np.array([[300, 500, 1]], np.float32), C, 0.5, 0.05, 100, False)
+    assert s2.tolist() == [1.0] and c2.tolist() == [0] and not b2.any()   # dummy detection
