@@ -76,23 +76,40 @@ int upsnet_mod_deform_im2col(void *stream, const float *data_im, const float *da
 
 /* Fused deformable convolution forward (v1 when mask == NULL, v2 otherwise), the MI355X-native
  * replacement for DeformConvFunction.forward's im2col + torch.mm (functions/deform_conv.py:43-57)
- * with no column buffer: bilinear sampling into LDS tiles feeding fp32 MFMA (v_mfma_f32_32x32x2_f32).
- * Up to 4 feature maps that share the same weights (the FCN head's four FPN levels) go in ONE launch.
- *   x[l]      [H_l, W_l, Cin]  NHWC
- *   offset[l] [Ho_l, Wo_l, dg*2*kh*kw] NHWC (channel order as the reference: 2*(i*kw+j) = dh, +1 = dw)
- *   mask[l]   [Ho_l, Wo_l, dg*kh*kw]  NHWC or NULL array
- *   wpack     [kh*kw*Cin, Cout_pad] (tap-major, channel-minor rows; see upsnet_deform_conv_pack_weight)
- *   bias      [Cout] or NULL;  out[l] [Ho_l, Wo_l, Cout] NHWC;  relu != 0 fuses max(.,0).
- * Pointer/shape arrays are HOST arrays of nlev entries. Cin % 32 == 0, Cout % 32 == 0, Cout <= 256. */
+ * with no column buffer: the dense implicit-GEMM kernel below with a bilinear-gather A operand
+ * (fp32 MFMA, v_mfma_f32_32x32x2_f32). Up to 4 feature maps that share the same weights (the FCN
+ * head's four FPN levels) go in ONE launch.
+ *   x[l]      [H_l, W_l, Cin]  NHWC (batch 1)
+ *   offset[l] [Ho_l, Wo_l, 2*kh*kw] NHWC (channel order as the reference: 2*(i*kw+j) = dh, +1 = dw)
+ *   mask[l]   [Ho_l, Wo_l, kh*kw]  NHWC, or mask == NULL
+ *   wpack     [kh*kw*Cin, ldw] from upsnet_conv_pack_weight; bias [Cout] or NULL
+ *   out[l]    [Ho_l, Wo_l, Cout] NHWC;  relu != 0 fuses max(.,0).
+ * Pointer/shape arrays are HOST arrays of nlev entries. Cin % 32 == 0, deformable_group == 1. */
 int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
                                     const float *const mask[], float *const out[], const int height[],
                                     const int width[], int cin, int cout, int kh, int kw, int pad_h, int pad_w,
                                     int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
-                                    const float *wpack, const float *bias, int relu);
+                                    const float *wpack, int ldw, const float *bias, int relu);
 
-/* weight [Cout, Cin, kh, kw] (reference layout, modules/deform_conv.py:43-44) -> wpack [kh*kw*Cin, Cout]. */
-int upsnet_deform_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw,
-                                   float *wpack);
+/* ============================== Dense convolution ============================== */
+
+/* Replaces nn.Conv2d (+ folded frozen BatchNorm + bias + residual add + ReLU) of the backbone / FPN / RPN / heads
+ * (upsnet/models/resnet.py:53-100, fpn.py:78-104, rpn.py:52-57, rcnn.py:79-87, fcn.py:88-108): NHWC fp32 implicit
+ * GEMM on v_mfma_f32_32x32x2_f32 with a fused epilogue. Up to 5 feature maps sharing the weights per launch.
+ *   x[i] [N_i,H_i,W_i,Cin] NHWC (Cin % 32 == 0), wpack [KH*KW*Cin, ldw] from upsnet_conv_pack_weight (ldw = Cout
+ *   rounded up to a multiple of 32), bias [Cout] or NULL, residual (NULL or array; entries [N_i,Ho,Wo,Cout]),
+ *   out[i] [N_i,Ho,Wo,Cout]; batch == NULL means N_i = 1. Pointer/shape arrays are HOST arrays of nseg entries. */
+int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                           float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                           const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
+                           int relu);
+
+/* Development knob for A/B measurements: pipe = -1 default / 0 / 1 (pinned k-loop pipeline), force_tile = 0 auto,
+ * 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64. Not needed in production. */
+void upsnet_conv_tuning(int pipe, int force_tile);
+
+/* weight [Cout, Cin, kh, kw] (nn.Conv2d layout) -> wpack [kh*kw*Cin, ldw] (tap-major rows, zero-padded columns). */
+int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);
 
 /* ============================== NMS ============================== */
 

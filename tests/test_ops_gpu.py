@@ -95,7 +95,8 @@ def _dcn_ref(x, off, w, b, k, pad, stride, dil, mask=None, relu=False):
 
 
 @pytest.mark.parametrize("cin,cout,sizes,mod,relu", [(32, 32, [(9, 13)], False, False), (64, 128, [(16, 24), (8, 12), (4, 6), (2, 3)], False, True),
-                                                     (32, 64, [(10, 10)], True, False), (32, 256, [(7, 19), (3, 5)], False, False)])
+                                                     (32, 64, [(10, 10)], True, False), (32, 256, [(7, 19), (3, 5)], False, False),
+                                                     (256, 128, [(40, 64), (20, 32)], False, True), (64, 19, [(11, 13)], True, False)])
 def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu):
     rng = np.random.default_rng(4)
     w = (rng.normal(size=(cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
@@ -104,7 +105,8 @@ def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu):
     offs = [(rng.normal(size=(1, 18, h, ww)) * 2).astype(np.float32) for h, ww in sizes]
     masks = [rng.uniform(0, 2, size=(1, 9, h, ww)).astype(np.float32) for h, ww in sizes] if mod else None
     wp = U.pack_dcn_weight(cu(w))
-    assert np.array_equal(wp.cpu().numpy(), w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    assert wp[1] == (cout + 31) // 32 * 32
+    assert np.array_equal(wp[0].cpu().numpy()[:, :cout], w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
     outs = U.deform_conv_fused([cu(x) for x in xs], [cu(o) for o in offs], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1),
                                masks=[cu(m) for m in masks] if mod else None, relu=relu)
     for i, o in enumerate(outs):

@@ -1,0 +1,59 @@
+"""Micro-benchmark of the fp32 MFMA conv / fused DCN kernels on the C1 shapes (development aid)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from upsnet_amd import ops
+
+torch.manual_seed(0)
+from upsnet_amd._lib import lib
+lib().upsnet_conv_tuning(int(os.environ.get('CONV_PIPE', '-1')), int(os.environ.get('CONV_TILE', '0')))
+print('pipe', os.environ.get('CONV_PIPE', '-1'), 'tile', os.environ.get('CONV_TILE', '0'), flush=True)
+reps = int(os.environ.get('REPS', '10'))
+def bench(name, fn, flops, bytes_):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("%-42s %8.3f ms  %7.1f TFLOP/s  %7.1f GB/s" % (name, ms, flops / ms / 1e9, bytes_ / ms / 1e6), flush=True)
+
+cases = [  # name, Cin, Cout, H, W, k, stride
+    ("fpn_p2 3x3 256->256 @256x512", 256, 256, 256, 512, 3, 1),
+    ("res2 conv1 1x1 256->64 @256x512", 256, 64, 256, 512, 1, 1),
+    ("res2 conv2 3x3 64->64 @256x512", 64, 64, 256, 512, 3, 1),
+    ("res2 conv3 1x1 64->256 @256x512", 64, 256, 256, 512, 1, 1),
+    ("res3 conv2 3x3 128->128 @128x256", 128, 128, 128, 256, 3, 1),
+    ("res4 conv2 3x3 256->256 @64x128", 256, 256, 64, 128, 3, 1),
+    ("res4 conv3 1x1 256->1024 @64x128", 256, 1024, 64, 128, 1, 1),
+    ("res5 conv2 3x3 512->512 @32x64", 512, 512, 32, 64, 3, 1),
+    ("fpn lat 1x1 2048->256 @32x64", 2048, 256, 32, 64, 1, 1),
+]
+only = os.environ.get('ONLY')
+for name, cin, cout, H, W, k, st in cases:
+    if only and only not in name: continue
+    x = torch.randn(1, cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, k, k, device='cuda') / (cin * k * k) ** 0.5
+    b = torch.randn(cout, device='cuda')
+    wp, ldw = ops.pack_conv_weight(w)
+    Ho, Wo = H // st, W // st
+    fl = 2.0 * cout * cin * k * k * Ho * Wo
+    by = 4.0 * (cin * H * W + cout * Ho * Wo + cout * cin * k * k)
+    bench("hip  " + name, lambda: ops.conv2d_nhwc(x, wp, ldw, b, cout, k, st, k // 2, relu=True), fl, by)
+    if not os.environ.get('NOTORCH'):
+        wt = w.contiguous(memory_format=torch.channels_last)
+        bench("torch " + name, lambda: F.relu(F.conv2d(x, wt, b, stride=st, padding=k // 2)), fl, by)
+
+if not only or 'dcn' in only:
+    sizes = [(256, 512), (128, 256), (64, 128), (32, 64)]
+    for cin, cout in ((256, 128), (128, 128)):
+        xs = [torch.randn(1, cin, h, w, device='cuda').contiguous(memory_format=torch.channels_last) for h, w in sizes]
+        offs = [(torch.randn(1, 18, h, w, device='cuda') * 2).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+        wgt = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
+        wp = ops.pack_dcn_weight(wgt)
+        hw = sum(h * w for h, w in sizes)
+        bench("dcn fused %d->%d 4 levels" % (cin, cout),
+              lambda: ops.deform_conv_fused(xs, offs, wp, None, cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True),
+              2.0 * cout * cin * 9 * hw, 4.0 * hw * (cin + 18 + cout))

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..config.config import config
+from . import hipconv
 from ..operators.modules.deform_conv import DeformConv, DeformConvWithOffset
 from ..operators.modules.roialign import RoIAlign
 
@@ -65,7 +66,7 @@ class FCNSubNet(nn.Module):
             if not ops.fused_dcn_supported(dc.in_channels, dc.out_channels, dc.deformable_groups, dc.groups):
                 xs = [self.conv[i](x) for x in xs]
                 continue
-            offsets = [layer.conv_offset(x) for x in xs]
+            offsets = hipconv.conv_multi(layer.conv_offset, xs)
             xs = ops.deform_conv_fused(xs, offsets, self._wpack(i, dc), dc.bias, dc.in_channels, dc.out_channels,
                                        dc.kernel_size, dc.stride, dc.padding, dc.dilation, relu=True)
         return xs
@@ -92,7 +93,7 @@ class FCNHead(nn.Module):
         fpn_p4 = F.interpolate(fpn_p4, None, 4, mode='bilinear', align_corners=False)
         fpn_p5 = F.interpolate(fpn_p5, None, 8, mode='bilinear', align_corners=False)
         feat = torch.cat([fpn_p2, fpn_p3, fpn_p4, fpn_p5], dim=1)
-        score = self.score(feat)
+        score = hipconv.conv(self.score, feat)
         ret = {'fcn_score': score, 'fcn_feat': feat}
         if self.upsample_rate != 1:
             ret['fcn_output'] = F.interpolate(score, None, self.upsample_rate, mode='bilinear', align_corners=False)

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..config.config import config
+from . import hipconv
 
 
 class FPN(nn.Module):
@@ -43,20 +44,18 @@ class FPN(nn.Module):
                              align_corners=False if self.upsample_method == 'bilinear' else None)
 
     def forward(self, res2, res3, res4, res5):
-        p5_1x1 = self.fpn_p5_1x1(res5)
-        p4_1x1 = self.fpn_p4_1x1(res4)
-        p3_1x1 = self.fpn_p3_1x1(res3)
-        p2_1x1 = self.fpn_p2_1x1(res2)
+        p5_1x1 = hipconv.conv(self.fpn_p5_1x1, res5)
         if hasattr(self, 'fpn_gap'):
             gap = self.fpn_gap(F.adaptive_avg_pool2d(res5, (1, 1)).flatten(1)).view(-1, self.feature_dim, 1, 1)
             p5_1x1 = p5_1x1 + gap
-        p4_plus = self.fpn_upsample(p5_1x1) + p4_1x1
-        p3_plus = self.fpn_upsample(p4_plus) + p3_1x1
-        p2_plus = self.fpn_upsample(p3_plus) + p2_1x1
-        p5 = self.fpn_p5(p5_1x1)
-        p4 = self.fpn_p4(p4_plus)
-        p3 = self.fpn_p3(p3_plus)
-        p2 = self.fpn_p2(p2_plus)
+        # top-down pathway: the lateral 1x1 and the "+ upsampled" add are one kernel (residual epilogue)
+        p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=self.fpn_upsample(p5_1x1))
+        p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=self.fpn_upsample(p4_plus))
+        p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=self.fpn_upsample(p3_plus))
+        p5 = hipconv.conv(self.fpn_p5, p5_1x1)
+        p4 = hipconv.conv(self.fpn_p4, p4_plus)
+        p3 = hipconv.conv(self.fpn_p3, p3_plus)
+        p2 = hipconv.conv(self.fpn_p2, p2_plus)
         if hasattr(self, 'fpn_p6'):
             return p2, p3, p4, p5, self.fpn_p6(p5)
         return p2, p3, p4, p5

@@ -1,0 +1,57 @@
+"""Route nn.Conv2d layers of the inference graph through the hand-written fp32 MFMA convolution
+(csrc/conv.hip) with fused bias / residual / ReLU epilogues.
+
+`conv(module, x, relu=False, residual=None)` computes relu?(module(x) + residual). Weights are packed once per
+module (cached; re-packed if the parameter changes). Layers the kernel does not cover (the 7x7 stem with
+Cin=3, dilated or grouped convs) and CPU tensors go through the module itself (library convolution) followed
+by the same epilogue in torch -- same math, unfused.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+ENABLED = True
+_cache = {}
+
+
+def _plan(m):
+    w = m.weight
+    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
+    ent = _cache.get(id(m))
+    if ent is None or ent[0] != key:
+        wp, ldw = ops.pack_conv_weight(w.detach())
+        ent = (key, wp, ldw)
+        _cache[id(m)] = ent
+    return ent[1], ent[2]
+
+
+def supported(m, x):
+    return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and
+            ops.conv_supported(m.in_channels, m.kernel_size[0], m.kernel_size[1], m.groups, m.dilation) and
+            m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
+
+
+def conv(m, x, relu=False, residual=None):
+    if supported(m, x):
+        wp, ldw = _plan(m)
+        return ops.conv2d_nhwc(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
+                               relu=relu, residual=residual)
+    y = m(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
+def conv_multi(m, xs, relu=False):
+    """The same conv module applied to several feature maps (FPN levels) in ONE launch."""
+    xs = list(xs)
+    if len(xs) <= 5 and all(supported(m, x) for x in xs):
+        wp, ldw = _plan(m)
+        return ops.conv2d_nhwc_multi(xs, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu)
+    return [conv(m, x, relu=relu) for x in xs]
+
+
+def clear_cache():
+    _cache.clear()

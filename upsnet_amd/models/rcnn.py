@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..config.config import config
+from . import hipconv
 from ..operators.modules.fpn_roi_align import FPNRoIAlign
 from ..operators.modules.roialign import RoIAlign
 
@@ -37,8 +38,9 @@ class MaskBranch(nn.Module):
 
     def forward(self, feat, rois):
         x = self.roi_pooling(feat, rois)
-        x = self.mask_conv4(self.mask_conv3(self.mask_conv2(self.mask_conv1(x))))
-        return self.mask_score(self.mask_deconv1(x))
+        for blk in (self.mask_conv1, self.mask_conv2, self.mask_conv3, self.mask_conv4):
+            x = hipconv.conv(blk[0], x, relu=True)
+        return hipconv.conv(self.mask_score, self.mask_deconv1(x))
 
 
 class RCNN(nn.Module):

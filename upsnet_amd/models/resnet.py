@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from ..config.config import config
 from ..operators.modules.deform_conv import DeformConv
+from . import hipconv
 
 
 def _frozen_bn(ch):
@@ -52,6 +53,14 @@ class _Block(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if isinstance(self.bn1, nn.Identity):  # BN folded: conv + bias (+ residual) + ReLU in one kernel each
+            y = hipconv.conv(self.conv1, x, relu=True)
+            if self.deformable:
+                y = torch.relu_(self.conv2(y, hipconv.conv(self.conv2_offset, y)))
+            else:
+                y = hipconv.conv(self.conv2, y, relu=True)
+            shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x)
+            return hipconv.conv(self.conv3, y, relu=True, residual=shortcut)
         y = torch.relu_(self.bn1(self.conv1(x)))
         y = self.conv2(y, self.conv2_offset(y)) if self.deformable else self.conv2(y)
         y = torch.relu_(self.bn2(y))

@@ -27,7 +27,7 @@ from .fcn import FCNHead
 from .fpn import FPN
 from .rcnn import RCNN, MaskBranch
 from .resnet import ResNetBackbone, fold_frozen_bn, resnet_rcnn
-from .rpn import RPN
+from .rpn import RPN, rpn_forward_levels
 
 
 class resnet_upsnet(resnet_rcnn):
@@ -85,11 +85,7 @@ class resnet_upsnet(resnet_rcnn):
             x = x.contiguous(memory_format=torch.channels_last)
         res2, res3, res4, res5 = self.resnet_backbone(x)
         pyramid = self.fpn(res2, res3, res4, res5)
-        rpn_cls_prob, rpn_bbox_pred = [], []
-        for feat in pyramid:
-            _, bbox_pred, cls_prob = self.rpn(feat)
-            rpn_cls_prob.append(cls_prob)
-            rpn_bbox_pred.append(bbox_pred)
+        _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
         return pyramid, rpn_cls_prob, rpn_bbox_pred
 
     def _tap(self, **kw):

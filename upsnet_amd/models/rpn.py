@@ -2,6 +2,8 @@
 import torch
 import torch.nn as nn
 
+from . import hipconv
+
 
 class RPN(nn.Module):
     def __init__(self, num_anchors=15, input_dim=256, with_norm='none'):
@@ -20,8 +22,16 @@ class RPN(nn.Module):
                 m.bias.data.zero_()
 
     def forward(self, data):
-        x = self.conv_proposal(data)
-        cls_score = self.cls_score(x)
-        bbox_pred = self.bbox_pred(x)
+        x = hipconv.conv(self.conv_proposal[0], data, relu=True)
+        cls_score = hipconv.conv(self.cls_score, x)
+        bbox_pred = hipconv.conv(self.bbox_pred, x)
         cls_prob = torch.sigmoid(cls_score)
         return cls_score, bbox_pred, cls_prob
+
+
+def rpn_forward_levels(rpn, feats):
+    """All pyramid levels through the shared RPN head: 3 launches instead of 3 per level."""
+    xs = hipconv.conv_multi(rpn.conv_proposal[0], feats, relu=True)
+    scores = hipconv.conv_multi(rpn.cls_score, xs)
+    boxes = hipconv.conv_multi(rpn.bbox_pred, xs)
+    return scores, boxes, [torch.sigmoid(s) for s in scores]

@@ -104,23 +104,24 @@ def mod_deform_im2col(data_im, data_offset, data_mask, im_shape, col_shape, kern
 
 
 def pack_dcn_weight(weight):
-    """[Cout,Cin,kh,kw] -> [kh*kw*Cin, Cout] (tap-major rows) for the fused kernel."""
-    require_cuda(weight)
-    weight = f32c(weight)
-    Cout, Cin, kh, kw = weight.shape
-    wp = torch.empty((kh * kw * Cin, Cout), dtype=torch.float32, device=weight.device)
-    check(lib().upsnet_deform_conv_pack_weight(stream(), ptr(weight), Cout, Cin, kh, kw, ptr(wp)), "deform_conv_pack_weight")
-    return wp
+    """[Cout,Cin,kh,kw] -> (wpack [kh*kw*Cin, ldw], ldw): same packing as the dense convolution."""
+    return pack_conv_weight(weight)
 
 
 def fused_dcn_supported(cin, cout, deformable_groups, groups):
-    return groups == 1 and deformable_groups == 1 and cin % 32 == 0 and cout in (32, 64, 128, 256)
+    return groups == 1 and deformable_groups == 1 and cin % 32 == 0
+
+
+def _nhwc_out(n, c, h, w, device):
+    """channels_last [n,c,h,w] output whose memory is NHWC-dense even for degenerate dims."""
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
 
 
 def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, dil, masks=None, relu=False):
     """Fused deformable conv over up to 4 maps sharing weights. xs/offsets/masks: lists of logical NCHW
-    tensors with batch 1; returns channels_last outputs [1,Cout,Ho,Wo]."""
-    require_cuda(wpack, *xs)
+    tensors with batch 1; wpack = (packed weight, ldw) from pack_dcn_weight; returns channels_last outputs."""
+    wp, ldw = wpack
+    require_cuda(wp, *xs)
     n = len(xs)
     assert 1 <= n <= 4 and len(offsets) == n
     xs = [nhwc(x.float()) for x in xs]
@@ -134,7 +135,7 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
         Ho, Wo = out_hw(x.shape[2], x.shape[3], ksize, pad, stride, dil)
         if tuple(o.shape) != (1, 2 * ksize[0] * ksize[1], Ho, Wo):
             raise RuntimeError("deform_conv_fused: offset shape %s != %s" % (tuple(o.shape), (1, 2 * ksize[0] * ksize[1], Ho, Wo)))
-        outs.append(torch.empty((1, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last))
+        outs.append(_nhwc_out(1, cout, Ho, Wo, x.device))
     b = None if bias is None else f32c(bias)
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -143,7 +144,7 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
                                                 ptr_array(masks) if masks is not None else None, ptr_array(outs),
                                                 int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
                                                 int(cin), int(cout), ksize[0], ksize[1], pad[0], pad[1], stride[0], stride[1],
-                                                dil[0], dil[1], 1, ptr(wpack), ptr(b), int(bool(relu))),
+                                                dil[0], dil[1], 1, ptr(wp), int(ldw), ptr(b), int(bool(relu))),
           "deform_conv_forward_nhwc")
     if PROFILE['enabled']:
         ev1.record()
@@ -335,3 +336,51 @@ def panoptic_fuse(fcn_output, num_stuff, mask_rois5, mask_logit, cls_idx, keep, 
                                      ptr(cls_idx.to(torch.int64).contiguous()), ptr(keep), ptr(num), ptr(real), int(min(m, 256)),
                                      ms, ptr(class_map), int(bool(enable_void)), ptr(pan), ptr(sem)), "panoptic_fuse")
     return pan, sem
+
+
+# ----------------------------------------------------------------------------- dense convolution (fp32 MFMA implicit GEMM)
+def conv_supported(cin, kh, kw, groups=1, dilation=(1, 1)):
+    return groups == 1 and tuple(dilation) == (1, 1) and cin % 32 == 0 and kh == kw and kh * kw <= 49
+
+
+def pack_conv_weight(weight):
+    """[Cout,Cin,kh,kw] -> ([kh*kw*Cin, ldw], ldw) with ldw = Cout rounded up to 32 (zero padded columns)."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cout, Cin, kh, kw = weight.shape
+    ldw = (Cout + 31) // 32 * 32
+    wp = torch.empty((kh * kw * Cin, ldw), dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_conv_pack_weight(stream(), ptr(weight), Cout, Cin, kh, kw, ldw, ptr(wp)), "conv_pack_weight")
+    return wp, ldw
+
+
+def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None):
+    """Up to 5 logical-NCHW tensors through the SAME convolution in one launch; returns channels_last outputs.
+    out_i = relu?(conv(x_i) + bias + residual_i)."""
+    require_cuda(wpack, *xs)
+    assert 1 <= len(xs) <= 5
+    xs = [nhwc(x.float()) for x in xs]
+    cin = xs[0].shape[1]
+    outs, ress = [], None
+    for x in xs:
+        N, C, H, W = x.shape
+        if C != cin:
+            raise RuntimeError("conv2d_nhwc_multi: channel mismatch")
+        outs.append(_nhwc_out(N, cout, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, x.device))
+    if residuals is not None:
+        ress = [nhwc(r.float()) for r in residuals]
+        for r, o in zip(ress, outs):
+            if tuple(r.shape) != tuple(o.shape):
+                raise RuntimeError("conv2d_nhwc: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+    check(lib().upsnet_conv2d_nhwc_f32(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None,
+                                       ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
+                                       int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
+                                       ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride),
+                                       int(pad), int(bool(relu))), "conv2d_nhwc_f32")
+    return outs
+
+
+def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residual=None):
+    """x: logical NCHW tensor (any batch); returns a channels_last [N,Cout,Ho,Wo] tensor.
+    out = relu?(conv(x) + bias + residual) in one kernel."""
+    return conv2d_nhwc_multi([x], wpack, ldw, bias, cout, ksize, stride, pad, relu, None if residual is None else [residual])[0]
