@@ -204,6 +204,14 @@ int upsnet_panoptic_fuse(void *stream, const float *fcn_output, int num_seg, int
                          int mask_size, const int64_t *class_map, int enable_void, int64_t *pan_out,
                          int64_t *sem_out);
 
+/* Same as upsnet_panoptic_fuse (enable_void branch) but ALSO fuses FCNHead's x4 bilinear upsampling
+ * (F.interpolate(score, None, 4, 'bilinear', align_corners=False), upsnet/models/fcn.py:101): takes the low-resolution
+ * fcn_score [S,Hs,Ws] (score_nhwc = 0) or [Hs,Ws,S] (score_nhwc = 1); label maps are [Hs*scale, Ws*scale]. */
+int upsnet_panoptic_fuse_up(void *stream, const float *fcn_score, int score_nhwc, int num_seg, int score_h, int score_w,
+                            int scale, int num_stuff, const float *mask_rois, const float *mask_logit,
+                            const int64_t *cls_idx, const int64_t *keep_inds, const int *num_keep, const int *real_keep,
+                            int kmax, int mask_size, const int64_t *class_map, int64_t *pan_out, int64_t *sem_out);
+
 /* Reference-shaped fusion on materialised planes (resnet_upsnet.py:234-243):
  * seg_inst, mask_energy [k,H,W]. */
 int upsnet_panoptic_argmax(void *stream, const float *fcn_output, int num_seg, int height, int width, int num_stuff,

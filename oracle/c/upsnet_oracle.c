@@ -405,3 +405,34 @@ void orc_panoptic_fuse(const float *fcn, int S, int H, int W, int s_stuff, const
     }
     free(logit);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * F.interpolate(score, None, scale, mode='bilinear', align_corners=False) (upsnet/models/fcn.py:101), planar
+ * [S,Hs,Ws] -> [S,Hs*scale,Ws*scale]. Restates PyTorch's upsample_bilinear2d arithmetic (ATen UpSample.cuh:
+ * src = r*(dst+0.5)-0.5 clamped at 0 with r = 1/scale; h1 = (int)src; h1p = h1 < Hs-1; lambda = src - h1;
+ * val = h0*(w0*v00 + w1*v01) + h1l*(w0*v10 + w1*v11)) in fp32 without FMA. PyTorch's own kernel is
+ * compiled with FMA contraction, so this equals torch to ~1 ulp, not bit-for-bit ("parity unpinned" at the
+ * ulp level, like every library op of the reference).
+ * ---------------------------------------------------------------------------------------- */
+void orc_upsample_bilinear(const float *src, int S, int Hs, int Ws, int scale, float *dst)
+{
+    const int H = Hs * scale, W = Ws * scale;
+    const float r = 1.0f / (float)scale;
+    for (int c = 0; c < S; ++c)
+        for (int y = 0; y < H; ++y) {
+            float h1r = r * ((float)y + 0.5f) - 0.5f;
+            if (h1r < 0) h1r = 0;
+            const int h1 = (int)h1r, h1p = h1 < Hs - 1 ? 1 : 0;
+            const float h1l = h1r - (float)h1, h0l = 1.0f - h1l;
+            for (int x = 0; x < W; ++x) {
+                float w1r = r * ((float)x + 0.5f) - 0.5f;
+                if (w1r < 0) w1r = 0;
+                const int w1 = (int)w1r, w1p = w1 < Ws - 1 ? 1 : 0;
+                const float w1l = w1r - (float)w1, w0l = 1.0f - w1l;
+                const float *p = src + (size_t)c * Hs * Ws;
+                const float top = w0l * p[h1 * Ws + w1] + w1l * p[h1 * Ws + w1 + w1p];
+                const float bot = w0l * p[(h1 + h1p) * Ws + w1] + w1l * p[(h1 + h1p) * Ws + w1 + w1p];
+                dst[((size_t)c * H + y) * W + x] = h0l * top + h1l * bot;
+            }
+        }
+}

@@ -3,12 +3,9 @@ upsnet/models/resnet_upsnet.py:88-248.
 
 Two entry points:
 
-* ``forward_oracle(model, data)`` -- the parity chain used by tests/test_model_gpu.py. Dense layers
-  (convolutions / GEMMs, i.e. library code, identical in product and check) run through the model's own
-  torch modules on its device with exactly the tensor shapes the product uses; every custom op between
-  them (proposals, detection selection, mask removal, SegTerm, fusion, semantic argmax) is the CPU
-  oracle. Each custom-op stage is therefore checked bit-for-bit on identical inputs, along real
-  pipeline data.
+* ``check_taps(taps)`` -- the parity chain used by tests/test_model_gpu.py and smoke(): every custom-op stage
+  (proposals, detection selection, mask removal, SegTerm, x4 upsampling, fusion, semantic argmax) is recomputed
+  by the CPU oracle from the tensors recorded during ONE product forward and compared bit-for-bit.
 
 * ``forward_cpu(model_cpu, data)`` -- the whole forward on the host (torch CPU convolutions + oracle ops),
   BASELINE.json configs[0] ("plumbing baseline") and bench.py's cpu_baseline.
@@ -30,44 +27,6 @@ def _np(t):
 def _cfg():
     from upsnet_amd.config.config import config
     return config
-
-
-def forward_oracle(model, data):
-    cfg = _cfg()
-    dev = next(model.parameters()).device
-    C, S = cfg.dataset.num_classes, cfg.dataset.num_seg_classes
-    post = cfg.test.rpn_post_nms_top_n
-    with torch.no_grad():
-        pyramid, rpn_prob, rpn_box = model._trunk(data)
-        feats = list(pyramid[:4])
-        im_info = np.asarray(data['im_info'], np.float32)
-        rois, scores = oops.pyramid_proposal([_np(t) for t in rpn_prob], [_np(t) for t in rpn_box], im_info[0],
-                                             cfg.network.rpn_feat_stride, cfg.network.anchor_scales,
-                                             cfg.network.anchor_ratios, cfg.test.rpn_pre_nms_top_n, post,
-                                             cfg.test.rpn_nms_thresh, cfg.test.rpn_min_size)
-        K = rois.shape[0]
-        rois_pad = np.zeros((post, 5), np.float32)
-        rois_pad[:K] = rois
-        n_dev = torch.tensor([K], dtype=torch.int32, device=dev)
-        fcn_output = model.fcn_head(*feats)['fcn_output']
-        rc = model.rcnn(feats, torch.from_numpy(rois_pad).to(dev), n_dev)
-        cls_prob = _np(F.softmax(rc['cls_score'], dim=1))[:K]
-        bbox_pred = _np(rc['bbox_pred'])[:K]
-        ds, db, dc = oops.mask_roi(rois, bbox_pred, cls_prob, im_info, C, cfg.test.nms_thresh, cfg.test.score_thresh,
-                                   cfg.test.max_det, False, cfg.network.bbox_reg_weights)
-        ps, pb, pc = oops.mask_roi(rois, bbox_pred, cls_prob, im_info, C, 0.5, cfg.test.panoptic_score_thresh,
-                                   cfg.test.max_det, True, cfg.network.bbox_reg_weights)
-        both = torch.from_numpy(np.vstack([db, pb])).to(dev)
-        mask_score = model.mask_branch(feats, both)
-        n_det = db.shape[0]
-        ms = cfg.network.mask_size
-        pan_logit = mask_score[n_det:].gather(1, torch.from_numpy(pc).to(dev).view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
-        fo = _np(fcn_output)
-        head = oops.panoptic_head(fo, pb, ps, _np(pan_logit), pc, S, C, enable_void=model.enable_void)
-    taps = dict(rois=rois, pred_boxes=db, cls_probs=ds, cls_inds=dc, panoptic_cls_inds=head['cls_idx'],
-                panoptic_cls_probs=ps[head['keep_inds']], fcn_outputs=head['sem'], panoptic_outputs=head['panoptic'],
-                mask_probs=_np(torch.sigmoid(mask_score[:n_det])))
-    return dict(n_rois=K, n_det=n_det, n_inst=int(head['k']), taps=taps)
 
 
 def check_taps(taps, enable_void=True):
@@ -99,7 +58,12 @@ def check_taps(taps, enable_void=True):
     res['mask_roi_panoptic'] = (np.array_equal(_np(taps['pan_boxes']), pb) and np.array_equal(_np(taps['pan_scores']), ps) and
                                 np.array_equal(taps['pan_cls'].cpu().numpy(), pc))
     # 3. panoptic head from the recorded mask logits / semantic logits
-    head = oops.panoptic_head(_np(taps['fcn_output']), _np(taps['pan_boxes']), _np(taps['pan_scores']), _np(taps['pan_logit']),
+    if 'fcn_score' in taps:  # fused x4 upsampling: restate F.interpolate (fcn.py:101) from the recorded low-res score
+        from . import upsample_bilinear
+        fcn_out = upsample_bilinear(_np(taps['fcn_score'])[0], 4)[None]
+    else:
+        fcn_out = _np(taps['fcn_output'])
+    head = oops.panoptic_head(fcn_out, _np(taps['pan_boxes']), _np(taps['pan_scores']), _np(taps['pan_logit']),
                               taps['pan_cls'].cpu().numpy(), S, C, enable_void=enable_void)
     res['mask_removal'] = np.array_equal(taps['keep'].cpu().numpy(), head['keep_inds'])
     res['panoptic'] = np.array_equal(taps['panoptic'].cpu().numpy()[0], head['panoptic'])

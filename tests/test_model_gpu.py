@@ -74,7 +74,8 @@ def test_custom_ops_bit_repeatable(setup):
             b, sc, c, _, num = model.mask_roi_panoptic.forward_padded(t['rois'], t['bbox_pred'], t['cls_prob'], t['im_info'], t['n_rois'])
             k = int(num.item())
             assert torch.equal(b[:k], t['pan_boxes']) and torch.equal(c[:k], t['pan_cls'])
-            keep, nk, real = model.mask_removal.select(t['pan_boxes'][:, 1:], t['pan_scores'], t['pan_logit'], t['pan_cls'], t['fcn_output'].shape[2:])
-            pan, sem = ops.panoptic_fuse(t['fcn_output'], 11, t['pan_boxes'], t['pan_logit'], t['pan_cls'], keep, nk, real,
-                                         model.seg_term.class_map, True)
+            H, W = t['fcn_score'].shape[2] * 4, t['fcn_score'].shape[3] * 4
+            keep, nk, real = model.mask_removal.select(t['pan_boxes'][:, 1:], t['pan_scores'], t['pan_logit'], t['pan_cls'], (H, W))
+            pan, sem = ops.panoptic_fuse_up(t['fcn_score'], 4, 11, t['pan_boxes'], t['pan_logit'], t['pan_cls'], keep, nk, real,
+                                            model.seg_term.class_map)
             assert torch.equal(pan, t['panoptic']) and torch.equal(sem, t['sem'])

@@ -309,3 +309,32 @@ def test_mask_removal_modules_and_dummy(U):
     # nothing survives (all logits negative) -> same fallback
     k, e = MaskRemoval(0.3)(cu(rois[:, 1:]), cu(prob), cu(-np.abs(logit) - 1), cu(cls), (96, 160))
     assert k.tolist() == [0] and not e.any()
+
+
+@pytest.mark.parametrize("m,S,C,Hs,Ws,nhwc", [(30, 19, 9, 32, 64, True), (60, 19, 9, 64, 128, False), (1, 19, 9, 16, 16, True),
+                                              (12, 133, 81, 24, 25, True), (40, 19, 9, 256, 512, True)])
+def test_panoptic_fuse_with_fused_upsample_bitexact(U, m, S, C, Hs, Ws, nhwc):
+    """x4 bilinear upsampling of fcn_score fused into the panoptic kernel == oracle (restated F.interpolate + head);
+    agreement with torch's materialised F.interpolate path is reported (ulp-level logit differences only)."""
+    from upsnet_amd.config.config import config
+    config.dataset.num_classes, config.dataset.num_seg_classes = C, S
+    rng = np.random.default_rng(m + S + Hs)
+    H, W = Hs * 4, Ws * 4
+    _, rois, prob, logit, cls = _pan_inputs(rng, m, S, C, H, W)
+    score = rng.normal(0, 3, size=(1, S, Hs, Ws)).astype(np.float32)
+    fcn = oracle.upsample_bilinear(score[0], 4)[None]
+    ref = oops.panoptic_head(fcn, rois, prob, logit, cls, S, C, enable_void=True)
+    keep, num, real = U.mask_removal(cu(rois[:, 1:]), cu(prob), cu(logit), cu(cls), C - 1, (H, W))
+    cmap = cu(oops.class_mapping(S, C))
+    sc = cu(score)
+    if nhwc:
+        sc = sc.contiguous(memory_format=torch.channels_last)
+    pan, sem = U.panoptic_fuse_up(sc, 4, S - (C - 1), cu(rois), cu(logit), cu(cls), keep, num, real, cmap)
+    assert np.array_equal(sem.cpu().numpy()[0], ref['sem'])
+    assert np.array_equal(pan.cpu().numpy()[0], ref['panoptic'])
+    # vs the materialised path through torch's own upsampling kernel
+    up = torch.nn.functional.interpolate(cu(score), None, 4, mode='bilinear', align_corners=False)
+    assert float((up - cu(fcn)).abs().max()) < 1e-5
+    pan2, _ = U.panoptic_fuse(up, S - (C - 1), cu(rois), cu(logit), cu(cls), keep, num, real, cmap, True)
+    assert float((pan2 != pan).float().mean()) < 1e-4
+    config.dataset.num_classes, config.dataset.num_seg_classes = 9, 19

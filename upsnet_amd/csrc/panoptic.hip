@@ -525,3 +525,182 @@ extern "C" int upsnet_panoptic_fuse(void *stream, const float *fcn_output, int n
     UPS_CHECK_LAUNCH("panoptic_fuse_kernel");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused head, variant that ALSO fuses the x`scale` bilinear upsampling of the semantic logits
+// (F.interpolate(score, None, 4, 'bilinear', align_corners=False), upsnet/models/fcn.py:101): reads the
+// low-resolution fcn_score (10 MB at C1) instead of a materialised 159 MB fcn_output. A workgroup owns a
+// 128 x 8 output tile; its (128/scale + 2) x (8/scale + 2) x S source patch is staged in LDS as [c][sy][sx];
+// every logit is re-interpolated from LDS with PyTorch's upsample_bilinear2d arithmetic restated in fp32
+// without FMA (bit-identical to oracle/c: orc_upsample_bilinear).
+#define FUP_TW 128
+#define FUP_TH 8
+#define FUP_MAXS 160      // max semantic classes (133 for COCO)
+
+struct UpCoef { int i0, ip; float l0, l1; };
+__device__ static inline UpCoef fup_coef(int dst, float r, int src_size)
+{
+    UpCoef c;
+    float s = r * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0) s = 0;
+    c.i0 = (int)s;
+    c.ip = c.i0 < src_size - 1 ? 1 : 0;
+    c.l1 = s - (float)c.i0;
+    c.l0 = 1.0f - c.l1;
+    return c;
+}
+
+template <int SCALE>
+__global__ void __launch_bounds__(256)
+panoptic_fuse_up_kernel(const float *__restrict__ score, const long pix_stride, const long ch_stride, const int S,
+                        const int Hs, const int Ws, const int s_stuff, const float *__restrict__ mask_rois,
+                        const float *__restrict__ logits, const int64_t *__restrict__ cls_idx,
+                        const int64_t *__restrict__ keep_inds, const int *__restrict__ num_keep,
+                        const int *__restrict__ real_keep, const int ms, const int64_t *__restrict__ class_map,
+                        const int enable_void, int64_t *__restrict__ pan, int64_t *__restrict__ sem)
+{
+    constexpr int SW = FUP_TW / SCALE + 2, SH = FUP_TH / SCALE + 2;  // source patch incl. halo
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *s_src = reinterpret_cast<float *>(smem_raw);                        // [S][SH][SW]
+    FuseInst *s_inst = reinterpret_cast<FuseInst *>(s_src + (size_t)S * SH * SW);  // [FUSE_MAXK]
+    int *s_list = reinterpret_cast<int *>(s_inst + FUSE_MAXK);
+    unsigned char *s_touch = reinterpret_cast<unsigned char *>(s_list + FUSE_MAXK);
+    __shared__ int s_nlist;
+
+    const int H = Hs * SCALE, W = Ws * SCALE;
+    const long hw = (long)H * W;
+    (void)hw;
+    const int tiles_x = (W + FUP_TW - 1) / FUP_TW;
+    const int ty0 = (blockIdx.x / tiles_x) * FUP_TH, tx0 = (blockIdx.x % tiles_x) * FUP_TW;
+    const int ty1 = min(ty0 + FUP_TH, H), tx1 = min(tx0 + FUP_TW, W);
+    const int k = min(*num_keep, FUSE_MAXK);
+    const bool real = *real_keep != 0;
+    const float r = 1.0f / (float)SCALE;
+
+    // ---- source patch origin: the first source row/col any pixel of the tile touches
+    const int sy0 = fup_coef(ty0, r, Hs).i0, sx0 = fup_coef(tx0, r, Ws).i0;
+    for (int idx = threadIdx.x; idx < S * SH * SW; idx += blockDim.x) {
+        const int c = idx % S, rest = idx / S;   // channel fastest: coalesced for NHWC score
+        const int sx = rest % SW, sy = rest / SW;
+        const int gy = min(sy0 + sy, Hs - 1), gx = min(sx0 + sx, Ws - 1);
+        s_src[(c * SH + sy) * SW + sx] = score[((long)gy * Ws + gx) * pix_stride + (long)c * ch_stride];
+    }
+    if (threadIdx.x == 0) s_nlist = 0;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const long i = keep_inds[j];
+        const float *rr = mask_rois + i * 5;
+        FuseInst fi;
+        fi.mb = pan_box(rr + 1, H, W);
+        const float b0 = (rr[1] * 4.0f) * 0.25f, b1 = (rr[2] * 4.0f) * 0.25f, b2 = (rr[3] * 4.0f) * 0.25f, b3 = (rr[4] * 4.0f) * 0.25f;
+        fi.sb = pan_seg_box(b0, b1, b2, b3, H, W);
+        const int64_t c = cls_idx[i];
+        fi.sem_ch = c != 0 ? (int)class_map[c] : -1;
+        fi.logit_off = (int)(i * ms * ms);
+        s_inst[j] = fi;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const FuseInst &fi = s_inst[j];
+        const bool tm = real && fi.mb.y_0 < ty1 && fi.mb.y_1 > ty0 && fi.mb.x_0 < tx1 && fi.mb.x_1 > tx0;
+        const bool ts = fi.sem_ch >= 0 && fi.sb.y0 < ty1 && fi.sb.y1 > ty0 && fi.sb.x0 < tx1 && fi.sb.x1 > tx0;
+        s_touch[j] = tm || ts;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int n = 0; for (int j = 0; j < k; ++j) if (s_touch[j]) s_list[n++] = j; s_nlist = n; }
+    __syncthreads();
+    const int nlist = s_nlist;
+
+    // thread -> 4 consecutive pixels of one tile row
+    const int y = ty0 + threadIdx.x / (FUP_TW / 4);
+    const int x0 = tx0 + (threadIdx.x % (FUP_TW / 4)) * 4;
+    if (y >= H || x0 >= W) return;
+    const UpCoef cy = fup_coef(y, r, Hs);
+    UpCoef cx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cx[q] = fup_coef(min(x0 + q, W - 1), r, Ws);
+    const int ly0 = cy.i0 - sy0, ly1 = ly0 + cy.ip;
+
+#define FUP_AT(C, Q)                                                                                              \
+    (cy.l0 * (cx[Q].l0 * s_src[((C) * SH + ly0) * SW + cx[Q].i0 - sx0] + cx[Q].l1 * s_src[((C) * SH + ly0) * SW + cx[Q].i0 - sx0 + cx[Q].ip]) + \
+     cy.l1 * (cx[Q].l0 * s_src[((C) * SH + ly1) * SW + cx[Q].i0 - sx0] + cx[Q].l1 * s_src[((C) * SH + ly1) * SW + cx[Q].i0 - sx0 + cx[Q].ip]))
+
+    float best[4], tmax[4], sbest[4];
+    int bi[4], sbi[4];
+    for (int c = 0; c < S; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = FUP_AT(c, q);
+            if (c == 0) { best[q] = v; bi[q] = 0; sbest[q] = v; sbi[q] = 0; }
+            else {
+                if (c < s_stuff && v > best[q]) { best[q] = v; bi[q] = c; }
+                if (v > sbest[q]) { sbest[q] = v; sbi[q] = c; }
+            }
+            if (c == s_stuff) tmax[q] = v;
+            else if (c > s_stuff && v > tmax[q]) tmax[q] = v;
+        }
+    }
+    float mi_listed[4];
+    int n_in[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mi_listed[q] = -INFINITY; n_in[q] = 0; }
+    int li = 0;
+    for (int j = 0; j < k; ++j) {
+        const bool listed = li < nlist && s_list[li] == j;
+        if (listed) ++li;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = x0 + q;
+            float si = 0.f, mk = 0.f;
+            bool inseg = false;
+            if (listed && x < W) {
+                const FuseInst &fi = s_inst[j];
+                if (fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && x >= fi.sb.x0 && x < fi.sb.x1) { si = FUP_AT(fi.sem_ch, q); inseg = true; }
+                if (real && y >= fi.mb.y_0 && y < fi.mb.y_1 && x >= fi.mb.x_0 && x < fi.mb.x_1)
+                    mk = pan_resize_at(logits + fi.logit_off, ms, fi.mb.w, fi.mb.h, x - fi.mb.bx0, y - fi.mb.by0);
+            }
+            const float inst = si + mk;
+            if (inst > best[q]) { best[q] = inst; bi[q] = s_stuff + j; }
+            if (inseg) { if (si > mi_listed[q]) mi_listed[q] = si; ++n_in[q]; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = x0 + q;
+        if (x >= W) continue;
+        float m = mi_listed[q];
+        if (n_in[q] < k) m = fmaxf(m, 0.f);
+        int64_t lab = bi[q];
+        if (enable_void) { const float vd = tmax[q] - m; if (vd > best[q]) lab = 255; }
+        pan[(long)y * W + x] = lab;
+        if (sem) sem[(long)y * W + x] = sbi[q];
+    }
+#undef FUP_AT
+}
+
+extern "C" int upsnet_panoptic_fuse_up(void *stream, const float *fcn_score, int score_nhwc, int num_seg, int score_h, int score_w,
+                                       int scale, int num_stuff, const float *mask_rois, const float *mask_logit,
+                                       const int64_t *cls_idx, const int64_t *keep_inds, const int *num_keep, const int *real_keep,
+                                       int kmax, int mask_size, const int64_t *class_map, int64_t *pan_out, int64_t *sem_out)
+{
+    UPS_REQUIRE(fcn_score && mask_rois && mask_logit && cls_idx && keep_inds && num_keep && real_keep && class_map && pan_out,
+                "panoptic_fuse_up: null pointer");
+    UPS_REQUIRE(scale == 4, "panoptic_fuse_up: only the x4 upsampling of FCNHead (upsample_rate=4) is built (got %d)", scale);
+    UPS_REQUIRE(num_stuff >= 1 && num_stuff < num_seg && num_seg <= FUP_MAXS, "panoptic_fuse_up: bad channel split %d/%d", num_stuff, num_seg);
+    UPS_REQUIRE(kmax >= 1 && kmax <= FUSE_MAXK, "panoptic_fuse_up: at most %d instances supported (got %d)", FUSE_MAXK, kmax);
+    UPS_REQUIRE(mask_size >= 2 && mask_size <= PAN_MAXMS, "panoptic_fuse_up: bad mask size");
+    const int H = score_h * scale, W = score_w * scale;
+    const int tiles = ((W + FUP_TW - 1) / FUP_TW) * ((H + FUP_TH - 1) / FUP_TH);
+    const size_t smem = (size_t)num_seg * (FUP_TH / 4 + 2) * (FUP_TW / 4 + 2) * sizeof(float) + FUSE_MAXK * (sizeof(FuseInst) + sizeof(int) + 1) + 16;
+    const long pix_stride = score_nhwc ? num_seg : 1, ch_stride = score_nhwc ? 1 : (long)score_h * score_w;
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panoptic_fuse_up_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(panoptic_fuse_up_kernel<4>, dim3(tiles), dim3(256), smem, (hipStream_t)stream, fcn_score, pix_stride, ch_stride,
+                       num_seg, score_h, score_w, num_stuff, mask_rois, mask_logit, cls_idx, keep_inds, num_keep, real_keep, mask_size,
+                       class_map, 1, pan_out, sem_out);
+    UPS_CHECK_LAUNCH("panoptic_fuse_up_kernel");
+    return 0;
+}

@@ -87,6 +87,14 @@ class FCNHead(nn.Module):
         nn.init.normal_(self.score.weight.data, 0, 0.01)
         self.score.bias.data.zero_()
 
+    def forward_score(self, fpn_p2, fpn_p3, fpn_p4, fpn_p5):
+        """fcn_score only ([1,S,H/4,W/4]); the x4 upsampling is fused into the panoptic kernel by the caller."""
+        fpn_p2, fpn_p3, fpn_p4, fpn_p5 = self.fcn_subnet.forward_levels([fpn_p2, fpn_p3, fpn_p4, fpn_p5])
+        fpn_p3 = F.interpolate(fpn_p3, None, 2, mode='bilinear', align_corners=False)
+        fpn_p4 = F.interpolate(fpn_p4, None, 4, mode='bilinear', align_corners=False)
+        fpn_p5 = F.interpolate(fpn_p5, None, 8, mode='bilinear', align_corners=False)
+        return hipconv.conv(self.score, torch.cat([fpn_p2, fpn_p3, fpn_p4, fpn_p5], dim=1))
+
     def forward(self, fpn_p2, fpn_p3, fpn_p4, fpn_p5, roi=None):
         fpn_p2, fpn_p3, fpn_p4, fpn_p5 = self.fcn_subnet.forward_levels([fpn_p2, fpn_p3, fpn_p4, fpn_p5])
         fpn_p3 = F.interpolate(fpn_p3, None, 2, mode='bilinear', align_corners=False)

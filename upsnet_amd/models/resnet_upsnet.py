@@ -105,13 +105,25 @@ class resnet_upsnet(resnet_rcnn):
         feats = list(pyramid[:4])
         im_info = data['im_info']
         rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
-        fcn_output = self.fcn_head(*feats)['fcn_output']
+        # x4 upsampling of the semantic logits is fused into the panoptic kernel (enable_void branch, rate 4)
+        fuse_up = self.enable_void and self.fcn_head.upsample_rate == 4
+        if fuse_up:
+            fcn_score = self.fcn_head.forward_score(*feats)
+            fcn_output = None
+            H, W = fcn_score.shape[2] * 4, fcn_score.shape[3] * 4
+        else:
+            fcn_output = self.fcn_head(*feats)['fcn_output']
+            H, W = fcn_output.shape[2:]
 
         rcnn_output = self.rcnn(feats, rois, n_rois)
         cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
         bbox_pred = rcnn_output['bbox_pred']
         self._tap(rpn_cls_prob=[t.detach().clone() for t in rpn_cls_prob], rpn_bbox_pred=[t.detach().clone() for t in rpn_bbox_pred],
-                  im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred, fcn_output=fcn_output)
+                  im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
+        if fuse_up:
+            self._tap(fcn_score=fcn_score)
+        else:
+            self._tap(fcn_output=fcn_output)
 
         # both detection selections are launched back to back; ONE host read of the two counters
         det_boxes, det_scores, det_cls, _, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
@@ -128,14 +140,18 @@ class resnet_upsnet(resnet_rcnn):
 
         self._tap(det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls, pan_boxes=pan_boxes, pan_scores=pan_scores,
                   pan_cls=pan_cls, pan_logit=pan_logit)
-        H, W = fcn_output.shape[2:]
         keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
-        if n_pan > 256:  # beyond the fused kernel's instance table: reference-shaped materialising path
+        cmap = self.seg_term.class_map.to(pan_boxes.device)
+        if n_pan > 256:  # beyond the fused kernels' instance table: reference-shaped materialising path
+            if fcn_output is None:
+                fcn_output = F.interpolate(fcn_score, None, 4, mode='bilinear', align_corners=False)
             panoptic, sem = self._materialised_head(fcn_output, pan_boxes, pan_logit, pan_cls, keep, num_keep, real_keep)
+        elif fuse_up:
+            panoptic, sem = ops.panoptic_fuse_up(fcn_score, 4, num_stuff, pan_boxes, pan_logit, pan_cls, keep, num_keep, real_keep, cmap)
         else:
-            panoptic, sem = ops.panoptic_fuse(fcn_output, num_stuff, pan_boxes, pan_logit, pan_cls, keep, num_keep,
-                                              real_keep, self.seg_term.class_map.to(fcn_output.device), self.enable_void)
+            panoptic, sem = ops.panoptic_fuse(fcn_output, num_stuff, pan_boxes, pan_logit, pan_cls, keep, num_keep, real_keep, cmap,
+                                              self.enable_void)
         k = int(num_keep.item())
         keep = keep[:k]
         self._tap(keep=keep, panoptic=panoptic, sem=sem)

@@ -384,3 +384,24 @@ def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, resid
     """x: logical NCHW tensor (any batch); returns a channels_last [N,Cout,Ho,Wo] tensor.
     out = relu?(conv(x) + bias + residual) in one kernel."""
     return conv2d_nhwc_multi([x], wpack, ldw, bias, cout, ksize, stride, pad, relu, None if residual is None else [residual])[0]
+
+
+def panoptic_fuse_up(fcn_score, scale, num_stuff, mask_rois5, mask_logit, cls_idx, keep, num, real, class_map, want_sem=True):
+    """Fused head INCLUDING FCNHead's x4 bilinear upsampling: takes the low-resolution fcn_score [1,S,Hs,Ws]
+    (logical NCHW; channels_last memory is consumed as is) and returns (panoptic, semantic) [1,Hs*scale,Ws*scale] int64."""
+    require_cuda(fcn_score, mask_rois5, mask_logit, cls_idx)
+    sc = fcn_score.float()
+    _, S, Hs, Ws = sc.shape
+    is_nhwc = (not sc.is_contiguous()) and sc.is_contiguous(memory_format=torch.channels_last)
+    sc = sc if is_nhwc else sc.contiguous()
+    mask_rois5 = f32c(mask_rois5)
+    m = mask_rois5.shape[0]
+    mask_logit = f32c(mask_logit).reshape(m, -1)
+    ms = int(round(mask_logit.shape[1] ** 0.5))
+    H, W = Hs * scale, Ws * scale
+    pan = torch.empty((1, H, W), dtype=torch.int64, device=sc.device)
+    sem = torch.empty((1, H, W), dtype=torch.int64, device=sc.device) if want_sem else None
+    check(lib().upsnet_panoptic_fuse_up(stream(), ptr(sc), int(is_nhwc), S, Hs, Ws, int(scale), int(num_stuff), ptr(mask_rois5),
+                                        ptr(mask_logit), ptr(cls_idx.to(torch.int64).contiguous()), ptr(keep), ptr(num), ptr(real),
+                                        int(min(m, 256)), ms, ptr(class_map), ptr(pan), ptr(sem)), "panoptic_fuse_up")
+    return pan, sem
