@@ -102,7 +102,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle.forward import cpu_copy, forward_cpu
         from upsnet_amd.synthetic import make_image
-        cores = os.cpu_count()
+        # 256 hardware threads make torch-CPU convolutions of this size slower, not faster (measured: 47 s vs a few
+        # seconds for the backbone); use a fixed, stated thread count
+        cores = min(32, os.cpu_count() or 1)
         torch.set_num_threads(cores)
         sc = args.cpu_baseline_scale
         h, w = int(H * sc) // 32 * 32, int(W * sc) // 32 * 32
@@ -116,19 +118,23 @@ def main():
         full = dt * (H * W) / float(h * w)
         cpu_baseline = {'value': round(1.0 / full, 5), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
                         'sample': '1 image %dx%d (%.2fx linear scale of the workload) in %.1f s, extrapolated by pixel count; '
-                                  'torch-CPU convs on %d threads + single-thread C oracle ops' % (h, w, sc, dt, cores),
+                                  'torch-CPU convs on %d threads (host has %d) + single-thread C oracle ops' % (h, w, sc, dt, cores, os.cpu_count()),
                         'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
                         'n_inst': out_cpu['n_inst']}
 
     last = res['last_out']
     line = {
-        'metric': 'images/sec (whole node), UPSNet-50 1024x2048', 'value': round(value, 4), 'unit': 'images/sec',
+        'metric': 'images/sec (whole node), %s' % {'upsnet50_cityscapes_1024x2048': 'UPSNet-50 1024x2048',
+                                                   'upsnet101dcn_coco_800x1333': 'UPSNet-101-DCN 800x1333'}.get(args.workload, args.workload),
+        'value': round(value, 4), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
         'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
-                   'backbone': 'PyTorch-ROCm (MIOpen) fp32, channels_last, frozen BN folded',
-                   'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, panoptic fusion',
+                   'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip), NHWC, frozen BN folded, bias/residual/ReLU fused; '
+                                  '7x7 stem + 2x2 deconv + FC GEMMs on PyTorch-ROCm',
+                   'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
+                                 'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank, final RCCL all_gather',
                    'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
         'roofline': roofline, 'cpu_baseline': cpu_baseline,

@@ -79,3 +79,25 @@ def test_custom_ops_bit_repeatable(setup):
             pan, sem = ops.panoptic_fuse_up(t['fcn_score'], 4, 11, t['pan_boxes'], t['pan_logit'], t['pan_cls'], keep, nk, real,
                                             model.seg_term.class_map)
             assert torch.equal(pan, t['panoptic']) and torch.equal(sem, t['sem'])
+
+
+def test_coco_r101_dcn_config_stagewise_parity():
+    """BASELINE.json configs[3] shape family: UPSNet-101-DCN (DCN v1 in every res3-5 block, GAP in FPN, 3 FCN layers,
+    81 / 133 classes, 300 proposals) on a small COCO-shaped image; every custom-op stage vs the oracle."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN, CITYSCAPES_R50
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model(cls_gain=0.3)
+        assert sum(1 for n, _ in model.named_modules() if n.endswith('conv2_offset')) == 4 + 23 + 3
+        data = make_image(200, 333, seed=2, device='cuda')   # padded to 224 x 352
+        model.taps = {}
+        with torch.no_grad():
+            out = model(data)
+        res = check_taps(model.taps, enable_void=True)
+        counts = res.pop('counts')
+        assert all(res.values()), (res, counts)
+        assert counts['n_rois'] <= 300 and out['panoptic_outputs'].shape == (1, 224, 352)
+    finally:
+        update_config_dict(CITYSCAPES_R50)

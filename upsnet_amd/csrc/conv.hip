@@ -341,8 +341,11 @@ static int conv_launch(hipStream_t st, ConvParams &p)
     return 0;
 }
 
-// Tile choice: the largest tile that still yields >= 2 workgroups per CU (256 CUs); small feature maps (res4/res5,
-// P4/P5) fall back to 64-pixel tiles so the chip stays filled. upsnet_conv_tuning(pipe, force_tile) overrides for A/B runs.
+// Tile choice (measured on MI355X over every conv shape of UPSNet-50 @1024x2048, tools/sweep_conv_tiles.py): on this chip
+// the fp32 MFMA kernel is occupancy-bound -- the 64-pixel tiles (88-150 registers, 33-50 KiB LDS -> 3-5 waves per SIMD)
+// beat the 128x128 tile (208 registers, 66 KiB -> 2 waves) on almost every layer. 64x128 wins for the large 3x3 layers
+// and for the deformable variant (A operand = expensive gather, computed once per 128 output channels); 64x64 elsewhere.
+// upsnet_conv_tuning(pipe, force_tile) overrides for A/B runs.
 static int g_pipe = -1, g_force_tile = 0;
 extern "C" void upsnet_conv_tuning(int pipe, int force_tile) { g_pipe = pipe; g_force_tile = force_tile; }
 
@@ -352,14 +355,11 @@ static int conv_dispatch2(hipStream_t st, ConvParams &p)
     long M = 0;
     for (int i = 0; i < p.nseg; ++i) M += p.seg[i].M;
     const bool n128 = p.ldw % 128 == 0, n64 = p.ldw % 64 == 0;
-    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
     int tile = g_force_tile;
     if (!tile) {
-        if (n128 && blocks(128, 128) >= 512) tile = 1;
-        else if (n64 && blocks(128, 64) >= 512) tile = 2;
-        else if (n128 && blocks(64, 128) >= 400) tile = 4;
-        else if (n64) tile = 5;
-        else tile = 3;
+        if (DEFORM) tile = n128 ? 4 : (n64 ? 5 : 3);
+        else if (n128 && p.KH * p.KW > 1 && M >= 32768) tile = 4;
+        else tile = n64 ? 5 : 3;
     }
     if (tile == 1 && !n128) tile = n64 ? 2 : 3;
     if ((tile == 2 || tile == 5) && !n64) tile = 3;
@@ -376,7 +376,7 @@ static int conv_dispatch2(hipStream_t st, ConvParams &p)
 template <int DEFORM>
 static int conv_dispatch(hipStream_t st, ConvParams &p)
 {
-    const int pipe = g_pipe >= 0 ? g_pipe : (DEFORM ? 0 : 1);
+    const int pipe = g_pipe >= 0 ? g_pipe : 1;
     return pipe ? conv_dispatch2<DEFORM, 1>(st, p) : conv_dispatch2<DEFORM, 0>(st, p);
 }
 

@@ -76,32 +76,57 @@ nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ count
     }
 }
 
-__global__ void __launch_bounds__(64)
-nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, const int *__restrict__ counts,
-                const uint8_t *__restrict__ pre_removed, const int nmax, const int CB, int *__restrict__ keep_idx,
-                int *__restrict__ keep_cnt)
+// uniform-lane read of a 64-bit value: v_readlane (scalar path, a few cycles) instead of a shuffle through the
+// LDS crossbar; `src` must be wave-uniform.
+__device__ static inline u64 readlane64(u64 v, int src)
 {
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, s), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s);
+    return ((u64)hi << 32) | lo;
+}
+
+#define NMS_SCAN_T 256
+#define NMS_LDS_ROWS 1024   // problems up to this many boxes keep their whole suppression mask in LDS (128 KiB)
+
+// One workgroup per problem; all threads stage the mask rows into LDS (when they fit), wave 0 does the greedy scan.
+__global__ void __launch_bounds__(NMS_SCAN_T)
+nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, const int *__restrict__ counts,
+                const uint8_t *__restrict__ pre_removed, const int nmax, const int CB, const int use_lds,
+                int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *smask = reinterpret_cast<u64 *>(smem_raw);
+    const int p = blockIdx.x, tid = threadIdx.x;
     const int n = min(counts[p], nmax);
     const int nb = (n + 63) >> 6;
     const u64 *mp = mask + (long)p * nmax * CB;
+    if (use_lds) {
+        // only words (row i, column block >= i/64) were produced by nms_mask_kernel; copy exactly those
+        for (int idx = tid; idx < n * nb; idx += NMS_SCAN_T) {
+            const int i = idx / nb, cb = idx - i * nb;
+            if (cb >= (i >> 6)) smask[i * nb + cb] = mp[(long)i * CB + cb];
+        }
+        __syncthreads();
+    }
+    if (tid >= 64) return;
+    const int lane = tid;
     const int *ord = order ? order + (long)p * nmax : nullptr;
     u64 remv0 = 0, remv1 = 0;  // suppression words `lane` and `lane + 64`
     int nkeep = 0;
     const int w0 = lane, w1 = lane + 64;
     for (int b = 0; b < nb; ++b) {
-        const u64 cur = shfl64(b < 64 ? remv0 : remv1, b & 63);
+        const u64 cur = readlane64(b < 64 ? remv0 : remv1, b & 63);
         const int i = b * 64 + lane;
         const bool valid = i < n;
         const int oi = valid ? (ord ? ord[i] : i) : 0;
         const bool pre = valid && pre_removed && pre_removed[(long)p * nmax + oi];
-        const u64 diag = valid ? mp[(long)i * CB + b] : 0;
+        const u64 diag = valid ? (use_lds ? smask[i * nb + b] : mp[(long)i * CB + b]) : 0;
         u64 alive = ~cur & __ballot(valid) & ~__ballot(pre);
         u64 kept = 0;
         while (alive) {
             const int t = __builtin_ctzll(alive);
             kept |= 1ULL << t;
-            alive &= ~shfl64(diag, t);
+            alive &= ~readlane64(diag, t);
             alive &= ~(1ULL << t);
         }
         if ((kept >> lane) & 1ULL)
@@ -109,21 +134,27 @@ nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, con
         nkeep += __builtin_popcountll(kept);
         const bool a0 = w0 > b && w0 < nb, a1 = w1 > b && w1 < nb;
         u64 kk = kept;
-        while (kk) {  // 4 independent row reads in flight per trip
-            long r[4];
-            int cnt = 0;
+        if (use_lds) {
+            u64 acc = 0;
+            while (kk) { const int t = __builtin_ctzll(kk); kk &= kk - 1; if (a0) acc |= smask[(b * 64 + t) * nb + w0]; }
+            remv0 |= acc;
+        } else {
+            while (kk) {  // 4 independent row reads in flight per trip
+                long r[4];
+                int cnt = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (kk) { r[q] = (long)(b * 64 + __builtin_ctzll(kk)) * CB; kk &= kk - 1; cnt = q + 1; } else r[q] = -1;
-            }
-            u64 v0[4], v1[4];
+                for (int q = 0; q < 4; ++q) {
+                    if (kk) { r[q] = (long)(b * 64 + __builtin_ctzll(kk)) * CB; kk &= kk - 1; cnt = q + 1; } else r[q] = -1;
+                }
+                u64 v0[4], v1[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v0[q] = (a0 && q < cnt) ? mp[r[q] + w0] : 0;
-                v1[q] = (a1 && q < cnt) ? mp[r[q] + w1] : 0;
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = (a0 && q < cnt) ? mp[r[q] + w0] : 0;
+                    v1[q] = (a1 && q < cnt) ? mp[r[q] + w1] : 0;
+                }
+                remv0 |= v0[0] | v0[1] | v0[2] | v0[3];
+                remv1 |= v1[0] | v1[1] | v1[2] | v1[3];
             }
-            remv0 |= v0[0] | v0[1] | v0[2] | v0[3];
-            remv1 |= v1[0] | v1[1] | v1[2] | v1[3];
         }
     }
     if (lane == 0) keep_cnt[p] = nkeep;
@@ -171,8 +202,18 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     UPS_CHECK_LAUNCH("nms_sort_kernel");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, w.mask);
     UPS_CHECK_LAUNCH("nms_mask_kernel");
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(64), 0, st, w.mask, w.order, counts, pre_removed, nmax, CB, keep_idx,
-                       keep_cnt);
+    const int use_lds = nmax <= NMS_LDS_ROWS;
+    const size_t scan_smem = use_lds ? (size_t)nmax * CB * sizeof(u64) : 0;
+    if (scan_smem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_scan_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, NMS_LDS_ROWS * (NMS_LDS_ROWS / 64) * 8));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(NMS_SCAN_T), scan_smem, st, w.mask, w.order, counts, pre_removed, nmax, CB,
+                       use_lds, keep_idx, keep_cnt);
     UPS_CHECK_LAUNCH("nms_scan_kernel");
     return 0;
 }
@@ -219,8 +260,8 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
             hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = ups_set_error("nms_host: H2D copy failed"); break; }
         hipLaunchKernelGGL(nms_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, raw, n, boxes_dim, packed);
         hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, mask);
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, 0, mask, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
-                           n, CB, keep, kc);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_T), 0, 0, mask, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
+                           n, CB, 0, keep, kc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { rc = ups_set_error("nms_host: launch failed: %s", hipGetErrorString(e)); break; }
         if (hipMemcpy(num_out, kc, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||

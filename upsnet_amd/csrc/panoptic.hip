@@ -19,6 +19,7 @@
 #include "upsnet_hip.h"
 
 #define PAN_T 1024
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 #define PAN_MAXDIM 4096   // max box side handled by the removal kernel's coefficient tables
 #define PAN_MAXINST 1024  // max instances entering mask removal
 #define PAN_MAXMS 32      // max mask side (28 in every config)
@@ -87,57 +88,103 @@ __device__ static inline long pan_block_sum(long v, long *sh)
     return t;
 }
 
+// Mask removal in two phases.
+//  A (mask_bits_kernel, fully parallel over instances x rows x 64-pixel words): resample each instance's 28x28
+//    logits into its box, threshold (> 0) and pack the result as a bitmap aligned to image columns
+//    (bits[(inst*H + y)*WW + x/64]); mask_sum[inst] = popcount total.
+//  B (mask_removal_kernel, one workgroup per thing class): walk that class's instances in global score order;
+//    overlap = popcount(bits & occupancy_bits[class]) over the box, decide with the reference's integer/fp64 rule
+//    (mask_removal.py:82), OR the kept bitmap into the class occupancy. The per-instance critical path is a few
+//    microseconds of 64-bit AND/popcount instead of a full resample of the box.
+__global__ void __launch_bounds__(256)
+mask_bits_kernel(const float *__restrict__ rois, const float *__restrict__ logits, const int m, const int ms, const int H,
+                 const int W, const int WW, unsigned long long *__restrict__ bits, int *__restrict__ mask_sum)
+{
+    __shared__ float s_logit[PAN_MAXMS * PAN_MAXMS];
+    const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < ms * ms; q += blockDim.x) s_logit[q] = logits[(long)inst * ms * ms + q];
+    __syncthreads();
+    const PanBox b = pan_box(rois + (long)inst * 4, H, W);
+    const int rx = b.x_1 - b.x_0, ry = b.y_1 - b.y_0;
+    if (rx <= 0 || ry <= 0) return;
+    const int wc0 = b.x_0 >> 6, nw = ((b.x_1 - 1) >> 6) - wc0 + 1;
+    const long items = (long)ry * nw;
+    int local = 0;
+    for (long it = (long)blockIdx.y * 4 + wave; it < items; it += (long)gridDim.y * 4) {
+        const int yy = (int)(it / nw), wc = wc0 + (int)(it % nw);
+        const int y = b.y_0 + yy, x = wc * 64 + lane;
+        bool on = false;
+        if (x >= b.x_0 && x < b.x_1) on = pan_resize_at(s_logit, ms, b.w, b.h, x - b.bx0, y - b.by0) > 0;
+        const unsigned long long word = __ballot(on);
+        if (lane == 0) { bits[((long)inst * H + y) * WW + wc] = word; local += __builtin_popcountll(word); }
+    }
+    if (lane == 0 && local) atomicAdd(&mask_sum[inst], local);
+}
+
 // grid = num_thing_classes, block = PAN_T
 __global__ void __launch_bounds__(PAN_T)
-mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ prob, const float *__restrict__ logits,
-                    const int64_t *__restrict__ cls_idx, const int m, const int ms, const int H, const int W,
-                    const double fraction_threshold, uint8_t *__restrict__ occupancy, int *__restrict__ sorted_idx,
-                    uint8_t *__restrict__ kept_flag)
+mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ prob, const int64_t *__restrict__ cls_idx,
+                    const int m, const int H, const int W, const int WW, const double fraction_threshold,
+                    const unsigned long long *__restrict__ bits, const int *__restrict__ mask_sum,
+                    unsigned long long *__restrict__ occbits, int *__restrict__ sorted_idx, uint8_t *__restrict__ kept_flag)
 {
     __shared__ ups_u64 s_keys[PAN_MAXINST];
-    __shared__ float s_logit[PAN_MAXMS * PAN_MAXMS];
-    __shared__ short s_cx0[PAN_MAXDIM], s_cx1[PAN_MAXDIM], s_cy0[PAN_MAXDIM], s_cy1[PAN_MAXDIM];
-    __shared__ float s_fx[PAN_MAXDIM], s_fy[PAN_MAXDIM];
+    __shared__ int s_my[PAN_MAXINST];
+    __shared__ float s_box[PAN_MAXINST][4];
     __shared__ long s_red[PAN_T / 64];
-    const int tid = threadIdx.x, my_cls = blockIdx.x;
+    __shared__ int s_cnt[PAN_T / 64];
+    const int tid = threadIdx.x, my_cls = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = ups_next_pow2(m < 64 ? 64 : m);
     for (int i = tid; i < M; i += PAN_T) s_keys[i] = i < m ? ups_make_key(prob[i], (unsigned)i, 0) : 0ULL;
     ups_block_sort_desc(s_keys, M);
-    uint8_t *__restrict__ occ = occupancy + (long)my_cls * H * W;
-    for (int si = 0; si < m; ++si) {
-        const int i = (int)ups_key_index(s_keys[si], 0);
-        if (my_cls == 0 && tid == 0) sorted_idx[si] = i;
-        if ((int)cls_idx[i] - 1 != my_cls) continue;  // uniform
-        const PanBox b = pan_box(rois + (long)i * 4, H, W);
+    // ---- ordered compaction of this class's instances (m <= PAN_MAXINST == PAN_T: one element per thread)
+    int idx = 0;
+    bool mine = false;
+    if (tid < m) {
+        idx = (int)ups_key_index(s_keys[tid], 0);
+        if (my_cls == 0) sorted_idx[tid] = idx;
+        mine = (int)cls_idx[idx] - 1 == my_cls;
+    }
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0) s_cnt[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int base = 0, n_my = 0;
+    for (int w = 0; w < PAN_T / 64; ++w) { const int c = s_cnt[w]; if (w < wave) base += c; n_my += c; }
+    if (mine) {
+        const int pos = base + __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));
+        s_my[pos] = tid;
+        s_box[pos][0] = rois[(long)idx * 4 + 0]; s_box[pos][1] = rois[(long)idx * 4 + 1];
+        s_box[pos][2] = rois[(long)idx * 4 + 2]; s_box[pos][3] = rois[(long)idx * 4 + 3];
+    }
+    __syncthreads();
+    unsigned long long *__restrict__ occ = occbits + (long)my_cls * H * WW;
+    for (int j = 0; j < n_my; ++j) {
+        const int si = s_my[j];
+        const int inst = (int)ups_key_index(s_keys[si], 0);
+        const PanBox b = pan_box(s_box[j], H, W);
         const int rx = b.x_1 - b.x_0, ry = b.y_1 - b.y_0;
         bool keep = false;
         if (rx > 0 && ry > 0) {
-            __syncthreads();
-            for (int q = tid; q < ms * ms; q += PAN_T) s_logit[q] = logits[(long)i * ms * ms + q];
-            for (int q = tid; q < rx; q += PAN_T) { int a, c; float f; pan_lin_coef(b.x_0 - b.bx0 + q, b.w, ms, a, c, f); s_cx0[q] = (short)a; s_cx1[q] = (short)c; s_fx[q] = f; }
-            for (int q = tid; q < ry; q += PAN_T) { int a, c; float f; pan_lin_coef(b.y_0 - b.by0 + q, b.h, ms, a, c, f); s_cy0[q] = (short)a; s_cy1[q] = (short)c; s_fy[q] = f; }
-            __syncthreads();
-            const long area = (long)rx * ry;
-            long sum = 0, ov = 0;
-            for (long t = tid; t < area; t += PAN_T) {
-                const int yy = (int)(t / rx), xx = (int)(t % rx);
-                const float v = pan_resize_coef(s_logit, ms, s_cx0[xx], s_cx1[xx], s_fx[xx], s_cy0[yy], s_cy1[yy], s_fy[yy]);
-                if (v > 0) {
-                    ++sum;
-                    if (occ[(long)(b.y_0 + yy) * W + b.x_0 + xx] >= 1) ++ov;
+            const long sum = mask_sum[inst];
+            if (sum > 0) {
+                const int wc0 = b.x_0 >> 6, nw = ((b.x_1 - 1) >> 6) - wc0 + 1;
+                const long items = (long)ry * nw;
+                const unsigned long long *__restrict__ bj = bits + (long)inst * H * WW;
+                long ov = 0;
+                for (long it = tid; it < items; it += PAN_T) {
+                    const long off = (long)(b.y_0 + (int)(it / nw)) * WW + wc0 + (int)(it % nw);
+                    ov += __builtin_popcountll(bj[off] & occ[off]);
                 }
-            }
-            sum = pan_block_sum(sum, s_red);
-            ov = pan_block_sum(ov, s_red);
-            keep = sum > 0 && !((double)ov / (double)sum > fraction_threshold);  // mask_removal.py:82
-            if (keep) {
-                for (long t = tid; t < area; t += PAN_T) {
-                    const int yy = (int)(t / rx), xx = (int)(t % rx);
-                    const float v = pan_resize_coef(s_logit, ms, s_cx0[xx], s_cx1[xx], s_fx[xx], s_cy0[yy], s_cy1[yy], s_fy[yy]);
-                    if (v > 0) occ[(long)(b.y_0 + yy) * W + b.x_0 + xx] += 1;
+                ov = pan_block_sum(ov, s_red);
+                keep = !((double)ov / (double)sum > fraction_threshold);  // mask_removal.py:82
+                if (keep) {
+                    for (long it = tid; it < items; it += PAN_T) {
+                        const long off = (long)(b.y_0 + (int)(it / nw)) * WW + wc0 + (int)(it % nw);
+                        occ[off] |= bj[off];
+                    }
                 }
+                __syncthreads();  // occupancy updated before the next instance of this class reads it
             }
-            __syncthreads();
         }
         if (tid == 0) kept_flag[si] = keep ? 1 : 0;
     }
@@ -157,12 +204,24 @@ mask_removal_finalize_kernel(const int64_t *__restrict__ cls_idx, const int m, c
     else { *num_keep = k; *real_keep = 1; }
 }
 
-static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-extern "C" size_t upsnet_mask_removal_workspace_bytes(int m, int ncls, int H, int W)
+struct MrPlan { size_t occ, bits, sums, sorted, kept, total; int WW; };
+static MrPlan mr_plan(int m, int ncls, int H, int W)
 {
-    return al256((size_t)(ncls < 1 ? 1 : ncls) * H * W) + al256((size_t)(m < 1 ? 1 : m) * 4) + al256((size_t)(m < 1 ? 1 : m)) + 256;
+    MrPlan p;
+    if (m < 1) m = 1;
+    if (ncls < 1) ncls = 1;
+    p.WW = (W + 63) / 64;
+    size_t o = 0;
+    p.occ = o; o += al256((size_t)ncls * H * p.WW * 8);
+    p.bits = o; o += al256((size_t)m * H * p.WW * 8);
+    p.sums = o; o += al256((size_t)m * 4);
+    p.sorted = o; o += al256((size_t)m * 4);
+    p.kept = o; o += al256((size_t)m);
+    p.total = o + 256;
+    return p;
 }
+
+extern "C" size_t upsnet_mask_removal_workspace_bytes(int m, int ncls, int H, int W) { return mr_plan(m, ncls, H, W).total; }
 
 extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_prob, const float *mask_logit,
                                    const int64_t *cls_idx, int m, int mask_size, int ncls, int H, int W,
@@ -173,16 +232,20 @@ extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const f
                 "mask_removal: null pointer");
     UPS_REQUIRE(m >= 1 && m <= PAN_MAXINST, "mask_removal: m must be 1..%d (got %d)", PAN_MAXINST, m);
     UPS_REQUIRE(mask_size >= 2 && mask_size <= PAN_MAXMS, "mask_removal: mask_size must be 2..%d", PAN_MAXMS);
-    UPS_REQUIRE(ncls >= 1 && H >= 1 && W >= 1 && H <= PAN_MAXDIM && W <= PAN_MAXDIM, "mask_removal: bad class count / image size (max side %d)", PAN_MAXDIM);
+    UPS_REQUIRE(ncls >= 1 && H >= 1 && W >= 1, "mask_removal: bad class count / image size");
+    const MrPlan pl = mr_plan(m, ncls, H, W);
     unsigned char *ws = (unsigned char *)workspace;
-    uint8_t *occ = ws; ws += al256((size_t)ncls * H * W);
-    int *sorted_idx = (int *)ws; ws += al256((size_t)m * 4);
-    uint8_t *kept = ws;
+    unsigned long long *occ = (unsigned long long *)(ws + pl.occ), *bits = (unsigned long long *)(ws + pl.bits);
+    int *sums = (int *)(ws + pl.sums), *sorted_idx = (int *)(ws + pl.sorted);
+    uint8_t *kept = ws + pl.kept;
     hipStream_t st = (hipStream_t)stream;
-    UPS_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)ncls * H * W, st));
+    UPS_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)ncls * H * pl.WW * 8, st));
+    UPS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)m * 4, st));
     UPS_CHECK_HIP(hipMemsetAsync(kept, 0, (size_t)m, st));
-    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, mask_logit, cls_idx, m,
-                       mask_size, H, W, fraction_threshold, occ, sorted_idx, kept);
+    hipLaunchKernelGGL(mask_bits_kernel, dim3(m, 32), dim3(256), 0, st, mask_rois, mask_logit, m, mask_size, H, W, pl.WW, bits, sums);
+    UPS_CHECK_LAUNCH("mask_bits_kernel");
+    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, cls_idx, m, H, W, pl.WW,
+                       fraction_threshold, bits, sums, occ, sorted_idx, kept);
     UPS_CHECK_LAUNCH("mask_removal_kernel");
     hipLaunchKernelGGL(mask_removal_finalize_kernel, dim3(1), dim3(64), 0, st, cls_idx, m, sorted_idx, kept, keep_inds, num_keep,
                        real_keep);

@@ -56,23 +56,72 @@ struct PropStage {
     int nlev, k;
 };
 
-// one workgroup per chunk: sort <= PROP_CH keys, write the top k (zero-padded)
+// one workgroup per chunk: top k of <= PROP_CH unique keys, sorted descending, zero-padded.
+// k <= PROP_SELK: exact radix select of the k-th largest key (8 passes of 8 bits over the keys in LDS, per-wave
+// private histograms), compaction of the k survivors, bitonic sort of just those; otherwise a full bitonic sort.
+#define PROP_SELK 2048
 __global__ void __launch_bounds__(1024)
 prop_topk_stage_kernel(const PropStage st, const ups_u64 *__restrict__ in, ups_u64 *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);
+    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);            // [PROP_CH]
+    ups_u64 *sel = keys + PROP_CH;                                     // [PROP_SELK]
+    unsigned *whist = reinterpret_cast<unsigned *>(sel + PROP_SELK);   // [16 waves][256]
+    __shared__ unsigned hist[256];
+    __shared__ ups_u64 s_prefix;
+    __shared__ unsigned s_need, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     int l = 0;
     for (int q = 1; q < st.nlev; ++q) if ((int)blockIdx.x >= st.chunk_start[q]) l = q;
     const int chunk = blockIdx.x - st.chunk_start[l];
     const long base = (long)chunk * PROP_CH;
     const int cn = (int)min((long)PROP_CH, (long)st.n_in[l] - base);
-    const int M = ups_next_pow2(cn < 64 ? 64 : cn);
+    const int k = st.k;
     const ups_u64 *__restrict__ src = in + st.in_off[l] + base;
-    for (int i = threadIdx.x; i < M; i += blockDim.x) keys[i] = i < cn ? src[i] : 0ULL;
-    ups_block_sort_desc(keys, M);
-    ups_u64 *__restrict__ dst = out + st.out_off[l] + (long)chunk * st.k;
-    for (int i = threadIdx.x; i < st.k; i += blockDim.x) dst[i] = i < cn ? keys[i] : 0ULL;
+    ups_u64 *__restrict__ dst = out + st.out_off[l] + (long)chunk * k;
+    if (cn <= k || k > PROP_SELK) {
+        const int M = ups_next_pow2(cn < 64 ? 64 : cn);
+        for (int i = tid; i < M; i += blockDim.x) keys[i] = i < cn ? src[i] : 0ULL;
+        ups_block_sort_desc(keys, M);
+        for (int i = tid; i < k; i += blockDim.x) dst[i] = i < cn ? keys[i] : 0ULL;
+        return;
+    }
+    for (int i = tid; i < cn; i += blockDim.x) keys[i] = src[i];
+    if (tid == 0) { s_prefix = 0; s_need = (unsigned)k; s_cnt = 0; }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        for (int i = lane; i < 256; i += 64) whist[wave * 256 + i] = 0;
+        __syncthreads();
+        const ups_u64 prefix = s_prefix;
+        for (int i = tid; i < cn; i += blockDim.x) {
+            const ups_u64 key = keys[i];
+            if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&whist[wave * 256 + (unsigned)((key >> shift) & 255ULL)], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) { unsigned t = 0; for (int w = 0; w < nwave; ++w) t += whist[w * 256 + tid]; hist[tid] = t; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = s_need;
+            int b = 255;
+            for (; b > 0; --b) { if (hist[b] >= need) break; need -= hist[b]; }
+            s_prefix = prefix | ((ups_u64)b << shift);
+            s_need = need;
+        }
+        __syncthreads();
+    }
+    const ups_u64 thr = s_prefix;   // the k-th largest key (keys are unique)
+    for (int i = tid; i < cn; i += blockDim.x) {
+        const ups_u64 key = keys[i];
+        // zero keys are padding from the previous stage (never selected; real keys are unique and non-zero)
+        if (key >= thr && key != 0ULL) { const unsigned pos = atomicAdd(&s_cnt, 1u); if (pos < (unsigned)PROP_SELK) sel[pos] = key; }
+    }
+    __syncthreads();
+    const int M2 = ups_next_pow2(k < 64 ? 64 : k);
+    const int got = (int)min(s_cnt, (unsigned)k);   // == k unless fewer than k real keys exist
+    for (int i = got + tid; i < M2; i += blockDim.x) sel[i] = 0ULL;
+    ups_block_sort_desc(sel, M2);
+    for (int i = tid; i < k; i += blockDim.x) dst[i] = sel[i];
 }
 
 // bbox_transform + clip_boxes + _filter_boxes on each level's sorted top-k keys (found via lv.key_off)
@@ -250,6 +299,15 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     UPS_CHECK_LAUNCH("prop_key_kernel");
 
     // tournament: repeat until every level is a single sorted chunk of k = pre_n keys
+    const size_t stage_smem = (size_t)PROP_CH * 8 + (size_t)PROP_SELK * 8 + 16 * 256 * 4;
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_topk_stage_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_smem));
+            attr_set = true;
+        }
+    }
     int cur = 0;
     int n_in[PROP_MAXLEV];
     for (int l = 0; l < nlev; ++l) n_in[l] = lv.n[l];
@@ -268,7 +326,7 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
             if (c > 1) more = true;
         }
         sg.chunk_start[nlev] = chunks_total;
-        hipLaunchKernelGGL(prop_topk_stage_kernel, dim3(chunks_total), dim3(1024), (size_t)PROP_CH * 8, st, sg, kbuf[cur],
+        hipLaunchKernelGGL(prop_topk_stage_kernel, dim3(chunks_total), dim3(1024), stage_smem, st, sg, kbuf[cur],
                            kbuf[cur ^ 1]);
         UPS_CHECK_LAUNCH("prop_topk_stage_kernel");
         cur ^= 1;
