@@ -10,8 +10,8 @@ rank, inputs resident in HBM, followed by a device sync (the reference's net_tim
 upsnet_end2end_test.py:244-252). Rank 0 prints ONE JSON line. `value` = images of all ranks / wall time
 (max over ranks, barrier + synchronize bracketed, includes the final RCCL gather of the label maps).
 
-Extra objects: "roofline" for the dominant hand-written kernel (the fused deformable convolution,
-timed live with events on the launch stream inside the timed region) and "cpu_baseline" (the CPU oracle's
+Extra objects: "roofline" for the dominant hand-written kernel family (the fp32 MFMA implicit-GEMM convolution,
+dense and deformable instances, timed live with events on the launch stream inside the timed region) and "cpu_baseline" (the CPU oracle's
 composite forward timed on the host cores of the same box, rank 0 / N=1 only).
 """
 import argparse
@@ -30,16 +30,6 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the same guide)
 
 
-def dcn_algorithmic(levels_hw, layers):
-    """fused DCN bytes = 4*HW*(Cin + 2*kh*kw*dg + Cout) + 4*Cout*Cin*kh*kw,
-    flops = 2*Cout*Cin*kh*kw*HW, per launch (= one layer over all FPN levels)."""
-    hw = sum(h * w for h, w in levels_hw)
-    out = []
-    for cin, cout in layers:
-        out.append((4.0 * hw * (cin + 18 + cout) + 4.0 * cout * cin * 9, 2.0 * cout * cin * 9 * hw))
-    return out
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -47,19 +37,34 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='upsnet50_cityscapes_1024x2048')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-scale', type=float, default=0.5,
+    ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
     args = ap.parse_args()
 
     from upsnet_amd import ops
     from upsnet_amd.upsnet_end2end_test import upsnet_test
 
-    ops.PROFILE['enabled'] = True
+    # kernel events are recorded on every PROFILE_EVERY-th timed image only (two events per launch are not free:
+    # recording all ~75 conv launches of every image costs ~3 % of the step time)
+    PROFILE_EVERY = 5
     ops.PROFILE['events'] = []
-    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup)
+    sampled = [0]
+
+    def on_step(s, out):
+        ops.PROFILE['enabled'] = ((s + 1) % PROFILE_EVERY == 0)
+        sampled[0] += int(ops.PROFILE['enabled'])
+
+    ops.PROFILE['enabled'] = True   # image 0 of the timed region (warm-up images are recorded too and dropped below)
+    sampled[0] = 1
+    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, on_step=on_step, on_warmup_done=lambda: ops.PROFILE['events'].clear())
     ops.PROFILE['enabled'] = False
+    if (args.steps) % PROFILE_EVERY == 0:
+        sampled[0] -= 1   # the toggle after the last step enabled recording for an image that never ran
     rank, world = res['rank'], res['world']
     if rank != 0:
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
     torch.cuda.synchronize()
     n_images = args.steps * world
@@ -67,35 +72,44 @@ def main():
     net = sorted(res['net_times'])
     p50_ms = 1000.0 * net[len(net) // 2]
 
-    # ---- roofline of the dominant hand-written kernel (fused DCN), from events inside the timed region
-    ev = ops.PROFILE['events'][-2 * args.steps:] if args.steps else []
-    dcn_ms = [s.elapsed_time(e) for (name, s, e) in ev if name == 'dcn_fused']
+    # ---- roofline of the dominant hand-written kernel family, from events recorded on the launch stream INSIDE the
+    # timed region: conv_igemm_f32_kernel (csrc/conv.hip) -- dense instances (backbone/FPN/RPN/heads) and the
+    # deformable instances (FCN head). Algorithmic work per launch: flops = 2*Cout*Cin*kh*kw*pixels,
+    # bytes = 4*(input + output (+ residual) + weights) (+ offsets for the deformable form), SURVEY.md section 8d.
     H, W = res['H'], res['W']
-    ph, pw = (H + 31) // 32 * 32, (W + 31) // 32 * 32
-    levels = [(ph // s, pw // s) for s in (4, 8, 16, 32)]
-    from upsnet_amd.config.config import config
-    layers = [(256, 128), (128, 128)] if config.network.fcn_num_layers == 2 else [(256, 256), (256, 128), (128, 128)]
-    alg = dcn_algorithmic(levels, layers)
+
+    n_sampled = max(sampled[0], 1)
+
+    def agg(kind):
+        ev = [e for e in ops.PROFILE['events'] if e[0] == kind]
+        ms = sum(e[1].elapsed_time(e[2]) for e in ev)
+        return len(ev), ms / 1000.0, sum(e[3] for e in ev), sum(e[4] for e in ev)
     roofline = None
-    if dcn_ms:
-        launches = len(dcn_ms)
-        avg_s = sum(dcn_ms) / launches / 1000.0
-        flops_per_launch = sum(a[1] for a in alg) / len(alg)
-        bytes_per_launch = sum(a[0] for a in alg) / len(alg)
-        achieved = flops_per_launch / avg_s / 1e12
+    n_c, t_c, f_c, b_c = agg('conv')
+    n_d, t_d, f_d, b_d = agg('dcn_fused')
+    if n_c and t_c > 0:
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_dcn_pmc.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_conv_pmc.json')  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        roofline = {'kernel': 'dcn_fused_nhwc_kernel', 'bound': 'mfma', 'achieved': round(achieved, 3),
-                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'traffic': traffic, 'avg_launch_ms': round(avg_s * 1000, 4), 'launches_timed': launches,
-                    'algorithmic_flops_per_launch': flops_per_launch, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                    'hbm_equiv_GBs': round(bytes_per_launch / avg_s / 1e9, 1),
-                    'hbm_equiv_frac': round(bytes_per_launch / avg_s / 1e9 / PEAK_HBM_GBS, 4)}
+        achieved = f_c / t_c / 1e12
+        roofline = {'kernel': 'conv_igemm_f32_kernel (dense instances, all tile variants)', 'bound': 'mfma',
+                    'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'launches_timed': n_c, 'images_sampled': n_sampled, 'launches_per_image': n_c // n_sampled,
+                    'avg_launch_ms': round(1000.0 * t_c / n_c, 4), 'ms_per_image': round(1000.0 * t_c / n_sampled, 3),
+                    'algorithmic_flops_per_launch': f_c / n_c, 'algorithmic_bytes_per_launch': b_c / n_c,
+                    'hbm_equiv_GBs': round(b_c / t_c / 1e9, 1)}
+        if n_d and t_d > 0:
+            roofline['deformable'] = {'kernel': 'conv_igemm_f32_kernel (deformable instances = fused DCN v1)', 'bound': 'mfma',
+                                      'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      'launches_timed': n_d, 'avg_launch_ms': round(1000.0 * t_d / n_d, 4),
+                                      'algorithmic_flops_per_launch': f_d / n_d, 'algorithmic_bytes_per_launch': b_d / n_d,
+                                      'hbm_equiv_GBs': round(b_d / t_d / 1e9, 1),
+                                      'hbm_equiv_frac': round(b_d / t_d / 1e9 / PEAK_HBM_GBS, 4)}
 
     # ---- CPU baseline: the oracle's composite forward on the host cores (bounded sample)
     cpu_baseline = None
@@ -117,7 +131,7 @@ def main():
         # scale the sample's time to a full-size image by pixel count (all heavy stages are O(pixels))
         full = dt * (H * W) / float(h * w)
         cpu_baseline = {'value': round(1.0 / full, 5), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-                        'sample': '1 image %dx%d (%.2fx linear scale of the workload) in %.1f s, extrapolated by pixel count; '
+                        'sample': '1 image %dx%d (%.2fx linear scale of the workload; scaled by pixel count if < 1) in %.1f s; '
                                   'torch-CPU convs on %d threads (host has %d) + single-thread C oracle ops' % (h, w, sc, dt, cores, os.cpu_count()),
                         'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
                         'n_inst': out_cpu['n_inst']}
@@ -140,6 +154,9 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu_baseline,
     }
     print(json.dumps(line), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -40,6 +40,7 @@ struct ConvParams {
     const float *w, *bias;
     int nseg, Cin, Cout, ldw, KH, KW, stride, pad, dil, relu;
     int m_tiles, n_tiles;
+    int kord;  // K walk: 1 = channel-slab outer / tap inner (default), 0 = tap outer / channel-slab inner
 };
 
 // corner descriptor of one (pixel, tap): element offsets of the 4 corners (clamped, always loadable),
@@ -115,15 +116,18 @@ conv_igemm_f32_kernel(const ConvParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int akr = lane >> 5, aij = lane & 31;
-    // XCD-aware tile order: the n-tiles that share one A panel run on the same XCD (same L2)
+    // XCD-aware tile order. Workgroup b is observed to run on XCD b % 8 (speed only, never correctness). Each XCD gets
+    // a CONTIGUOUS range of m-tiles (so the 3x3 / bilinear halos of vertically adjacent tiles hit the same 4 MiB L2)
+    // and all n-tiles of an m-tile (they share the A panel) stay on that XCD.
     int m_t, n_t;
     {
         const int bid = blockIdx.x, nt = p.n_tiles;
-        const int group = 8 * nt;
-        const int g = bid / group, r = bid % group;
-        const int full = (p.m_tiles / 8) * 8;
-        if (g * 8 < full) { m_t = g * 8 + (r & 7); n_t = r >> 3; }
-        else { const int rem = bid - full * nt; m_t = full + rem / nt; n_t = rem % nt; }
+        const int per = (p.m_tiles + 7) >> 3;
+        const int q = bid >> 3;
+        n_t = q % nt;
+        const int local = q / nt;
+        m_t = (bid & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
     }
     int si = 0;
 #pragma unroll
@@ -167,6 +171,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     bool rv0 = false, rv1 = false, rv2 = false, rv3 = false;
     DcnDesc d0, d1, d2, d3;
     int desc_tap = -1;
+    int f_tap = 0, f_cs = 0, f_ki = 0, f_kj = 0;  // (tap, channel slab) of the NEXT slab to fetch
 
 #define CV_LOAD_B(Q) \
     (*reinterpret_cast<const float4 *>(wrow + (long)((tid + 256 * (Q)) / (BN / 4)) * p.ldw + 4 * ((tid + 256 * (Q)) % (BN / 4))))
@@ -187,8 +192,14 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 #define CV_FETCH(S)                                                                                                   \
     {                                                                                                                 \
-        const int tap = (S) / cin_slabs, cs = ((S) - tap * cin_slabs) * CV_BK;                                        \
-        const int ki = tap / p.KW, kj = tap - ki * p.KW;                                                              \
+        const int tap = f_tap, cs = f_cs, ki = f_ki, kj = f_kj;                                                       \
+        if (p.kord) {                                                                                                 \
+            if (++f_tap == ntap) { f_tap = 0; f_ki = 0; f_kj = 0; f_cs += CV_BK; }                                    \
+            else if (++f_kj == p.KW) { f_kj = 0; ++f_ki; }                                                            \
+        } else {                                                                                                      \
+            f_cs += CV_BK;                                                                                            \
+            if (f_cs == p.Cin) { f_cs = 0; ++f_tap; if (++f_kj == p.KW) { f_kj = 0; ++f_ki; } }                       \
+        }                                                                                                             \
         if (DEFORM) {                                                                                                 \
             if (tap != desc_tap) {                                                                                    \
                 desc_tap = tap;                                                                                       \
@@ -336,7 +347,8 @@ static int conv_launch(hipStream_t st, ConvParams &p)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE>), dim3(p.m_tiles * p.n_tiles), dim3(256), smem, st, p);
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;  // see the XCD-aware tile order in the kernel
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE>), dim3(grid), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("conv_igemm_f32_kernel");
     return 0;
 }
@@ -346,8 +358,13 @@ static int conv_launch(hipStream_t st, ConvParams &p)
 // beat the 128x128 tile (208 registers, 66 KiB -> 2 waves) on almost every layer. 64x128 wins for the large 3x3 layers
 // and for the deformable variant (A operand = expensive gather, computed once per 128 output channels); 64x64 elsewhere.
 // upsnet_conv_tuning(pipe, force_tile) overrides for A/B runs.
-static int g_pipe = -1, g_force_tile = 0;
-extern "C" void upsnet_conv_tuning(int pipe, int force_tile) { g_pipe = pipe; g_force_tile = force_tile; }
+static int g_pipe = -1, g_force_tile = 0, g_kord = 1;
+extern "C" void upsnet_conv_tuning(int pipe, int force_tile)
+{
+    g_pipe = pipe < 0 ? -1 : (pipe & 1);
+    g_kord = pipe < 0 ? 1 : ((pipe & 2) ? 0 : 1);  // bit 1 of `pipe` selects the tap-outer K walk (A/B runs only)
+    g_force_tile = force_tile;
+}
 
 template <int DEFORM, int PIPE>
 static int conv_dispatch2(hipStream_t st, ConvParams &p)
@@ -377,6 +394,7 @@ template <int DEFORM>
 static int conv_dispatch(hipStream_t st, ConvParams &p)
 {
     const int pipe = g_pipe >= 0 ? g_pipe : 1;
+    p.kord = g_kord;
     return pipe ? conv_dispatch2<DEFORM, 1>(st, p) : conv_dispatch2<DEFORM, 0>(st, p);
 }
 

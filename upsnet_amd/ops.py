@@ -148,7 +148,10 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
           "deform_conv_forward_nhwc")
     if PROFILE['enabled']:
         ev1.record()
-        PROFILE['events'].append(('dcn_fused', ev0, ev1))
+        npix = sum(o.shape[2] * o.shape[3] for o in outs)
+        taps = ksize[0] * ksize[1]
+        PROFILE['events'].append(('dcn_fused', ev0, ev1, 2.0 * cout * cin * taps * npix,
+                                  4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps)))
     return outs
 
 
@@ -372,11 +375,20 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
         for r, o in zip(ress, outs):
             if tuple(r.shape) != tuple(o.shape):
                 raise RuntimeError("conv2d_nhwc: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().upsnet_conv2d_nhwc_f32(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None,
                                        ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
                                        int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
                                        ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride),
                                        int(pad), int(bool(relu))), "conv2d_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
+        nin = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
+                                  4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1) + cout * cin * ksize * ksize)))
     return outs
 
 

@@ -36,11 +36,13 @@ def init_distributed():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        local = local % torch.cuda.device_count()  # (several ranks may share a GPU in single-GPU smoke runs)
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl' if use_cuda else 'gloo', rank=rank, world_size=world)
+        backend = os.environ.get('UPSNET_DIST_BACKEND', 'nccl' if use_cuda else 'gloo')
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, (torch.device('cuda', local) if use_cuda else torch.device('cpu'))
 
 
@@ -54,6 +56,8 @@ def gather_results(local, world, device):
     Returns on every rank a dict image_id -> (label_map, n_inst). Ranks may hold different counts: pad."""
     if world == 1:
         return {i: (lab, n) for i, lab, n in local}
+    if dist.get_backend() == 'gloo':
+        device = torch.device('cpu')
     counts = torch.tensor([len(local)], dtype=torch.int64, device=device)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)
@@ -78,7 +82,7 @@ def gather_results(local, world, device):
 
 
 def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, seed=0, pipeline='fused', gather=True,
-                on_step=None):
+                on_step=None, on_warmup_done=None):
     """Run `steps` timed images per rank (after `warmup` untimed ones). Returns a dict with the whole-job
     wall time (max over ranks, barrier + sync bracketed), per-image net_time samples and the gathered results."""
     rank, world, device = init_distributed()
@@ -98,6 +102,8 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         for w in range(warmup):
             model(get(w))
         torch.cuda.synchronize(device)
+        if on_warmup_done is not None:
+            on_warmup_done()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
