@@ -33,10 +33,11 @@ for key, cnt in sorted(shapes.items(), key=lambda kv: -kv[1]):
         res = [torch.randn_like(o) for o in ops.conv2d_nhwc_multi(xs, wp, ldw, b, cout, k, st, k // 2)]
     line = []
     best = None
-    for tile in (0, 1, 2, 4, 5, 3):
+    for tile in (0, 1, 2, 4, 5, 6, 3):
         if tile == 1 and ldw % 128: continue
         if tile == 4 and ldw % 128: continue
-        if tile in (2, 5) and ldw % 64: continue
+        if tile in (2, 5, 6) and ldw % 64: continue
+        if tile == 6 and cin % 64: continue
         lib().upsnet_conv_tuning(-1, tile)
         for _ in range(2): ops.conv2d_nhwc_multi(xs, wp, ldw, b, cout, k, st, k // 2, True, res)
         torch.cuda.synchronize()

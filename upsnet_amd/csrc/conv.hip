@@ -40,7 +40,7 @@ struct ConvParams {
     const float *w, *bias;
     int nseg, Cin, Cout, ldw, KH, KW, stride, pad, dil, relu;
     int m_tiles, n_tiles;
-    int kord;  // K walk: 1 = channel-slab outer / tap inner (default), 0 = tap outer / channel-slab inner
+    int kord;  // K walk: 0 = tap outer / channel-slab inner (default), 1 = channel-slab outer / tap inner
 };
 
 // corner descriptor of one (pixel, tap): element offsets of the 4 corners (clamped, always loadable),
@@ -97,21 +97,25 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
 // WM x WN = 32x32 tiles per wave, waves arranged WAVES_M x WAVES_N (4 waves): BM = 32*WM*WAVES_M (128 or 64) output
 // pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup.
 // DEFORM: 0 dense, 1 deformable v1, 2 deformable v2 (modulated). PIPE: pin the k-loop software pipeline.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE, int BK>
 __global__ void __launch_bounds__(256)
 conv_igemm_f32_kernel(const ConvParams p)
 {
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int LDA = BM + 1;
-    constexpr int PXT = BM / 32;  // pixels staged per thread per slab
+    constexpr int CH4 = BK / 4;        // float4 channel groups per slab row (8 or 16)
+    constexpr int RP = 256 / CH4;      // pixels staged per pass of the 256 threads (32 or 16)
+    constexpr int PXT = BM / RP;       // pixels staged per thread per slab (2 or 4)
     static_assert((BM == 128 || BM == 64) && WAVES_M * WAVES_N == 4, "tile");
     static_assert(BN == 32 || BN == 64 || BN == 128, "BN");
-    constexpr int B_F4 = (CV_BK * BN / 4) / 256;  // float4 per thread for the B slab (1, 2 or 4)
+    static_assert((BK == 32 || BK == 64) && PXT <= 4, "BK");
+    constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread for the B slab (1, 2 or 4)
+    static_assert(B_F4 >= 1 && B_F4 <= 4, "B staging");
     constexpr bool MOD = DEFORM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *As = reinterpret_cast<float *>(smem_raw);     // [2][CV_BK][LDA]
-    float *Bs = As + 2 * CV_BK * LDA;                    // [2][CV_BK][BN]
+    float *As = reinterpret_cast<float *>(smem_raw);     // [2][BK][LDA]
+    float *Bs = As + 2 * BK * LDA;                       // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
@@ -137,14 +141,14 @@ conv_igemm_f32_kernel(const ConvParams p)
     const int n0 = n_t * BN;
     const int ntap = p.KH * p.KW;
 
-    // ---- per-thread A staging geometry: 4 pixels (prow + 32 r), channels 4*ch4..+3 of the slab
-    const int ch4 = tid & 7, prow = tid >> 3;
+    // ---- per-thread A staging geometry: PXT pixels (prow + RP r), channels 4*ch4..+3 of the slab
+    const int ch4 = tid % CH4, prow = tid / CH4;
     int pix_n[4], pix_h[4], pix_w[4];
     long pix_p[4];
     const long HoWo = (long)sg.Ho * sg.Wo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const long pp = p0 + prow + 32 * r;
+        const long pp = p0 + prow + RP * r;
         if (r < PXT && pp < sg.M) {
             const int n = (int)(pp / HoWo);
             const int rem = (int)(pp - (long)n * HoWo);
@@ -152,7 +156,7 @@ conv_igemm_f32_kernel(const ConvParams p)
             pix_p[r] = pp;
         } else { pix_n[r] = -1; pix_h[r] = 0; pix_w[r] = 0; pix_p[r] = -1; }
     }
-    const int cin_slabs = p.Cin / CV_BK;
+    const int cin_slabs = p.Cin / BK;
     const int nslabs = ntap * cin_slabs;
 
     floatx16 acc[WM][WN];
@@ -194,10 +198,10 @@ conv_igemm_f32_kernel(const ConvParams p)
     {                                                                                                                 \
         const int tap = f_tap, cs = f_cs, ki = f_ki, kj = f_kj;                                                       \
         if (p.kord) {                                                                                                 \
-            if (++f_tap == ntap) { f_tap = 0; f_ki = 0; f_kj = 0; f_cs += CV_BK; }                                    \
+            if (++f_tap == ntap) { f_tap = 0; f_ki = 0; f_kj = 0; f_cs += BK; }                                       \
             else if (++f_kj == p.KW) { f_kj = 0; ++f_ki; }                                                            \
         } else {                                                                                                      \
-            f_cs += CV_BK;                                                                                            \
+            f_cs += BK;                                                                                               \
             if (f_cs == p.Cin) { f_cs = 0; ++f_tap; if (++f_kj == p.KW) { f_kj = 0; ++f_ki; } }                       \
         }                                                                                                             \
         if (DEFORM) {                                                                                                 \
@@ -223,7 +227,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 #define CV_STASH_PX(R, VX, VY, VZ, VW)                                                                                \
     {                                                                                                                 \
-        const int px = prow + 32 * R;                                                                                 \
+        const int px = prow + RP * R;                                                                                 \
         sa[(4 * ch4 + 0) * LDA + px] = VX;                                                                         \
         sa[(4 * ch4 + 1) * LDA + px] = VY;                                                                         \
         sa[(4 * ch4 + 2) * LDA + px] = VZ;                                                                         \
@@ -235,7 +239,7 @@ conv_igemm_f32_kernel(const ConvParams p)
                 dcn_blend1(D, A0.z, A1.z, A2.z, A3.z, MOD), dcn_blend1(D, A0.w, A1.w, A2.w, A3.w, MOD))
 #define CV_STASH(BUF)                                                                                                 \
     {                                                                                                                 \
-        float *sa = As + (BUF) * CV_BK * LDA;                                                                         \
+        float *sa = As + (BUF) * BK * LDA;                                                                            \
         if (DEFORM) {                                                                                                 \
             CV_STASH_DEFORM(0, d0, a00, a01, a02, a03) CV_STASH_DEFORM(1, d1, a10, a11, a12, a13)                     \
             if (PXT > 2) { CV_STASH_DEFORM(2, d2, a20, a21, a22, a23) CV_STASH_DEFORM(3, d3, a30, a31, a32, a33) }    \
@@ -243,7 +247,7 @@ conv_igemm_f32_kernel(const ConvParams p)
             CV_STASH_DENSE(0, a00, rv0) CV_STASH_DENSE(1, a10, rv1)                                                   \
             if (PXT > 2) { CV_STASH_DENSE(2, a20, rv2) CV_STASH_DENSE(3, a30, rv3) }                                  \
         }                                                                                                             \
-        float4 *sb = reinterpret_cast<float4 *>(Bs + (BUF) * CV_BK * BN);                                             \
+        float4 *sb = reinterpret_cast<float4 *>(Bs + (BUF) * BK * BN);                                                \
         sb[tid] = rb0;                                                                                                \
         if (B_F4 > 1) sb[tid + 256] = rb1;                                                                            \
         if (B_F4 > 2) { sb[tid + 512] = rb2; sb[tid + 768] = rb3; }                                                   \
@@ -258,8 +262,8 @@ conv_igemm_f32_kernel(const ConvParams p)
         // Deformable: CV_STASH blends with d0..d3, which CV_FETCH refreshes at tap boundaries BEFORE issuing that
         // slab's loads; fetch(s+1) and stash(s+1) always see the same descriptors, slab s was stashed earlier.
         if (more) CV_FETCH(s + 1)
-        const float *a = As + buf * CV_BK * LDA + wm * (WM * 32) + aij;
-        const float *b = Bs + buf * CV_BK * BN + wn * (WN * 32) + aij;
+        const float *a = As + buf * BK * LDA + wm * (WM * 32) + aij;
+        const float *b = Bs + buf * BK * BN + wn * (WN * 32) + aij;
         // software-pipelined k loop: the LDS fragment reads of step k+1 are issued before the MFMAs of step k, and
         // the next slab's registers are written to the other LDS buffer under the last quarter of the MFMAs
         float av[2][WM], bv[2][WN];
@@ -268,15 +272,15 @@ conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < WN; ++j) bv[0][j] = b[akr * BN + 32 * j];
 #pragma unroll
-        for (int k = 0; k < CV_BK / 2; ++k) {
+        for (int k = 0; k < BK / 2; ++k) {
             const int cur = k & 1, nxt = cur ^ 1;
-            if (k + 1 < CV_BK / 2) {
+            if (k + 1 < BK / 2) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) av[nxt][i] = a[(2 * (k + 1) + akr) * LDA + 32 * i];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bv[nxt][j] = b[(2 * (k + 1) + akr) * BN + 32 * j];
             }
-            if (PIPE && k == 3 * (CV_BK / 2) / 4 && more) CV_STASH(buf ^ 1)
+            if (PIPE && k == 3 * (BK / 2) / 4 && more) CV_STASH(buf ^ 1)
             if (PIPE) __builtin_amdgcn_sched_barrier(0);  // keep the k+1 fragment reads (and the stash) ahead of step k's MFMAs
 #pragma unroll
             for (int i = 0; i < WM; ++i)
@@ -331,7 +335,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE, int BK = CV_BK>
 static int conv_launch(hipStream_t st, ConvParams &p)
 {
     constexpr int BN = WAVES_N * WN * 32, BM = WAVES_M * WM * 32;
@@ -340,15 +344,15 @@ static int conv_launch(hipStream_t st, ConvParams &p)
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + BM - 1) / BM); }
     p.m_tiles = tiles;
     p.n_tiles = (p.Cout + BN - 1) / BN;
-    const size_t smem = (size_t)(2 * CV_BK * (BM + 1) + 2 * CV_BK * BN) * sizeof(float);
+    const size_t smem = (size_t)(2 * BK * (BM + 1) + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_set && smem > 64 * 1024) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE>),
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE, BK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;  // see the XCD-aware tile order in the kernel
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE, BK>), dim3(grid), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("conv_igemm_f32_kernel");
     return 0;
 }
@@ -358,11 +362,11 @@ static int conv_launch(hipStream_t st, ConvParams &p)
 // beat the 128x128 tile (208 registers, 66 KiB -> 2 waves) on almost every layer. 64x128 wins for the large 3x3 layers
 // and for the deformable variant (A operand = expensive gather, computed once per 128 output channels); 64x64 elsewhere.
 // upsnet_conv_tuning(pipe, force_tile) overrides for A/B runs.
-static int g_pipe = -1, g_force_tile = 0, g_kord = 1;
+static int g_pipe = -1, g_force_tile = 0, g_kord = 0;
 extern "C" void upsnet_conv_tuning(int pipe, int force_tile)
 {
     g_pipe = pipe < 0 ? -1 : (pipe & 1);
-    g_kord = pipe < 0 ? 1 : ((pipe & 2) ? 0 : 1);  // bit 1 of `pipe` selects the tap-outer K walk (A/B runs only)
+    g_kord = pipe < 0 ? 0 : ((pipe & 2) ? 1 : 0);  // bit 1 of `pipe` selects the slab-outer K walk (A/B runs only)
     g_force_tile = force_tile;
 }
 
@@ -381,11 +385,13 @@ static int conv_dispatch2(hipStream_t st, ConvParams &p)
     if (tile == 1 && !n128) tile = n64 ? 2 : 3;
     if ((tile == 2 || tile == 5) && !n64) tile = 3;
     if (tile == 4 && !n128) tile = n64 ? 5 : 3;
+    if (tile == 6 && (!n64 || p.Cin % 64 != 0)) tile = n64 ? 5 : 3;
     switch (tile) {
     case 1: return conv_launch<2, 2, 2, 2, DEFORM, PIPE>(st, p);   // 128 x 128
     case 2: return conv_launch<1, 2, 4, 1, DEFORM, PIPE>(st, p);   // 128 x 64
     case 4: return conv_launch<1, 2, 2, 2, DEFORM, PIPE>(st, p);   // 64 x 128
     case 5: return conv_launch<1, 1, 2, 2, DEFORM, PIPE>(st, p);   // 64 x 64
+    case 6: return conv_launch<1, 1, 2, 2, DEFORM, PIPE, 64>(st, p);  // 64 x 64, 64-channel K slabs
     default: return conv_launch<1, 1, 4, 1, DEFORM, PIPE>(st, p);  // 128 x 32
     }
 }
