@@ -104,9 +104,9 @@ int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const
                            const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
                            int relu);
 
-/* Development knob for A/B measurements: pipe = -1 default / 0 / 1 (pinned k-loop pipeline), force_tile = 0 auto,
- * 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64. Not needed in production. */
-void upsnet_conv_tuning(int pipe, int force_tile);
+/* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
+ * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). `reserved` is ignored. Not needed in production. */
+void upsnet_conv_tuning(int reserved, int force_tile);
 
 /* weight [Cout, Cin, kh, kw] (nn.Conv2d layout) -> wpack [kh*kw*Cin, ldw] (tap-major rows, zero-padded columns). */
 int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);

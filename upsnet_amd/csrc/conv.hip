@@ -7,10 +7,10 @@
 // v2: mod_deform_conv_kernel.cu:187-249).
 //
 // Here: NHWC activations, weights pre-packed once to [kh*kw*Cin, ldw] (tap-major rows, ldw = Cout rounded up to 32,
-// zero padded). A workgroup owns 128 output pixels x BN output channels. K is walked in slabs of one tap x 32 input
+// zero padded). A workgroup owns BM (64/128) output pixels x BN output channels. K is walked in slabs of one tap x 32 input
 // channels. While slab s is contracted from LDS with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
-// accumulation in a fixed k order), the global loads of slab s+1 are already in flight into registers
-// (double-buffered LDS, one barrier per slab):
+// accumulation in a fixed k order), the global loads of slab s+2 (dense) / s+1 (deformable) are already in flight
+// into registers (double-buffered LDS, one barrier per slab):
 //   dense      : one float4 per (pixel, 4 channels), zero-filled outside the image;
 //   deformable : the four bilinear corners as float4 channel runs; offsets -> corner addresses + weights are
 //                computed once per tap in registers with the reference's exact fp32 arithmetic; the blend (and the
@@ -40,23 +40,26 @@ struct ConvParams {
     const float *w, *bias;
     int nseg, Cin, Cout, ldw, KH, KW, stride, pad, dil, relu;
     int m_tiles, n_tiles;
-    int kord;  // K walk: 0 = tap outer / channel-slab inner (default), 1 = channel-slab outer / tap inner
 };
 
-// corner descriptor of one (pixel, tap): element offsets of the 4 corners (clamped, always loadable),
-// validity bits, blend weights (deform_conv_kernel.cu:88-118 arithmetic), v2 modulation
+// corner descriptor of one (pixel, tap), kept small (4-5 registers) because the deformable instances are register-bound:
+// BYTE offset of the top-left corner (clamped, always loadable; advances by one channel slab per fetch), the bilinear
+// fractions, validity bits 0-3 (corner inside the image) and step bits 4-5 (right / lower neighbour is a distinct,
+// in-range pixel), v2 modulation. Weights are re-derived at blend time with the reference's exact fp32 expressions
+// (deform_conv_kernel.cu:88-118).
 struct DcnDesc {
-    int o1, o2, o3, o4;
-    float w1, w2, w3, w4, m;
+    unsigned o1;
+    float lh, lw, m;
     unsigned vb;
 };
 
-__device__ static inline DcnDesc dcn_desc(const ConvSeg &sg, const long pp, const int tap, const int ntap, const int h_base,
-                                          const int w_base, const int cin, const bool mod)
+// nb: element offset of (image n, channel group) of this thread inside the feature map
+__device__ static inline DcnDesc dcn_desc(const ConvSeg &sg, const long pp, const int nb, const int tap, const int ntap,
+                                          const int h_base, const int w_base, const int cin, const bool mod)
 {
     DcnDesc d;
-    d.o1 = d.o2 = d.o3 = d.o4 = 0;
-    d.w1 = d.w2 = d.w3 = d.w4 = 0.f;
+    d.o1 = 4u * (unsigned)nb;
+    d.lh = d.lw = 0.f;
     d.m = 1.f;
     d.vb = 0;
     if (pp < 0) return d;
@@ -68,13 +71,15 @@ __device__ static inline DcnDesc dcn_desc(const ConvSeg &sg, const long pp, cons
     if (h_im > -1 && w_im > -1 && h_im < (float)H && w_im < (float)W) {
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
         const int h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-        const float hh = 1.0f - lh, hw = 1.0f - lw;
-        d.w1 = hh * hw; d.w2 = hh * lw; d.w3 = lh * hw; d.w4 = lh * lw;
+        d.lh = h_im - (float)h_low;
+        d.lw = w_im - (float)w_low;
         const bool a = h_low >= 0, b = h_high <= H - 1, c = w_low >= 0, e = w_high <= W - 1;
-        const int hl = a ? h_low : 0, hhi = b ? h_high : H - 1, wl = c ? w_low : 0, whi = e ? w_high : W - 1;
-        d.o1 = (hl * W + wl) * cin; d.o2 = (hl * W + whi) * cin; d.o3 = (hhi * W + wl) * cin; d.o4 = (hhi * W + whi) * cin;
-        d.vb = (a && c ? 1u : 0u) | (a && e ? 2u : 0u) | (b && c ? 4u : 0u) | (b && e ? 8u : 0u);
+        const int hl = a ? h_low : 0, wl = c ? w_low : 0;
+        d.o1 = 4u * (unsigned)(nb + (hl * W + wl) * cin);
+        // right neighbour differs from the left one iff both w_low >= 0 and w_high <= W-1 (otherwise the clamped pair
+        // coincides and the invalid one is masked); same for rows
+        d.vb = (a && c ? 1u : 0u) | (a && e ? 2u : 0u) | (b && c ? 4u : 0u) | (b && e ? 8u : 0u) |
+               (c && e ? 16u : 0u) | (a && b ? 32u : 0u);
     }
     if (mod) d.m = sg.mask[pp * ntap + tap];
     return d;
@@ -82,23 +87,34 @@ __device__ static inline DcnDesc dcn_desc(const ConvSeg &sg, const long pp, cons
 
 __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, float v3, float v4, const bool mod)
 {
+    const float hh = 1.0f - d.lh, hw = 1.0f - d.lw;
+    const float w1 = hh * hw, w2 = hh * d.lw, w3 = d.lh * hw, w4 = d.lh * d.lw;
     v1 = (d.vb & 1u) ? v1 : 0.f;
     v2 = (d.vb & 2u) ? v2 : 0.f;
     v3 = (d.vb & 4u) ? v3 : 0.f;
     v4 = (d.vb & 8u) ? v4 : 0.f;
-    float val = d.w1 * v1;
-    val = val + d.w2 * v2;
-    val = val + d.w3 * v3;
-    val = val + d.w4 * v4;
+    float val = w1 * v1;
+    val = val + w2 * v2;
+    val = val + w3 * v3;
+    val = val + w4 * v4;
     if (mod) val = val * d.m;
     return val;
 }
 
 // WM x WN = 32x32 tiles per wave, waves arranged WAVES_M x WAVES_N (4 waves): BM = 32*WM*WAVES_M (128 or 64) output
-// pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup.
-// DEFORM: 0 dense, 1 deformable v1, 2 deformable v2 (modulated). PIPE: pin the k-loop software pipeline.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE, int BK>
-__global__ void __launch_bounds__(256)
+// pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup. BK = input channels per K slab (32 / 64).
+// DEFORM: 0 dense, 1 deformable v1, 2 deformable v2 (modulated).
+//
+// Schedule of one slab (KS = BK/2 MFMA steps per 32x32 tile), pinned with sched_barrier because a wave that runs
+// alone on its SIMD (small feature maps) only keeps the MFMA pipe busy if everything else sits in the shadow of an MFMA:
+//   step 0        issue the global loads of a later slab (dense: slab s+2 into the register set not in use;
+//                 deformable: slab s+1) -- addresses advance incrementally, they are only recomputed at tap changes
+//   step k        LDS fragment reads of step k+1, then the MFMAs of step k
+//   steps KS-6..  registers of slab s+1 -> the other LDS buffer, one pixel (or the B slab) per step
+//   step KS-2     barrier (all fragment reads of this buffer are complete, all stashes visible)
+//   step KS-1     fragment reads of step 0 of slab s+1 from the other buffer
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK>
+__global__ void __launch_bounds__(256, (WM * WN <= 2 && BK == 32) ? 3 : 1)
 conv_igemm_f32_kernel(const ConvParams p)
 {
     constexpr int BN = WAVES_N * WN * 32;
@@ -107,10 +123,12 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr int CH4 = BK / 4;        // float4 channel groups per slab row (8 or 16)
     constexpr int RP = 256 / CH4;      // pixels staged per pass of the 256 threads (32 or 16)
     constexpr int PXT = BM / RP;       // pixels staged per thread per slab (2 or 4)
+    constexpr int KS = BK / 2;
     static_assert((BM == 128 || BM == 64) && WAVES_M * WAVES_N == 4, "tile");
     static_assert(BN == 32 || BN == 64 || BN == 128, "BN");
     static_assert((BK == 32 || BK == 64) && PXT <= 4, "BK");
     constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread for the B slab (1, 2 or 4)
+    constexpr int BROWS = 256 / (BN / 4);      // B slab rows covered by one pass of the 256 threads
     static_assert(B_F4 >= 1 && B_F4 <= 4, "B staging");
     constexpr bool MOD = DEFORM == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -156,8 +174,7 @@ conv_igemm_f32_kernel(const ConvParams p)
             pix_p[r] = pp;
         } else { pix_n[r] = -1; pix_h[r] = 0; pix_w[r] = 0; pix_p[r] = -1; }
     }
-    const int cin_slabs = p.Cin / BK;
-    const int nslabs = ntap * cin_slabs;
+    const int nslabs = ntap * (p.Cin / BK);
 
     floatx16 acc[WM][WN];
 #pragma unroll
@@ -167,139 +184,191 @@ conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Staging registers (named scalars: arrays captured by lambdas / indexed in loops were demoted to scratch).
+    // Operand addressing: uniform 64-bit base + 32-bit per-lane byte offset (one global_load each, no 64-bit VALU).
     // Loads are UNCONDITIONAL (clamped addresses); zero-fill / validity is applied when the registers are written
     // to LDS -- a "load or 0" select at the load site makes hipcc branch around every load and wait vmcnt(0) each.
-    float4 a00, a01, a02, a03, a10, a11, a12, a13, a20, a21, a22, a23, a30, a31, a32, a33;  // [pixel r][corner]
-    float4 rb0, rb1, rb2, rb3;
-    bool rv0 = false, rv1 = false, rv2 = false, rv3 = false;
+    // All staging state is in named scalars: arrays captured by lambdas / indexed in loops were demoted to scratch.
+    const char *xbase = reinterpret_cast<const char *>(sg.x);
+    const unsigned ldw4 = 4u * (unsigned)p.ldw;
+    const unsigned cin4 = 4u * (unsigned)p.Cin, wcin4 = cin4 * (unsigned)sg.W;  // byte steps to the right / lower pixel
+    const char *wb0 = reinterpret_cast<const char *>(p.w) + 4 * n0;
+    const char *wb1 = wb0 + (size_t)BROWS * ldw4, *wb2 = wb0 + (size_t)2 * BROWS * ldw4, *wb3 = wb0 + (size_t)3 * BROWS * ldw4;
+    unsigned ob = (unsigned)(tid / (BN / 4)) * ldw4 + 16u * (unsigned)(tid % (BN / 4));  // advances BK rows per slab
+    unsigned oa0 = 0, oa1 = 0, oa2 = 0, oa3 = 0;               // dense: byte offset of this thread's float4 per pixel
+    bool cv0 = false, cv1 = false, cv2 = false, cv3 = false;   // dense: tap inside the image
+    int f_cs = 0, f_tap = 0, f_ki = 0, f_kj = 0;               // (channel slab, tap) of the NEXT slab to fetch
+    bool f_newtap = true;
+    float4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;             // dense register set X
+    float4 ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3;             // dense register set Y
+    bool xv0 = false, xv1 = false, xv2 = false, xv3 = false, yv0 = false, yv1 = false, yv2 = false, yv3 = false;
+    float4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;  // deformable: [pixel][corner]
     DcnDesc d0, d1, d2, d3;
-    int desc_tap = -1;
-    int f_tap = 0, f_cs = 0, f_ki = 0, f_kj = 0;  // (tap, channel slab) of the NEXT slab to fetch
 
-#define CV_LOAD_B(Q) \
-    (*reinterpret_cast<const float4 *>(wrow + (long)((tid + 256 * (Q)) / (BN / 4)) * p.ldw + 4 * ((tid + 256 * (Q)) % (BN / 4))))
-#define CV_FETCH_DENSE(R, A0, RV)                                                                                     \
+#define CV_LDX(O) (*reinterpret_cast<const float4 *>(xbase + (O)))
+#define CV_TAP_DENSE(R)                                                                                               \
     {                                                                                                                 \
-        const int hi = pix_h[R] + ki * p.dil, wi = pix_w[R] + kj * p.dil;                                             \
-        RV = pix_n[R] >= 0 && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;                                           \
+        const int hi = pix_h[R] + f_ki * p.dil, wi = pix_w[R] + f_kj * p.dil;                                         \
+        cv##R = pix_n[R] >= 0 && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;                                        \
         const int hc = min(max(hi, 0), sg.H - 1), wc = min(max(wi, 0), sg.W - 1), nc = max(pix_n[R], 0);             \
-        A0 = *reinterpret_cast<const float4 *>(sg.x + (((long)nc * sg.H + hc) * sg.W + wc) * p.Cin + cs + 4 * ch4);   \
+        oa##R = 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + 4 * ch4);                                    \
     }
-#define CV_FETCH_DEFORM(R, D, A0, A1, A2, A3)                                                                         \
+#define CV_TAP_DEFORM(R)                                                                                              \
+    d##R = dcn_desc(sg, pix_p[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, f_tap, ntap,                      \
+                    pix_h[R] + f_ki * p.dil, pix_w[R] + f_kj * p.dil, p.Cin, MOD);
+#define CV_ADVANCE                                                                                                    \
+    ob += (unsigned)BK * ldw4;                                                                                        \
+    f_cs += BK;                                                                                                       \
+    f_newtap = f_cs == p.Cin;                                                                                         \
+    if (f_newtap) { f_cs = 0; ++f_tap; if (++f_kj == p.KW) { f_kj = 0; ++f_ki; } }
+#define CV_FETCH_B(P)                                                                                                 \
+    P##b0 = *reinterpret_cast<const float4 *>(wb0 + ob);                                                              \
+    if (B_F4 > 1) P##b1 = *reinterpret_cast<const float4 *>(wb1 + ob);                                                \
+    if (B_F4 > 2) { P##b2 = *reinterpret_cast<const float4 *>(wb2 + ob); P##b3 = *reinterpret_cast<const float4 *>(wb3 + ob); }
+#define CV_FETCH_DENSE(P)                                                                                             \
     {                                                                                                                 \
-        const float *xb = sg.x + (long)max(pix_n[R], 0) * sg.H * sg.W * p.Cin + cs + 4 * ch4;                         \
-        A0 = *reinterpret_cast<const float4 *>(xb + D.o1);                                                            \
-        A1 = *reinterpret_cast<const float4 *>(xb + D.o2);                                                            \
-        A2 = *reinterpret_cast<const float4 *>(xb + D.o3);                                                            \
-        A3 = *reinterpret_cast<const float4 *>(xb + D.o4);                                                            \
-    }
-#define CV_FETCH(S)                                                                                                   \
-    {                                                                                                                 \
-        const int tap = f_tap, cs = f_cs, ki = f_ki, kj = f_kj;                                                       \
-        if (p.kord) {                                                                                                 \
-            if (++f_tap == ntap) { f_tap = 0; f_ki = 0; f_kj = 0; f_cs += BK; }                                       \
-            else if (++f_kj == p.KW) { f_kj = 0; ++f_ki; }                                                            \
-        } else {                                                                                                      \
-            f_cs += BK;                                                                                               \
-            if (f_cs == p.Cin) { f_cs = 0; ++f_tap; if (++f_kj == p.KW) { f_kj = 0; ++f_ki; } }                       \
+        if (f_newtap) { CV_TAP_DENSE(0) CV_TAP_DENSE(1) if (PXT > 2) { CV_TAP_DENSE(2) CV_TAP_DENSE(3) } }            \
+        P##a0 = CV_LDX(oa0); P##v0 = cv0; oa0 += 4u * BK;                                                             \
+        P##a1 = CV_LDX(oa1); P##v1 = cv1; oa1 += 4u * BK;                                                             \
+        if (PXT > 2) {                                                                                                \
+            P##a2 = CV_LDX(oa2); P##v2 = cv2; oa2 += 4u * BK;                                                         \
+            P##a3 = CV_LDX(oa3); P##v3 = cv3; oa3 += 4u * BK;                                                         \
         }                                                                                                             \
-        if (DEFORM) {                                                                                                 \
-            if (tap != desc_tap) {                                                                                    \
-                desc_tap = tap;                                                                                       \
-                d0 = dcn_desc(sg, pix_p[0], tap, ntap, pix_h[0] + ki * p.dil, pix_w[0] + kj * p.dil, p.Cin, MOD);     \
-                d1 = dcn_desc(sg, pix_p[1], tap, ntap, pix_h[1] + ki * p.dil, pix_w[1] + kj * p.dil, p.Cin, MOD);     \
-                if (PXT > 2) {                                                                                        \
-                d2 = dcn_desc(sg, pix_p[2], tap, ntap, pix_h[2] + ki * p.dil, pix_w[2] + kj * p.dil, p.Cin, MOD);     \
-                d3 = dcn_desc(sg, pix_p[3], tap, ntap, pix_h[3] + ki * p.dil, pix_w[3] + kj * p.dil, p.Cin, MOD);     \
-                }                                                                                                     \
-            }                                                                                                         \
-            CV_FETCH_DEFORM(0, d0, a00, a01, a02, a03) CV_FETCH_DEFORM(1, d1, a10, a11, a12, a13)                     \
-            if (PXT > 2) { CV_FETCH_DEFORM(2, d2, a20, a21, a22, a23) CV_FETCH_DEFORM(3, d3, a30, a31, a32, a33) }    \
-        } else {                                                                                                      \
-            CV_FETCH_DENSE(0, a00, rv0) CV_FETCH_DENSE(1, a10, rv1)                                                   \
-            if (PXT > 2) { CV_FETCH_DENSE(2, a20, rv2) CV_FETCH_DENSE(3, a30, rv3) }                                  \
-        }                                                                                                             \
-        const float *wrow = p.w + ((long)tap * p.Cin + cs) * p.ldw + n0;                                              \
-        rb0 = CV_LOAD_B(0);                                                                                           \
-        if (B_F4 > 1) rb1 = CV_LOAD_B(1);                                                                             \
-        if (B_F4 > 2) { rb2 = CV_LOAD_B(2); rb3 = CV_LOAD_B(3); }                                                     \
+        CV_FETCH_B(P)                                                                                                 \
+        CV_ADVANCE                                                                                                    \
     }
-#define CV_STASH_PX(R, VX, VY, VZ, VW)                                                                                \
+#define CV_FETCH_DEFORM_PX(R)                                                                                         \
     {                                                                                                                 \
-        const int px = prow + RP * R;                                                                                 \
-        sa[(4 * ch4 + 0) * LDA + px] = VX;                                                                         \
-        sa[(4 * ch4 + 1) * LDA + px] = VY;                                                                         \
-        sa[(4 * ch4 + 2) * LDA + px] = VZ;                                                                         \
-        sa[(4 * ch4 + 3) * LDA + px] = VW;                                                                         \
+        const unsigned oR_ = d##R.o1 + ((d##R.vb & 16u) ? cin4 : 0u), oD_ = d##R.o1 + ((d##R.vb & 32u) ? wcin4 : 0u); \
+        c##R##0 = CV_LDX(d##R.o1); c##R##1 = CV_LDX(oR_); c##R##2 = CV_LDX(oD_); c##R##3 = CV_LDX(oD_ + (oR_ - d##R.o1)); \
+        d##R.o1 += 4u * BK;                                                                                           \
     }
-#define CV_STASH_DENSE(R, A0, RV) CV_STASH_PX(R, RV ? A0.x : 0.f, RV ? A0.y : 0.f, RV ? A0.z : 0.f, RV ? A0.w : 0.f)
-#define CV_STASH_DEFORM(R, D, A0, A1, A2, A3)                                                                         \
-    CV_STASH_PX(R, dcn_blend1(D, A0.x, A1.x, A2.x, A3.x, MOD), dcn_blend1(D, A0.y, A1.y, A2.y, A3.y, MOD),            \
-                dcn_blend1(D, A0.z, A1.z, A2.z, A3.z, MOD), dcn_blend1(D, A0.w, A1.w, A2.w, A3.w, MOD))
-#define CV_STASH(BUF)                                                                                                 \
+#define CV_FETCH_DEFORM                                                                                               \
     {                                                                                                                 \
-        float *sa = As + (BUF) * BK * LDA;                                                                            \
-        if (DEFORM) {                                                                                                 \
-            CV_STASH_DEFORM(0, d0, a00, a01, a02, a03) CV_STASH_DEFORM(1, d1, a10, a11, a12, a13)                     \
-            if (PXT > 2) { CV_STASH_DEFORM(2, d2, a20, a21, a22, a23) CV_STASH_DEFORM(3, d3, a30, a31, a32, a33) }    \
-        } else {                                                                                                      \
-            CV_STASH_DENSE(0, a00, rv0) CV_STASH_DENSE(1, a10, rv1)                                                   \
-            if (PXT > 2) { CV_STASH_DENSE(2, a20, rv2) CV_STASH_DENSE(3, a30, rv3) }                                  \
-        }                                                                                                             \
+        if (f_newtap) { CV_TAP_DEFORM(0) CV_TAP_DEFORM(1) if (PXT > 2) { CV_TAP_DEFORM(2) CV_TAP_DEFORM(3) } }        \
+        CV_FETCH_DEFORM_PX(0) CV_FETCH_DEFORM_PX(1)                                                                   \
+        if (PXT > 2) { CV_FETCH_DEFORM_PX(2) CV_FETCH_DEFORM_PX(3) }                                                  \
+        CV_FETCH_B(x)                                                                                                 \
+        CV_ADVANCE                                                                                                    \
+    }
+#define CV_FETCH_x CV_FETCH_DENSE(x)
+#define CV_FETCH_y CV_FETCH_DENSE(y)
+#define CV_FETCH_c CV_FETCH_DEFORM
+#define CV_FETCH(SET) CV_FETCH_##SET
+
+#define CV_STASH_PX(BUF, R, VX, VY, VZ, VW)                                                                           \
+    {                                                                                                                 \
+        float *sa = As + (BUF) * BK * LDA + prow + RP * R;                                                            \
+        sa[(4 * ch4 + 0) * LDA] = VX;                                                                                 \
+        sa[(4 * ch4 + 1) * LDA] = VY;                                                                                 \
+        sa[(4 * ch4 + 2) * LDA] = VZ;                                                                                 \
+        sa[(4 * ch4 + 3) * LDA] = VW;                                                                                 \
+    }
+#define CV_STASH_A_DENSE(P, BUF, R)                                                                                   \
+    CV_STASH_PX(BUF, R, P##v##R ? P##a##R.x : 0.f, P##v##R ? P##a##R.y : 0.f, P##v##R ? P##a##R.z : 0.f, P##v##R ? P##a##R.w : 0.f)
+#define CV_STASH_A_x(BUF, R) CV_STASH_A_DENSE(x, BUF, R)
+#define CV_STASH_A_y(BUF, R) CV_STASH_A_DENSE(y, BUF, R)
+#define CV_STASH_A_c(BUF, R)                                                                                          \
+    CV_STASH_PX(BUF, R, dcn_blend1(d##R, (c##R##0).x, (c##R##1).x, (c##R##2).x, (c##R##3).x, MOD),                            \
+                dcn_blend1(d##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y, MOD),                                    \
+                dcn_blend1(d##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z, MOD),                                    \
+                dcn_blend1(d##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w, MOD))
+#define CV_STASH_A(SET, BUF, R) CV_STASH_A_##SET(BUF, R)
+#define CV_STASH_B_P(P, BUF)                                                                                          \
+    {                                                                                                                 \
         float4 *sb = reinterpret_cast<float4 *>(Bs + (BUF) * BK * BN);                                                \
-        sb[tid] = rb0;                                                                                                \
-        if (B_F4 > 1) sb[tid + 256] = rb1;                                                                            \
-        if (B_F4 > 2) { sb[tid + 512] = rb2; sb[tid + 768] = rb3; }                                                   \
+        sb[tid] = P##b0;                                                                                              \
+        if (B_F4 > 1) sb[tid + 256] = P##b1;                                                                          \
+        if (B_F4 > 2) { sb[tid + 512] = P##b2; sb[tid + 768] = P##b3; }                                               \
+    }
+#define CV_STASH_B_x(BUF) CV_STASH_B_P(x, BUF)
+#define CV_STASH_B_y(BUF) CV_STASH_B_P(y, BUF)
+#define CV_STASH_B_c(BUF) CV_STASH_B_P(x, BUF)
+#define CV_STASH_B(SET, BUF) CV_STASH_B_##SET(BUF)
+
+    float av[2][WM], bv[2][WN];  // MFMA fragments, double-buffered over k steps (carried across slabs)
+#define CV_FRAG(BUF, K, SLOT)                                                                                         \
+    {                                                                                                                 \
+        const float *a_ = As + (BUF) * BK * LDA + wm * (WM * 32) + aij + (2 * (K) + akr) * LDA;                       \
+        const float *b_ = Bs + (BUF) * BK * BN + wn * (WN * 32) + aij + (2 * (K) + akr) * BN;                         \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) av[SLOT][i] = a_[32 * i];                                      \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) bv[SLOT][j] = b_[32 * j];                                      \
+    }
+// one slab: contract LDS buffer BUF; DO_FETCH: issue loads into FSET; DO_STASH: registers SSET -> buffer BUF^1
+#define CV_SLAB(BUF, FSET, SSET, DO_FETCH, DO_STASH)                                                                  \
+    {                                                                                                                 \
+        const bool do_fetch_ = (DO_FETCH), do_stash_ = (DO_STASH);                                                    \
+        _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                                              \
+            const int cur = k & 1, nxt = cur ^ 1;                                                                     \
+            if (k == 0 && do_fetch_) CV_FETCH(FSET)                                                                   \
+            if (k + 1 < KS) CV_FRAG(BUF, k + 1, nxt)                                                                  \
+            else if (do_stash_) CV_FRAG((BUF) ^ 1, 0, nxt)                                                            \
+            if (do_stash_) {                                                                                          \
+                if (k == KS - 6) CV_STASH_A(SSET, (BUF) ^ 1, 0)                                                       \
+                if (k == KS - 5) CV_STASH_A(SSET, (BUF) ^ 1, 1)                                                       \
+                if (PXT > 2 && k == KS - 4) CV_STASH_A(SSET, (BUF) ^ 1, 2)                                            \
+                if (PXT > 2 && k == KS - 3) CV_STASH_A(SSET, (BUF) ^ 1, 3)                                            \
+                if (k == KS - 3) CV_STASH_B(SSET, (BUF) ^ 1)                                                          \
+            }                                                                                                         \
+            if (k == KS - 2) __syncthreads();                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);     \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
     }
 
-    CV_FETCH(0)
-    CV_STASH(0)
-    __syncthreads();
-    for (int s = 0; s < nslabs; ++s) {
-        const int buf = s & 1;
-        const bool more = s + 1 < nslabs;
-        // Deformable: CV_STASH blends with d0..d3, which CV_FETCH refreshes at tap boundaries BEFORE issuing that
-        // slab's loads; fetch(s+1) and stash(s+1) always see the same descriptors, slab s was stashed earlier.
-        if (more) CV_FETCH(s + 1)
-        const float *a = As + buf * BK * LDA + wm * (WM * 32) + aij;
-        const float *b = Bs + buf * BK * BN + wn * (WN * 32) + aij;
-        // software-pipelined k loop: the LDS fragment reads of step k+1 are issued before the MFMAs of step k, and
-        // the next slab's registers are written to the other LDS buffer under the last quarter of the MFMAs
-        float av[2][WM], bv[2][WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) av[0][i] = a[akr * LDA + 32 * i];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bv[0][j] = b[akr * BN + 32 * j];
-#pragma unroll
-        for (int k = 0; k < BK / 2; ++k) {
-            const int cur = k & 1, nxt = cur ^ 1;
-            if (k + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i) av[nxt][i] = a[(2 * (k + 1) + akr) * LDA + 32 * i];
-#pragma unroll
-                for (int j = 0; j < WN; ++j) bv[nxt][j] = b[(2 * (k + 1) + akr) * BN + 32 * j];
-            }
-            if (PIPE && k == 3 * (BK / 2) / 4 && more) CV_STASH(buf ^ 1)
-            if (PIPE) __builtin_amdgcn_sched_barrier(0);  // keep the k+1 fragment reads (and the stash) ahead of step k's MFMAs
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
-            if (PIPE) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!PIPE && more) CV_STASH(buf ^ 1)
+    if (DEFORM) {
+        CV_FETCH(c)
+        CV_STASH_A(c, 0, 0) CV_STASH_A(c, 0, 1)
+        if (PXT > 2) { CV_STASH_A(c, 0, 2) CV_STASH_A(c, 0, 3) }
+        CV_STASH_B(c, 0)
         __syncthreads();
+        CV_FRAG(0, 0, 0)
+        for (int s = 0; s < nslabs; s += 2) {
+            CV_SLAB(0, c, c, s + 1 < nslabs, s + 1 < nslabs)
+            if (s + 1 >= nslabs) break;
+            CV_SLAB(1, c, c, s + 2 < nslabs, s + 2 < nslabs)
+        }
+    } else {
+        CV_FETCH(x)
+        CV_STASH_A(x, 0, 0) CV_STASH_A(x, 0, 1)
+        if (PXT > 2) { CV_STASH_A(x, 0, 2) CV_STASH_A(x, 0, 3) }
+        CV_STASH_B(x, 0)
+        if (nslabs > 1) CV_FETCH(y)
+        __syncthreads();
+        CV_FRAG(0, 0, 0)
+        for (int s = 0; s < nslabs; s += 2) {
+            CV_SLAB(0, x, y, s + 2 < nslabs, s + 1 < nslabs)
+            if (s + 1 >= nslabs) break;
+            CV_SLAB(1, y, x, s + 3 < nslabs, s + 2 < nslabs)
+        }
     }
-#undef CV_LOAD_B
+#undef CV_LDX
+#undef CV_TAP_DENSE
+#undef CV_TAP_DEFORM
+#undef CV_ADVANCE
+#undef CV_FETCH_B
 #undef CV_FETCH_DENSE
+#undef CV_FETCH_DEFORM_PX
 #undef CV_FETCH_DEFORM
+#undef CV_FETCH_x
+#undef CV_FETCH_y
+#undef CV_FETCH_c
 #undef CV_FETCH
 #undef CV_STASH_PX
-#undef CV_STASH_DENSE
-#undef CV_STASH_DEFORM
-#undef CV_STASH
+#undef CV_STASH_A_DENSE
+#undef CV_STASH_A_x
+#undef CV_STASH_A_y
+#undef CV_STASH_A_c
+#undef CV_STASH_A
+#undef CV_STASH_B_P
+#undef CV_STASH_B_x
+#undef CV_STASH_B_y
+#undef CV_STASH_B_c
+#undef CV_STASH_B
+#undef CV_FRAG
+#undef CV_SLAB
 
     // ---- fused epilogue: + bias, + residual, ReLU. Residual values are loaded 16 at a time, unconditionally
     // (clamped row), before any of them is used, so the loads overlap instead of serialising.
@@ -335,7 +404,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int PIPE, int BK = CV_BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK = CV_BK>
 static int conv_launch(hipStream_t st, ConvParams &p)
 {
     constexpr int BN = WAVES_N * WN * 32, BM = WAVES_M * WM * 32;
@@ -347,39 +416,31 @@ static int conv_launch(hipStream_t st, ConvParams &p)
     const size_t smem = (size_t)(2 * BK * (BM + 1) + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_set && smem > 64 * 1024) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE, BK>),
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;  // see the XCD-aware tile order in the kernel
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, PIPE, BK>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK>), dim3(grid), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("conv_igemm_f32_kernel");
     return 0;
 }
 
-// Tile choice (measured on MI355X over every conv shape of UPSNet-50 @1024x2048, tools/sweep_conv_tiles.py): on this chip
-// the fp32 MFMA kernel is occupancy-bound -- the 64-pixel tiles (88-150 registers, 33-50 KiB LDS -> 3-5 waves per SIMD)
-// beat the 128x128 tile (208 registers, 66 KiB -> 2 waves) on almost every layer. 64x128 wins for the large 3x3 layers
-// and for the deformable variant (A operand = expensive gather, computed once per 128 output channels); 64x64 elsewhere.
-// upsnet_conv_tuning(pipe, force_tile) overrides for A/B runs.
-static int g_pipe = -1, g_force_tile = 0, g_kord = 0;
-extern "C" void upsnet_conv_tuning(int pipe, int force_tile)
-{
-    g_pipe = pipe < 0 ? -1 : (pipe & 1);
-    g_kord = pipe < 0 ? 0 : ((pipe & 2) ? 1 : 0);  // bit 1 of `pipe` selects the slab-outer K walk (A/B runs only)
-    g_force_tile = force_tile;
-}
+// Tile choice (measured on MI355X over every conv shape of UPSNet-50 @1024x2048, tools/sweep_conv_tiles.py): with the pinned
+// schedule above one wave keeps the MFMA pipe ~80 % busy, and the 64x64 tile (107 registers, 33 KiB LDS -> 4 workgroups per
+// CU) wins on every dense layer, from 2048 to 174592 pixels. The deformable variants use 64x128 (the A operand is an
+// expensive gather, computed once per 128 output channels; 168 registers -> 3 waves per SIMD). Cout <= 32 heads use 128x32.
+// upsnet_conv_tuning(0, force_tile) overrides for A/B runs.
+static int g_force_tile = 0;
+extern "C" void upsnet_conv_tuning(int reserved, int force_tile) { (void)reserved; g_force_tile = force_tile; }
 
-template <int DEFORM, int PIPE>
-static int conv_dispatch2(hipStream_t st, ConvParams &p)
+template <int DEFORM>
+static int conv_dispatch(hipStream_t st, ConvParams &p)
 {
-    long M = 0;
-    for (int i = 0; i < p.nseg; ++i) M += p.seg[i].M;
     const bool n128 = p.ldw % 128 == 0, n64 = p.ldw % 64 == 0;
     int tile = g_force_tile;
     if (!tile) {
         if (DEFORM) tile = n128 ? 4 : (n64 ? 5 : 3);
-        else if (n128 && p.KH * p.KW > 1 && M >= 32768) tile = 4;
         else tile = n64 ? 5 : 3;
     }
     if (tile == 1 && !n128) tile = n64 ? 2 : 3;
@@ -387,21 +448,13 @@ static int conv_dispatch2(hipStream_t st, ConvParams &p)
     if (tile == 4 && !n128) tile = n64 ? 5 : 3;
     if (tile == 6 && (!n64 || p.Cin % 64 != 0)) tile = n64 ? 5 : 3;
     switch (tile) {
-    case 1: return conv_launch<2, 2, 2, 2, DEFORM, PIPE>(st, p);   // 128 x 128
-    case 2: return conv_launch<1, 2, 4, 1, DEFORM, PIPE>(st, p);   // 128 x 64
-    case 4: return conv_launch<1, 2, 2, 2, DEFORM, PIPE>(st, p);   // 64 x 128
-    case 5: return conv_launch<1, 1, 2, 2, DEFORM, PIPE>(st, p);   // 64 x 64
-    case 6: return conv_launch<1, 1, 2, 2, DEFORM, PIPE, 64>(st, p);  // 64 x 64, 64-channel K slabs
-    default: return conv_launch<1, 1, 4, 1, DEFORM, PIPE>(st, p);  // 128 x 32
+    case 1: return conv_launch<2, 2, 2, 2, DEFORM>(st, p);      // 128 x 128
+    case 2: return conv_launch<1, 2, 4, 1, DEFORM>(st, p);      // 128 x 64
+    case 4: return conv_launch<1, 2, 2, 2, DEFORM>(st, p);      // 64 x 128
+    case 5: return conv_launch<1, 1, 2, 2, DEFORM>(st, p);      // 64 x 64
+    case 6: return conv_launch<1, 1, 2, 2, DEFORM, 64>(st, p);  // 64 x 64, 64-channel K slabs
+    default: return conv_launch<1, 1, 4, 1, DEFORM>(st, p);     // 128 x 32
     }
-}
-
-template <int DEFORM>
-static int conv_dispatch(hipStream_t st, ConvParams &p)
-{
-    const int pipe = g_pipe >= 0 ? g_pipe : 1;
-    p.kord = g_kord;
-    return pipe ? conv_dispatch2<DEFORM, 1>(st, p) : conv_dispatch2<DEFORM, 0>(st, p);
 }
 
 static int conv_fill(ConvParams &p, const char *who, int nseg, const float *const x[], const float *const res[],
@@ -414,6 +467,7 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
     UPS_REQUIRE(Cin > 0 && Cin % CV_BK == 0, "%s: Cin must be a multiple of 32 (got %d)", who, Cin);
     UPS_REQUIRE(Cout > 0 && ldw % 32 == 0 && ldw >= Cout, "%s: ldw must be Cout rounded up to 32 (got %d for Cout=%d)", who, ldw, Cout);
     UPS_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0 && dil >= 1, "%s: bad kernel/stride/pad/dilation", who);
+    UPS_REQUIRE((long)KH * KW * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
     p.w = wpack; p.bias = bias; p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
     int tiles = 0;
@@ -427,7 +481,7 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
             s.Ho = (height[i] + 2 * pad - (dil * (KH - 1) + 1)) / stride + 1;
             s.Wo = (width[i] + 2 * pad - (dil * (KW - 1) + 1)) / stride + 1;
             UPS_REQUIRE(s.Ho > 0 && s.Wo > 0, "%s: empty output for feature map %d", who, i);
-            UPS_REQUIRE((long)height[i] * width[i] * Cin < 2147483647L, "%s: feature map %d too large for 32-bit offsets", who, i);
+            UPS_REQUIRE((long)nb * height[i] * width[i] * Cin < (1L << 30), "%s: feature map %d exceeds 4 GiB (32-bit byte offsets); split the batch", who, i);
             s.M = (long)nb * s.Ho * s.Wo;
             s.tile_start = tiles;
             tiles += (int)((s.M + 127) / 128);
