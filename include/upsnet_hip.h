@@ -204,6 +204,14 @@ int upsnet_panoptic_fuse(void *stream, const float *fcn_output, int num_seg, int
                          int mask_size, const int64_t *class_map, int enable_void, int64_t *pan_out,
                          int64_t *sem_out);
 
+/* Tail of the semantic head (upsnet/models/fcn.py:94-100: upsample x2/x4/x8, concat, 1x1 `score` conv), with the linear
+ * 1x1 convolution commuted below the bilinear upsampling: part[l] = W[:, 128 l:128 (l+1)] . y_l at level l's own
+ * resolution, NHWC [height >> l, width >> l, num_seg] (made with upsnet_conv2d_nhwc_f32); this entry computes
+ *   score[y,x,s] = bias[s] + part[0][y,x,s] + sum_{l>=1} bilinear_up_{2^l}(part[l])[y,x,s]   (align_corners = False)
+ * into score [height, width, num_seg] NHWC. bias may be NULL. 1 <= nlev <= 4. */
+int upsnet_fcn_score_combine(void *stream, int nlev, const float *const part[], int num_seg, int height, int width,
+                             const float *bias, float *score);
+
 /* Same as upsnet_panoptic_fuse (enable_void branch) but ALSO fuses FCNHead's x4 bilinear upsampling
  * (F.interpolate(score, None, 4, 'bilinear', align_corners=False), upsnet/models/fcn.py:101): takes the low-resolution
  * fcn_score [S,Hs,Ws] (score_nhwc = 0) or [Hs,Ws,S] (score_nhwc = 1); label maps are [Hs*scale, Ws*scale]. */

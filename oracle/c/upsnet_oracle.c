@@ -436,3 +436,36 @@ void orc_upsample_bilinear(const float *src, int S, int Hs, int Ws, int scale, f
             }
         }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Semantic-head tail with the 1x1 score conv commuted below the bilinear upsampling (fcn.py:94-100 restated through
+ * linearity): out[y,x,s] = bias[s] + part0[y,x,s] + sum_{l>=1} up_{2^l}(part_l)[y,x,s]; all maps NHWC [H>>l, W>>l, S].
+ * Interpolation terms as in orc_upsample_bilinear (PyTorch upsample_bilinear2d, align_corners=False).
+ * ---------------------------------------------------------------------------------------- */
+void orc_fcn_score_combine(const float *const *part, int nlev, int S, int H, int W, const float *bias, float *out)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int s = 0; s < S; ++s) {
+                const size_t idx = ((size_t)y * W + x) * S + s;
+                float acc = part[0][idx];
+                if (bias) acc = acc + bias[s];
+                for (int l = 1; l < nlev; ++l) {
+                    const int Hs = H >> l, Ws = W >> l;
+                    const float r = 1.0f / (float)(1 << l);
+                    float h1r = r * ((float)y + 0.5f) - 0.5f;
+                    if (h1r < 0) h1r = 0;
+                    const int h1 = (int)h1r, h1p = h1 < Hs - 1 ? 1 : 0;
+                    const float h1l = h1r - (float)h1, h0l = 1.0f - h1l;
+                    float w1r = r * ((float)x + 0.5f) - 0.5f;
+                    if (w1r < 0) w1r = 0;
+                    const int w1 = (int)w1r, w1p = w1 < Ws - 1 ? 1 : 0;
+                    const float w1l = w1r - (float)w1, w0l = 1.0f - w1l;
+                    const float *q = part[l] + s;
+                    const float top = w0l * q[((size_t)h1 * Ws + w1) * S] + w1l * q[((size_t)h1 * Ws + w1 + w1p) * S];
+                    const float bot = w0l * q[((size_t)(h1 + h1p) * Ws + w1) * S] + w1l * q[((size_t)(h1 + h1p) * Ws + w1 + w1p) * S];
+                    acc = acc + (h0l * top + h1l * bot);
+                }
+                out[idx] = acc;
+            }
+}

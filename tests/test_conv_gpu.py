@@ -39,3 +39,42 @@ def test_conv2d_nhwc_vs_torch(N, Cin, Cout, H, W, k, stride, pad, relu, res, bia
     # channels_last input gives the same bits as an NCHW input (layout plumbing only)
     out2 = ops.conv2d_nhwc(x.contiguous(memory_format=torch.channels_last), wp, ldw, b, Cout, k, stride, pad, relu=relu, residual=r)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("S,H,W,nlev,bias", [(19, 32, 64, 4, True), (133, 24, 40, 4, True), (5, 8, 8, 2, False), (19, 16, 16, 1, True)])
+def test_fcn_score_combine_vs_oracle(S, H, W, nlev, bias):
+    """Bit-exact vs the C oracle (same expression order, no FMA)."""
+    import oracle
+    from upsnet_amd import ops
+    rng = np.random.default_rng(S + H)
+    parts = [rng.standard_normal((H >> l, W >> l, S)).astype(np.float32) for l in range(nlev)]
+    b = rng.standard_normal(S).astype(np.float32) if bias else None
+    ref = oracle.fcn_score_combine(parts, b)
+    tp = [torch.from_numpy(t).cuda().permute(2, 0, 1)[None] for t in parts]   # logical NCHW over NHWC memory
+    out = ops.fcn_score_combine(tp, None if b is None else torch.from_numpy(b).cuda())
+    assert out.shape == (1, S, H, W)
+    np.testing.assert_array_equal(out[0].permute(1, 2, 0).cpu().numpy(), ref)
+
+
+def test_fcn_head_commuted_score_vs_reference_order():
+    """FCNHead.forward_score with the 1x1 conv commuted below the upsampling == the reference op order (fcn.py:94-100), 1e-4."""
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.models.fcn import FCNHead
+    torch.manual_seed(3)
+    head = FCNHead(256, 19, 2).cuda().eval()
+    torch.nn.init.normal_(head.score.weight, 0, 0.05)
+    torch.nn.init.normal_(head.score.bias, 0, 0.5)
+    for layer in head.fcn_subnet.conv:
+        torch.nn.init.normal_(layer[0].conv_offset.weight, 0, 0.01)
+    feats = [torch.randn(1, 256, 64 >> l, 96 >> l, device='cuda') for l in range(4)]
+    with torch.no_grad():
+        a = head.forward_score(*feats, commute=True)
+        b = head.forward_score(*feats, commute=False)
+        # and against plain torch ops on the subnet outputs (the reference's own sequence)
+        ys = head.fcn_subnet.forward_levels(feats)
+        ups = [ys[0]] + [F.interpolate(ys[l], None, 2 ** l, mode='bilinear', align_corners=False) for l in (1, 2, 3)]
+        c = F.conv2d(torch.cat([u.contiguous() for u in ups], 1), head.score.weight, head.score.bias)
+    assert a.shape == b.shape == c.shape == (1, 19, 64, 96)
+    np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -148,3 +148,20 @@ def test_mask_roi_invariants():
     assert (b[:, 1:] >= 0).all() and (b[:, 3] <= 499).all() and (b[:, 4] <= 299).all() and not b[:, 0].any()
     s2, b2, c2 = oops.mask_roi(rois, delta, prob * 0, np.array([[300, 500, 1]], np.float32), C, 0.5, 0.05, 100, False)
     assert s2.tolist() == [1.0] and c2.tolist() == [0] and not b2.any()   # dummy detection
+
+
+def test_fcn_score_combine_matches_torch_sequence():
+    """oracle.fcn_score_combine == conv1x1(cat(upsampled levels)) of torch (fcn.py:94-100) up to fp32 summation order."""
+    import torch
+    import torch.nn.functional as F
+    import oracle
+    rng = np.random.default_rng(0)
+    S, H, W, C = 7, 16, 24, 12
+    ys = [torch.from_numpy(rng.standard_normal((1, C, H >> l, W >> l)).astype(np.float32)) for l in range(4)]
+    wgt = torch.from_numpy(rng.standard_normal((S, 4 * C, 1, 1)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(S).astype(np.float32))
+    ups = [ys[0]] + [F.interpolate(ys[l], None, 2 ** l, mode='bilinear', align_corners=False) for l in (1, 2, 3)]
+    ref = F.conv2d(torch.cat(ups, 1), wgt, b)[0].permute(1, 2, 0).numpy()
+    parts = [F.conv2d(ys[l], wgt[:, l * C:(l + 1) * C])[0].permute(1, 2, 0).contiguous().numpy() for l in range(4)]
+    out = oracle.fcn_score_combine(parts, b.numpy())
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)

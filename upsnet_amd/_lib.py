@@ -42,6 +42,7 @@ _SIGNATURES = {
     "upsnet_seg_term": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_int, P]),
     "upsnet_panoptic_fuse": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, P, P]),
     "upsnet_panoptic_fuse_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, P, P]),
+    "upsnet_fcn_score_combine": (c_int, [P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
 }
 

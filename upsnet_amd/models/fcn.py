@@ -87,9 +87,28 @@ class FCNHead(nn.Module):
         nn.init.normal_(self.score.weight.data, 0, 0.01)
         self.score.bias.data.zero_()
 
-    def forward_score(self, fpn_p2, fpn_p3, fpn_p4, fpn_p5):
-        """fcn_score only ([1,S,H/4,W/4]); the x4 upsampling is fused into the panoptic kernel by the caller."""
-        fpn_p2, fpn_p3, fpn_p4, fpn_p5 = self.fcn_subnet.forward_levels([fpn_p2, fpn_p3, fpn_p4, fpn_p5])
+    def _score_parts(self):
+        """Per-level column blocks of the 1x1 score weight, packed for the MFMA conv kernel (cached)."""
+        w = self.score.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, '_score_pack', None) is None or self._score_pack[0] != key:
+            c = w.shape[1] // 4
+            self._score_pack = (key, [ops.pack_conv_weight(w.detach()[:, l * c:(l + 1) * c].contiguous()) for l in range(4)])
+        return self._score_pack[1]
+
+    def forward_score(self, fpn_p2, fpn_p3, fpn_p4, fpn_p5, commute=True):
+        """fcn_score only ([1,S,H/4,W/4]); the x4 upsampling is fused into the panoptic kernel by the caller.
+        commute=True evaluates conv1x1(cat(up(y_l))) as sum_l up(W_l y_l) (both linear): four small products at the
+        levels' own resolution + one combine kernel instead of three 128-channel upsample passes, a 512-channel concat
+        and the wide conv. Same value up to fp32 summation order."""
+        ys = self.fcn_subnet.forward_levels([fpn_p2, fpn_p3, fpn_p4, fpn_p5])
+        S = self.score.out_channels
+        if (commute and ys[0].is_cuda and ys[0].shape[0] == 1 and ys[0].shape[2] % 8 == 0 and ys[0].shape[3] % 8 == 0 and
+                all(y.shape[1] * 4 == self.score.in_channels and ops.conv_supported(y.shape[1], 1, 1, 1, (1, 1)) for y in ys)):
+            packs = self._score_parts()
+            parts = [ops.conv2d_nhwc(y, wp, ldw, None, S, 1, 1, 0) for y, (wp, ldw) in zip(ys, packs)]
+            return ops.fcn_score_combine(parts, self.score.bias)
+        fpn_p2, fpn_p3, fpn_p4, fpn_p5 = ys
         fpn_p3 = F.interpolate(fpn_p3, None, 2, mode='bilinear', align_corners=False)
         fpn_p4 = F.interpolate(fpn_p4, None, 4, mode='bilinear', align_corners=False)
         fpn_p5 = F.interpolate(fpn_p5, None, 8, mode='bilinear', align_corners=False)

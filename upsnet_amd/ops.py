@@ -398,6 +398,21 @@ def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, resid
     return conv2d_nhwc_multi([x], wpack, ldw, bias, cout, ksize, stride, pad, relu, None if residual is None else [residual])[0]
 
 
+def fcn_score_combine(parts, bias=None):
+    """score = bias + parts[0] + sum_l bilinear_up_{2^l}(parts[l]); parts[l]: logical NCHW [1,S,H>>l,W>>l] (channels_last
+    memory). Returns a channels_last [1,S,H,W] tensor (fcn.py:94-100 with the 1x1 conv commuted below the upsampling)."""
+    require_cuda(*parts)
+    parts = [nhwc(t.float()) for t in parts]
+    _, S, H, W = parts[0].shape
+    for l, t in enumerate(parts):
+        if tuple(t.shape) != (1, S, H >> l, W >> l):
+            raise RuntimeError("fcn_score_combine: level %d has shape %s, expected %s" % (l, tuple(t.shape), (1, S, H >> l, W >> l)))
+    out = _nhwc_out(1, S, H, W, parts[0].device)
+    check(lib().upsnet_fcn_score_combine(stream(), len(parts), ptr_array(parts), S, H, W, ptr(None if bias is None else f32c(bias)),
+                                         ptr(out)), "fcn_score_combine")
+    return out
+
+
 def panoptic_fuse_up(fcn_score, scale, num_stuff, mask_rois5, mask_logit, cls_idx, keep, num, real, class_map, want_sem=True):
     """Fused head INCLUDING FCNHead's x4 bilinear upsampling: takes the low-resolution fcn_score [1,S,Hs,Ws]
     (logical NCHW; channels_last memory is consumed as is) and returns (panoptic, semantic) [1,Hs*scale,Ws*scale] int64."""
