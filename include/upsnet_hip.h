@@ -98,11 +98,13 @@ int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const float *const x
  * GEMM on v_mfma_f32_32x32x2_f32 with a fused epilogue. Up to 5 feature maps sharing the weights per launch.
  *   x[i] [N_i,H_i,W_i,Cin] NHWC (Cin % 32 == 0), wpack [KH*KW*Cin, ldw] from upsnet_conv_pack_weight (ldw = Cout
  *   rounded up to a multiple of 32), bias [Cout] or NULL, residual (NULL or array; entries [N_i,Ho,Wo,Cout]),
- *   out[i] [N_i,Ho,Wo,Cout]; batch == NULL means N_i = 1. Pointer/shape arrays are HOST arrays of nseg entries. */
+ *   out[i] [N_i,Ho,Wo,Cout]; batch == NULL means N_i = 1. Pointer/shape arrays are HOST arrays of nseg entries.
+ *   residual_up != 0: residual entries are [N_i,Ho/2,Wo/2,Cout] and are added through a nearest x2 upsampling
+ *   (the FPN top-down add, F.interpolate(scale_factor=2, mode='nearest') + sum, fpn.py:34,90-96). */
 int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
                            float *const out[], const int batch[], const int height[], const int width[], int Cin,
                            const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
-                           int relu);
+                           int relu, int residual_up);
 
 /* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
  * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). `reserved` is ignored. Not needed in production. */

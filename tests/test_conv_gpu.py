@@ -78,3 +78,22 @@ def test_fcn_head_commuted_score_vs_reference_order():
     assert a.shape == b.shape == c.shape == (1, 19, 64, 96)
     np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 64, 256, 16, 24), (2, 32, 64, 6, 10), (1, 256, 256, 64, 128)])
+def test_conv_residual_nearest_upsample_fused(N, Cin, Cout, H, W):
+    """FPN top-down add: conv1x1(x) + nearest_up2(residual) with the upsampling folded into the residual read (fpn.py:34,90-96)."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    r = torch.randn(N, Cout, H // 2, W // 2, device='cuda')
+    wp, ldw = ops.pack_conv_weight(w)
+    out = ops.conv2d_nhwc(x, wp, ldw, b, Cout, 1, 1, 0, residual=r, residual_up=True)
+    mat = ops.conv2d_nhwc(x, wp, ldw, b, Cout, 1, 1, 0, residual=F.interpolate(r, scale_factor=2, mode='nearest'))
+    assert torch.equal(out, mat)   # same kernel, same operands: identical bits
+    ref = F.conv2d(x.double(), w.double(), b.double()) + F.interpolate(r, scale_factor=2, mode='nearest').double()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x, wp, ldw, b, Cout, 1, 1, 0, residual=r)   # shape mismatch without residual_up

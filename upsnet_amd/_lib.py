@@ -23,7 +23,7 @@ _SIGNATURES = {
     "upsnet_deform_im2col": (c_int, [P, P, P] + [c_int] * 13 + [P]),
     "upsnet_mod_deform_im2col": (c_int, [P, P, P, P] + [c_int] * 15 + [P]),
     "upsnet_deform_conv_forward_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 11 + [P, c_int, P, c_int]),
-    "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_tuning": (None, [c_int, c_int]),
     "upsnet_conv_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "upsnet_nms_host": (c_int, [P, P, P, c_int, c_int, c_float, c_int]),

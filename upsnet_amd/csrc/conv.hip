@@ -39,6 +39,7 @@ struct ConvParams {
     ConvSeg seg[CV_MAXSEG];
     const float *w, *bias;
     int nseg, Cin, Cout, ldw, KH, KW, stride, pad, dil, relu;
+    int res_up;  // residual is at half resolution and added through a nearest x2 upsampling (FPN top-down path)
     int m_tiles, n_tiles;
 };
 
@@ -113,7 +114,7 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
 //   steps KS-6..  registers of slab s+1 -> the other LDS buffer, one pixel (or the B slab) per step
 //   step KS-2     barrier (all fragment reads of this buffer are complete, all stashes visible)
 //   step KS-1     fragment reads of step 0 of slab s+1 from the other buffer
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK, int RESUP>
 __global__ void __launch_bounds__(256, (WM * WN <= 2 && BK == 32) ? 3 : 1)
 conv_igemm_f32_kernel(const ConvParams p)
 {
@@ -372,7 +373,11 @@ conv_igemm_f32_kernel(const ConvParams p)
 
     // ---- fused epilogue: + bias, + residual, ReLU. Residual values are loaded 16 at a time, unconditionally
     // (clamped row), before any of them is used, so the loads overlap instead of serialising.
+    // res_up: the residual lives at half resolution and is read through a nearest x2 upsampling
+    // (F.interpolate(scale_factor=2, mode='nearest') of the FPN top-down path, fpn.py:34,90-96): src = (h >> 1, w >> 1).
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
+    constexpr bool res_up = RESUP != 0;
+    const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int co = n0 + wn * (WN * 32) + 32 * j + aij;
@@ -383,12 +388,38 @@ conv_igemm_f32_kernel(const ConvParams p)
         for (int i = 0; i < WM; ++i) {
             const long pbase = p0 + wm * (WM * 32) + 32 * i + 4 * akr;
             float rr[16];
-            if (has_res) {
+            if (has_res && !res_up) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     long pp = pbase + (r & 3) + 8 * (r >> 2);
                     pp = pp < sg.M ? pp : sg.M - 1;
                     rr[r] = sg.res[pp * p.Cout + coc];
+                }
+            } else if (has_res) {
+                // one division for the first row of this thread; the other 15 rows (offsets <= 27) are reached by
+                // increments with at most one line / image wrap when Wo >= 32 (otherwise divide per row)
+                const long pb = pbase < sg.M ? pbase : sg.M - 1;
+                const int n_b = (int)(pb / HoWo);
+                const int rem_b = (int)(pb - (long)n_b * HoWo);
+                const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+                const bool fast = sg.Wo >= 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    int n = n_b, h = h_b, w = w_b;
+                    if (pbase + off < sg.M) {
+                        if (fast) {
+                            w += off;
+                            if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                            if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+                        } else {
+                            const long pp = pbase + off;
+                            n = (int)(pp / HoWo);
+                            const int rem = (int)(pp - (long)n * HoWo);
+                            h = rem / sg.Wo; w = rem - h * sg.Wo;
+                        }
+                    }
+                    rr[r] = sg.res[(((long)n * Hr + (h >> 1)) * Wr + (w >> 1)) * p.Cout + coc];
                 }
             }
 #pragma unroll
@@ -404,7 +435,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK = CV_BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK = CV_BK, int RESUP = 0>
 static int conv_launch(hipStream_t st, ConvParams &p)
 {
     constexpr int BN = WAVES_N * WN * 32, BM = WAVES_M * WM * 32;
@@ -416,12 +447,12 @@ static int conv_launch(hipStream_t st, ConvParams &p)
     const size_t smem = (size_t)(2 * BK * (BM + 1) + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_set && smem > 64 * 1024) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK>),
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK, RESUP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;  // see the XCD-aware tile order in the kernel
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK, RESUP>), dim3(grid), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("conv_igemm_f32_kernel");
     return 0;
 }
@@ -447,6 +478,10 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
     if ((tile == 2 || tile == 5) && !n64) tile = 3;
     if (tile == 4 && !n128) tile = n64 ? 5 : 3;
     if (tile == 6 && (!n64 || p.Cin % 64 != 0)) tile = n64 ? 5 : 3;
+    if (p.res_up) {  // nearest-upsampled residual (FPN top-down add): separate instances, dense only
+        UPS_REQUIRE(!DEFORM, "conv: residual_up is not available for deformable convolution");
+        return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 1>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 1>(st, p);
+    }
     switch (tile) {
     case 1: return conv_launch<2, 2, 2, 2, DEFORM>(st, p);      // 128 x 128
     case 2: return conv_launch<1, 2, 4, 1, DEFORM>(st, p);      // 128 x 64
@@ -469,7 +504,7 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
     UPS_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0 && dil >= 1, "%s: bad kernel/stride/pad/dilation", who);
     UPS_REQUIRE((long)KH * KW * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
     p.w = wpack; p.bias = bias; p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw; p.KH = KH; p.KW = KW;
-    p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu;
+    p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu; p.res_up = 0;
     int tiles = 0;
     for (int i = 0; i < CV_MAXSEG; ++i) {
         ConvSeg &s = p.seg[i];
@@ -497,12 +532,18 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
 extern "C" int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
                                       float *const out[], const int batch[], const int height[], const int width[], int Cin,
                                       const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride,
-                                      int pad, int relu)
+                                      int pad, int relu, int residual_up)
 {
     ConvParams p;
     int rc = conv_fill(p, "conv2d_nhwc_f32", nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout, wpack, ldw,
                        bias, KH, KW, stride, pad, 1, relu);
     if (rc) return rc;
+    if (residual_up) {
+        UPS_REQUIRE(residual, "conv2d_nhwc_f32: residual_up without a residual");
+        for (int i = 0; i < nseg; ++i)
+            UPS_REQUIRE(p.seg[i].Ho % 2 == 0 && p.seg[i].Wo % 2 == 0, "conv2d_nhwc_f32: residual_up needs even output dims (map %d: %dx%d)", i, p.seg[i].Ho, p.seg[i].Wo);
+        p.res_up = 1;
+    }
     return conv_dispatch<0>((hipStream_t)stream, p);
 }
 

@@ -49,9 +49,15 @@ class FPN(nn.Module):
             gap = self.fpn_gap(F.adaptive_avg_pool2d(res5, (1, 1)).flatten(1)).view(-1, self.feature_dim, 1, 1)
             p5_1x1 = p5_1x1 + gap
         # top-down pathway: the lateral 1x1 and the "+ upsampled" add are one kernel (residual epilogue)
-        p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=self.fpn_upsample(p5_1x1))
-        p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=self.fpn_upsample(p4_plus))
-        p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=self.fpn_upsample(p3_plus))
+        # (and for nearest upsampling the x2 upsample is folded into the residual read: nothing is materialised)
+        if self.upsample_method == 'nearest' and all(t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0 for t in (res2, res3, res4)):
+            p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=p5_1x1, residual_up=True)
+            p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=p4_plus, residual_up=True)
+            p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=p3_plus, residual_up=True)
+        else:
+            p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=self.fpn_upsample(p5_1x1))
+            p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=self.fpn_upsample(p4_plus))
+            p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=self.fpn_upsample(p3_plus))
         p5 = hipconv.conv(self.fpn_p5, p5_1x1)
         p4 = hipconv.conv(self.fpn_p4, p4_plus)
         p3 = hipconv.conv(self.fpn_p3, p3_plus)

@@ -33,14 +33,15 @@ def supported(m, x):
             m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
 
 
-def conv(m, x, relu=False, residual=None):
+def conv(m, x, relu=False, residual=None, residual_up=False):
+    """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add)."""
     if supported(m, x):
         wp, ldw = _plan(m)
         return ops.conv2d_nhwc(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
-                               relu=relu, residual=residual)
+                               relu=relu, residual=residual, residual_up=residual_up)
     y = m(x)
     if residual is not None:
-        y = y + residual
+        y = y + (F.interpolate(residual, scale_factor=2, mode='nearest') if residual_up else residual)
     return F.relu(y, inplace=True) if relu else y
 
 

@@ -90,7 +90,8 @@ class resnet_upsnet(resnet_rcnn):
 
     def _tap(self, **kw):
         if self.taps is not None:
-            self.taps.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+            self.taps.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else
+                                  [t.detach().clone() for t in v] if isinstance(v, (list, tuple)) else v) for k, v in kw.items()})
 
     def forward(self, data, label=None):
         if label is not None:
@@ -118,7 +119,7 @@ class resnet_upsnet(resnet_rcnn):
         rcnn_output = self.rcnn(feats, rois, n_rois)
         cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
         bbox_pred = rcnn_output['bbox_pred']
-        self._tap(rpn_cls_prob=[t.detach().clone() for t in rpn_cls_prob], rpn_bbox_pred=[t.detach().clone() for t in rpn_bbox_pred],
+        self._tap(rpn_cls_prob=rpn_cls_prob, rpn_bbox_pred=rpn_bbox_pred,
                   im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
         if fuse_up:
             self._tap(fcn_score=fcn_score)
@@ -181,7 +182,7 @@ class resnet_upsnet(resnet_rcnn):
         rcnn_output = self.rcnn(feats, rois)
         cls_score, bbox_pred = rcnn_output['cls_score'], rcnn_output['bbox_pred']
         cls_prob = F.softmax(cls_score, dim=1)
-        self._tap(rpn_cls_prob=[t.detach().clone() for t in rpn_cls_prob], rpn_bbox_pred=[t.detach().clone() for t in rpn_bbox_pred],
+        self._tap(rpn_cls_prob=rpn_cls_prob, rpn_bbox_pred=rpn_bbox_pred,
                   im_info=im_info, rois=rois, n_rois=rois.shape[0], cls_prob=cls_prob, bbox_pred=bbox_pred,
                   fcn_output=fcn_output['fcn_output'])
 

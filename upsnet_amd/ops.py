@@ -357,9 +357,10 @@ def pack_conv_weight(weight):
     return wp, ldw
 
 
-def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None):
+def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None, residual_up=False):
     """Up to 5 logical-NCHW tensors through the SAME convolution in one launch; returns channels_last outputs.
-    out_i = relu?(conv(x_i) + bias + residual_i)."""
+    out_i = relu?(conv(x_i) + bias + residual_i); residual_up: residual_i is at half resolution and is added through
+    a nearest x2 upsampling (FPN top-down path)."""
     require_cuda(wpack, *xs)
     assert 1 <= len(xs) <= 5
     xs = [nhwc(x.float()) for x in xs]
@@ -373,8 +374,9 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
     if residuals is not None:
         ress = [nhwc(r.float()) for r in residuals]
         for r, o in zip(ress, outs):
-            if tuple(r.shape) != tuple(o.shape):
-                raise RuntimeError("conv2d_nhwc: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+            want = (o.shape[0], o.shape[1], o.shape[2] // 2, o.shape[3] // 2) if residual_up else tuple(o.shape)
+            if tuple(r.shape) != want or (residual_up and (o.shape[2] % 2 or o.shape[3] % 2)):
+                raise RuntimeError("conv2d_nhwc: residual shape %s != %s" % (tuple(r.shape), want))
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -382,7 +384,7 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
                                        ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
                                        int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
                                        ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride),
-                                       int(pad), int(bool(relu))), "conv2d_nhwc_f32")
+                                       int(pad), int(bool(relu)), int(bool(residual_up and ress is not None))), "conv2d_nhwc_f32")
     if PROFILE['enabled']:
         ev1.record()
         npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
@@ -392,10 +394,11 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
     return outs
 
 
-def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residual=None):
+def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residual=None, residual_up=False):
     """x: logical NCHW tensor (any batch); returns a channels_last [N,Cout,Ho,Wo] tensor.
     out = relu?(conv(x) + bias + residual) in one kernel."""
-    return conv2d_nhwc_multi([x], wpack, ldw, bias, cout, ksize, stride, pad, relu, None if residual is None else [residual])[0]
+    return conv2d_nhwc_multi([x], wpack, ldw, bias, cout, ksize, stride, pad, relu, None if residual is None else [residual],
+                             residual_up)[0]
 
 
 def fcn_score_combine(parts, bias=None):
