@@ -13,6 +13,8 @@ Two execution styles produce identical results:
     MaskRemoval -> SegTerm -> cat/argmax) through the drop-in modules, materialising what the
     reference materialises. Used by the parity tests.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -30,11 +32,16 @@ from .resnet import ResNetBackbone, fold_frozen_bn, resnet_rcnn
 from .rpn import RPN, rpn_forward_levels
 
 
+_SIDE = {}  # device index -> (side stream, fork event, join event)
+
 class resnet_upsnet(resnet_rcnn):
 
     def __init__(self, backbone_depth, pipeline='fused'):
         super(resnet_upsnet, self).__init__()
         self.pipeline = pipeline
+        # semantic head on a side stream, concurrent with the detection chain (a CU-masked side stream that keeps a few CUs
+        # free for the latency-bound kernels was measured too: 66-75 img/s vs 80-81, so it is an ordinary stream)
+        self.overlap_streams = os.environ.get('UPSNET_OVERLAP', '1') != '0'
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
         self.num_classes = config.dataset.num_classes
         self.num_seg_classes = config.dataset.num_seg_classes
@@ -79,14 +86,25 @@ class resnet_upsnet(resnet_rcnn):
         return self
 
     # ------------------------------------------------------------------ shared trunk
-    def _trunk(self, data):
+    def _pyramid(self, data):
         x = data['data']
         if getattr(self, '_channels_last', False):
             x = x.contiguous(memory_format=torch.channels_last)
         res2, res3, res4, res5 = self.resnet_backbone(x)
-        pyramid = self.fpn(res2, res3, res4, res5)
+        return self.fpn(res2, res3, res4, res5)
+
+    def _trunk(self, data):
+        pyramid = self._pyramid(data)
         _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
         return pyramid, rpn_cls_prob, rpn_bbox_pred
+
+    def _side_stream(self):
+        """(side stream, fork event, join event) of the current device; kept outside the module so that the model stays
+        deep-copyable / picklable."""
+        dev = torch.cuda.current_device()
+        if dev not in _SIDE:
+            _SIDE[dev] = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+        return _SIDE[dev]
 
     def _tap(self, **kw):
         if self.taps is not None:
@@ -102,30 +120,38 @@ class resnet_upsnet(resnet_rcnn):
 
     # ------------------------------------------------------------------ MI355X pipeline
     def _forward_fused(self, data):
-        pyramid, rpn_cls_prob, rpn_bbox_pred = self._trunk(data)
+        pyramid = self._pyramid(data)
         feats = list(pyramid[:4])
         im_info = data['im_info']
-        rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
         # x4 upsampling of the semantic logits is fused into the panoptic kernel (enable_void branch, rate 4)
         fuse_up = self.enable_void and self.fcn_head.upsample_rate == 4
-        if fuse_up:
-            fcn_score = self.fcn_head.forward_score(*feats)
-            fcn_output = None
-            H, W = fcn_score.shape[2] * 4, fcn_score.shape[3] * 4
-        else:
-            fcn_output = self.fcn_head(*feats)['fcn_output']
-            H, W = fcn_output.shape[2:]
+        # The semantic head (offset convs + deformable convs, ~2 ms of MFMA-bound work) depends only on the FPN outputs, not on
+        # the RPN / proposal / detection chain (which contains a dozen latency-bound single-workgroup kernels): it is issued on
+        # a side stream right after the FPN so the two overlap on the GPU; the main stream joins it before the panoptic fusion.
+        main = torch.cuda.current_stream()
+        side, ev_fork, ev_join = self._side_stream() if self.overlap_streams else (main, None, None)
+        if side is not main:
+            ev_fork.record(main)
+            side.wait_event(ev_fork)
+        with torch.cuda.stream(side):
+            if fuse_up:
+                fcn_score = self.fcn_head.forward_score(*feats)
+                fcn_output = None
+                H, W = fcn_score.shape[2] * 4, fcn_score.shape[3] * 4
+            else:
+                fcn_output = self.fcn_head(*feats)['fcn_output']
+                H, W = fcn_output.shape[2:]
+            if side is not main:
+                ev_join.record(side)
+                (fcn_score if fuse_up else fcn_output).record_stream(main)
 
+        _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
+        rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
         rcnn_output = self.rcnn(feats, rois, n_rois)
         cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
         bbox_pred = rcnn_output['bbox_pred']
         self._tap(rpn_cls_prob=rpn_cls_prob, rpn_bbox_pred=rpn_bbox_pred,
                   im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
-        if fuse_up:
-            self._tap(fcn_score=fcn_score)
-        else:
-            self._tap(fcn_output=fcn_output)
-
         # both detection selections are launched back to back; ONE host read of the two counters
         det_boxes, det_scores, det_cls, _, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
         pan_boxes, pan_scores, pan_cls, _, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
@@ -144,6 +170,12 @@ class resnet_upsnet(resnet_rcnn):
         keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
         cmap = self.seg_term.class_map.to(pan_boxes.device)
+        if side is not main:
+            main.wait_event(ev_join)
+        if fuse_up:
+            self._tap(fcn_score=fcn_score)
+        else:
+            self._tap(fcn_output=fcn_output)
         if n_pan > 256:  # beyond the fused kernels' instance table: reference-shaped materialising path
             if fcn_output is None:
                 fcn_output = F.interpolate(fcn_score, None, 4, mode='bilinear', align_corners=False)
