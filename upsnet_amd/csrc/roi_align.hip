@@ -46,6 +46,52 @@ __device__ static inline float roi_blend(const RoiTap &t, float v1, float v2, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// NHWC bin evaluation for sampling_ratio == 2 (the only value the reference uses, functions/roialign.py:22): the four
+// sample descriptors are set up first and all 16 corner vectors of a channel group are loaded UNCONDITIONALLY (clamped
+// addresses; samples outside the map are deselected afterwards), so the 16 loads of a wave are in flight together instead
+// of four dependent round trips. Summation order and arithmetic are the reference's (roi_align_kernel.cu:199-231).
+__device__ static inline void roi_bin_nhwc_g2(const float4 *__restrict__ feat, const int c4n, const int height, const int width,
+                                              const float roi_start_h, const float roi_start_w, const float bin_size_h,
+                                              const float bin_size_w, const int ph, const int pw, const int lane,
+                                              float4 *__restrict__ o4)
+{
+    RoiTap t0, t1, t2, t3;
+    const float y0 = roi_start_h + (float)ph * bin_size_h + (0.f + .5f) * bin_size_h / 2.0f;
+    const float y1 = roi_start_h + (float)ph * bin_size_h + (1.f + .5f) * bin_size_h / 2.0f;
+    const float x0 = roi_start_w + (float)pw * bin_size_w + (0.f + .5f) * bin_size_w / 2.0f;
+    const float x1 = roi_start_w + (float)pw * bin_size_w + (1.f + .5f) * bin_size_w / 2.0f;
+    t0.y_low = t0.y_high = t0.x_low = t0.x_high = 0; t1 = t0; t2 = t0; t3 = t0;
+    const bool k0 = roi_tap(height, width, y0, x0, t0), k1 = roi_tap(height, width, y0, x1, t1);
+    const bool k2 = roi_tap(height, width, y1, x0, t2), k3 = roi_tap(height, width, y1, x1, t3);
+#define RB_OFF(T, YY, XX) ((unsigned)((T.YY * width + T.XX) * c4n))
+    const unsigned a0 = RB_OFF(t0, y_low, x_low), a1 = RB_OFF(t0, y_low, x_high), a2 = RB_OFF(t0, y_high, x_low), a3 = RB_OFF(t0, y_high, x_high);
+    const unsigned b0 = RB_OFF(t1, y_low, x_low), b1 = RB_OFF(t1, y_low, x_high), b2 = RB_OFF(t1, y_high, x_low), b3 = RB_OFF(t1, y_high, x_high);
+    const unsigned c0 = RB_OFF(t2, y_low, x_low), c1 = RB_OFF(t2, y_low, x_high), c2 = RB_OFF(t2, y_high, x_low), c3 = RB_OFF(t2, y_high, x_high);
+    const unsigned d0 = RB_OFF(t3, y_low, x_low), d1 = RB_OFF(t3, y_low, x_high), d2 = RB_OFF(t3, y_high, x_low), d3 = RB_OFF(t3, y_high, x_high);
+#undef RB_OFF
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+        const float4 *f = feat + c4;
+        const float4 va0 = f[a0], va1 = f[a1], va2 = f[a2], va3 = f[a3];
+        const float4 vb0 = f[b0], vb1 = f[b1], vb2 = f[b2], vb3 = f[b3];
+        const float4 vc0 = f[c0], vc1 = f[c1], vc2 = f[c2], vc3 = f[c3];
+        const float4 vd0 = f[d0], vd1 = f[d1], vd2 = f[d2], vd3 = f[d3];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#define RB_ACC(K, T, V0, V1, V2, V3)                                      \
+        acc.x += K ? roi_blend(T, V0.x, V1.x, V2.x, V3.x) : 0.f;         \
+        acc.y += K ? roi_blend(T, V0.y, V1.y, V2.y, V3.y) : 0.f;         \
+        acc.z += K ? roi_blend(T, V0.z, V1.z, V2.z, V3.z) : 0.f;         \
+        acc.w += K ? roi_blend(T, V0.w, V1.w, V2.w, V3.w) : 0.f;
+        RB_ACC(k0, t0, va0, va1, va2, va3)
+        RB_ACC(k1, t1, vb0, vb1, vb2, vb3)
+        RB_ACC(k2, t2, vc0, vc1, vc2, vc3)
+        RB_ACC(k3, t3, vd0, vd1, vd2, vd3)
+#undef RB_ACC
+        acc.x /= 4.0f; acc.y /= 4.0f; acc.z /= 4.0f; acc.w /= 4.0f;
+        o4[c4] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NCHW drop-in: one thread per output element (n, c, ph, pw), pw fastest.
 __global__ void __launch_bounds__(256)
 roi_align_nchw_kernel(const long nthreads, const float *__restrict__ feat, const float spatial_scale,
@@ -159,6 +205,10 @@ fpn_roi_align_nhwc_kernel(const FpnFeat ft, const int channels, const float *__r
     const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
     const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
     const float count = (float)(grid_h * grid_w);
+    if (sampling_ratio == 2 && (long)height * width * c4n < (1L << 31)) {
+        roi_bin_nhwc_g2(feat, c4n, height, width, roi_start_h, roi_start_w, bin_size_h, bin_size_w, ph, pw, lane, o4);
+        return;
+    }
 
     for (int c4 = lane; c4 < c4n; c4 += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -234,6 +284,10 @@ roi_align_nhwc_kernel(const float *__restrict__ feat_, const int channels, const
     const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
     const float count = (float)(grid_h * grid_w);
     float4 *o4 = reinterpret_cast<float4 *>(out + bin * channels);
+    if (sampling_ratio == 2 && (long)height * width * c4n < (1L << 31)) {
+        roi_bin_nhwc_g2(feat, c4n, height, width, roi_start_h, roi_start_w, bin_size_h, bin_size_w, ph, pw, lane, o4);
+        return;
+    }
     for (int c4 = lane; c4 < c4n; c4 += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int iy = 0; iy < grid_h; ++iy) {

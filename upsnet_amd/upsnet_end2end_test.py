@@ -115,7 +115,7 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
             net_timer.toc()
             outs.append((i, out['panoptic_outputs'][0].to(torch.uint8), int(out['panoptic_cls_inds'].numel())))
             if on_step is not None:
-                on_step(s, out)
+                on_step(s, out, model)
         results = gather_results(outs, world, device) if gather else None
         torch.cuda.synchronize(device)
         if world > 1:
