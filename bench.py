@@ -157,8 +157,8 @@ def main():
         'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
-                   'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip), NHWC, frozen BN folded, bias/residual/ReLU fused; '
-                                  '7x7 stem + 2x2 deconv + FC GEMMs on PyTorch-ROCm',
+                   'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip) for every convolution incl. the 7x7 stem and the 2x2 '
+                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; max-pool + FC GEMMs on PyTorch-ROCm',
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank, final RCCL all_gather',

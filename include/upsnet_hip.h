@@ -91,6 +91,20 @@ int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const float *const x
                                     int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
                                     const float *wpack, int ldw, const float *bias, int relu);
 
+/* ============================== Input blob (the step before the path) ============================== */
+
+/* BaseDataset.prep_im_for_blob + im_list_to_blob (upsnet/dataset/base_dataset.py:143-173,898-923) in one kernel:
+ * image_hwc uint8 [height,width,3] (BGR) -> float32, minus pixel_means (in double, like numpy's float32 -= float64),
+ * bilinear resize by im_scale (cv2.resize INTER_LINEAR semantics; identity for im_scale == 1), zero padded to
+ * [padded_h, padded_w]. resized_h/w = cvRound(height*im_scale) etc. are computed by the caller (host mirror:
+ * upsnet_amd/dataset/blob.py). nhwc4 == 0: blob is planar [3,padded_h,padded_w] (the reference's layout);
+ * nhwc4 != 0: blob is [padded_h,padded_w,4] with a zero 4th channel (input of upsnet_conv2d_stem_nhwc4_f32). */
+int upsnet_prep_image_u8(void *stream, const unsigned char *image_hwc, int height, int width, const double pixel_means[3],
+                         double im_scale, int resized_h, int resized_w, int padded_h, int padded_w, int nhwc4, float *blob);
+
+/* Layout plumbing: fp32 [N,C<=4,H,W] planar -> [N,H,W,4] (missing channels zero). */
+int upsnet_image_to_nhwc4(void *stream, const float *nchw, int batch, int channels, int height, int width, float *nhwc4);
+
 /* ============================== Dense convolution ============================== */
 
 /* Replaces nn.Conv2d (+ folded frozen BatchNorm + bias + residual add + ReLU) of the backbone / FPN / RPN / heads
@@ -105,6 +119,23 @@ int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const
                            float *const out[], const int batch[], const int height[], const int width[], int Cin,
                            const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
                            int relu, int residual_up);
+
+/* 7x7/2 stem (upsnet/models/resnet.py:347-356, conv1 + frozen BN + ReLU): Cin <= 4 input given as NHWC with 4 channels
+ * (x [N,H,W,4], 4th channel ignored by zero weights; see upsnet_image_to_nhwc4 / upsnet_prep_image_u8). One K slab of the
+ * implicit GEMM is one kernel row: 8 consecutive pixels x 4 channels. wpack [KH*32, ldw] from upsnet_conv_pack_weight_stem
+ * (weight [Cout,Cin,KH,KW], KW <= 8); out [N,Ho,Wo,Cout] NHWC; bias/ReLU fused. */
+int upsnet_conv2d_stem_nhwc4_f32(void *stream, const float *x, int batch, int height, int width, const float *wpack,
+                                 int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad, int relu,
+                                 float *out);
+int upsnet_conv_pack_weight_stem(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);
+
+/* nn.ConvTranspose2d(Cin, Cout, 2, 2, 0) (+ bias + ReLU) of the mask head (upsnet/models/rcnn.py:60,84) as ONE GEMM with
+ * 4*Cout columns (dy, dx, co) whose epilogue stores column (dy,dx,co) of input pixel (h,w) at output pixel (2h+dy, 2w+dx):
+ * x [N,H,W,Cin] NHWC -> out [N,2H,2W,Cout] NHWC. wpack [Cin, ldw >= 4*Cout] from upsnet_deconv2x2_pack_weight
+ * (weight [Cin,Cout,2,2], the PyTorch layout). */
+int upsnet_deconv2x2_nhwc_f32(void *stream, const float *x, int batch, int height, int width, int Cin, const float *wpack,
+                              int ldw, const float *bias, int Cout, int relu, float *out);
+int upsnet_deconv2x2_pack_weight(void *stream, const float *weight, int cin, int cout, int ldw, float *wpack);
 
 /* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
  * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). `reserved` is ignored. Not needed in production. */

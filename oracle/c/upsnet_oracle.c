@@ -469,3 +469,48 @@ void orc_fcn_score_combine(const float *const *part, int nlev, int S, int H, int
                 out[idx] = acc;
             }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Input blob: BaseDataset.prep_im_for_blob + im_list_to_blob (upsnet/dataset/base_dataset.py:143-173, 898-923).
+ *   im uint8 [H,W,3] -> float32; im -= pixel_means (a float64 array: numpy computes float32 - float64 in double and rounds
+ *   the result to float32); cv2.resize(im, None, None, fx=s, fy=s, INTER_LINEAR) with dsize = cvRound(size * s) (given by the
+ *   caller as Hr, Wr) and coordinate scale 1/s; HWC -> CHW; zero pad to [Hp, Wp]. cv2 is absent: OpenCV's published
+ *   INTER_LINEAR formula (see orc_lin_coef) -- PARITY UNPINNED for s != 1; for s == 1 it is an exact copy, which is pinned
+ *   against the reference's own Python (tests/golden/make_golden.py).
+ * out: planar [3,Hp,Wp].
+ * ---------------------------------------------------------------------------------------- */
+static void orc_lin_coef_scale(int d, double scale, int ssize, int *s0, int *s1, float *f)
+{
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+    *s0 = sx;
+    *s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
+    *f = fx;
+}
+
+void orc_prep_image(const uint8_t *im, int H, int W, const double *means, double im_scale, int Hr, int Wr, int Hp, int Wp, float *out)
+{
+    const double inv = 1.0 / im_scale;
+    memset(out, 0, sizeof(float) * 3 * (size_t)Hp * Wp);
+    for (int y = 0; y < Hr; ++y) {
+        int y0, y1; float fy;
+        orc_lin_coef_scale(y, inv, H, &y0, &y1, &fy);
+        for (int x = 0; x < Wr; ++x) {
+            int x0, x1; float fx;
+            orc_lin_coef_scale(x, inv, W, &x0, &x1, &fx);
+            const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+            for (int c = 0; c < 3; ++c) {
+                const float s00 = (float)((double)im[((size_t)y0 * W + x0) * 3 + c] - means[c]);
+                const float s01 = (float)((double)im[((size_t)y0 * W + x1) * 3 + c] - means[c]);
+                const float s10 = (float)((double)im[((size_t)y1 * W + x0) * 3 + c] - means[c]);
+                const float s11 = (float)((double)im[((size_t)y1 * W + x1) * 3 + c] - means[c]);
+                const float r0 = s00 * a0 + s01 * a1;
+                const float r1 = s10 * a0 + s11 * a1;
+                out[((size_t)c * Hp + y) * Wp + x] = r0 * b0 + r1 * b1;
+            }
+        }
+    }
+}

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Golden vectors for the input blob made by the REFERENCE's own Python:
+BaseDataset.prep_im_for_blob + im_list_to_blob (upsnet/dataset/base_dataset.py:143-173, 898-923), imported from
+/root/reference with the in-process shims of make_golden.py plus stand-ins for pycocotools / the logger.
+
+cv2 does not exist here, so only im_scale == 1 (the Cityscapes test setting: scales=[1024], max_size=2048) can be pinned this
+way -- for fx = fy = 1 cv2.resize is the identity and the shim returns the image unchanged; what the fixture pins is the
+float32 - float64 mean subtraction, HWC -> CHW and the zero padding to a multiple of 32. Scaled inputs stay parity-unpinned
+(oracle restates OpenCV's INTER_LINEAR formula).
+
+Run in the build container:  python tests/golden/make_golden_blob.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (installs the shims, puts /root/reference on sys.path)
+
+
+def _resize(src, dsize=None, dst=None, fx=0, fy=0, interpolation=1):
+    assert dsize is None and fx == 1.0 and fy == 1.0, "only the identity resize can be produced without cv2"
+    return src
+
+
+sys.modules['cv2'].resize = _resize
+sys.modules['cv2'].INTER_LINEAR = 1
+sys.modules['cv2'].INTER_NEAREST = 0
+for name in ('pycocotools', 'pycocotools.cocoeval', 'pycocotools.mask', 'pycocotools.coco'):
+    m = types.ModuleType(name)
+    m.COCOeval = object
+    m.COCO = object
+    sys.modules[name] = m
+lg = types.ModuleType('lib.utils.logging')
+lg.logger = types.SimpleNamespace(info=print, warning=print, error=print)
+sys.modules.setdefault('lib', types.ModuleType('lib'))
+sys.modules.setdefault('lib.utils', types.ModuleType('lib.utils'))
+sys.modules['lib.utils.logging'] = lg
+for name, attrs in (('upsnet.rpn.anchors', dict(anchors_cython=None)), ('upsnet.bbox.sample_rois', dict(sample_rois=None, compute_mask_rcnn_bg_targets=None)),
+                    ('upsnet.rpn.assign_anchor', dict(add_rpn_blobs=None))):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+import collections  # noqa: E402
+import collections.abc  # noqa: E402
+collections.Sequence = collections.abc.Sequence
+
+from upsnet.config.config import config  # noqa: E402
+from upsnet.dataset.base_dataset import BaseDataset  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(7)
+    config.network.use_caffe_model = True
+    config.network.has_fpn = True
+    config.network.rpn_feat_stride = [4, 8, 16, 32, 64]
+    pixel_means = np.array((102.9801, 115.9465, 122.7717,))
+    out = {}
+    for tag, (H, W, target, max_size) in {'even': (64, 128, 64, 128), 'ragged': (50, 75, 50, 100)}.items():
+        im = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        ims, scales = BaseDataset.prep_im_for_blob(None, im.copy(), pixel_means, [target], max_size)
+        assert scales == [1.0]
+        blob = BaseDataset.im_list_to_blob(None, [ims[0].transpose(2, 0, 1)])
+        out[tag + '_im'] = im
+        out[tag + '_blob'] = blob
+        out[tag + '_cfg'] = np.array([target, max_size], np.int64)
+    path = os.path.join(HERE, 'input_blob.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

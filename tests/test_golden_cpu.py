@@ -73,3 +73,16 @@ def test_panoptic_head():
     pan2, _ = oracle.panoptic_fuse(g["fcn"][0], 11, inst[0], energy[0], False)
     # argmax(softmax(x)) through torch's own softmax: allow the (rare) rounding-tie pixels, report them
     assert (pan2 != g["pan_softmax"][0]).mean() < 1e-3
+
+
+def test_input_blob_golden_from_reference_python():
+    """oracle.prep_image == BaseDataset.prep_im_for_blob + im_list_to_blob of the reference (im_scale 1: mean subtraction in
+    double, HWC->CHW, zero pad to 32), fixtures from tests/golden/make_golden_blob.py."""
+    import oracle
+    g = np.load(os.path.join(G, "input_blob.npz"))
+    means = np.array((102.9801, 115.9465, 122.7717,))
+    for tag in ("even", "ragged"):
+        target, max_size = [int(v) for v in g[tag + "_cfg"]]
+        blob, scale = oracle.prep_image(g[tag + "_im"], means, target, max_size)
+        assert scale == 1.0
+        np.testing.assert_array_equal(blob, g[tag + "_blob"])

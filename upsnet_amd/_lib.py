@@ -42,6 +42,12 @@ _SIGNATURES = {
     "upsnet_seg_term": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_int, P]),
     "upsnet_panoptic_fuse": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, P, P]),
     "upsnet_panoptic_fuse_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, P, P]),
+    "upsnet_conv2d_stem_nhwc4_f32": (c_int, [P, P, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "upsnet_conv_pack_weight_stem": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "upsnet_deconv2x2_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P]),
+    "upsnet_deconv2x2_pack_weight": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "upsnet_prep_image_u8": (c_int, [P, P, c_int, c_int, P, c_double, c_int, c_int, c_int, c_int, c_int, P]),
+    "upsnet_image_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_fcn_score_combine": (c_int, [P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
 }

@@ -39,7 +39,8 @@ struct ConvParams {
     ConvSeg seg[CV_MAXSEG];
     const float *w, *bias;
     int nseg, Cin, Cout, ldw, KH, KW, stride, pad, dil, relu;
-    int res_up;  // residual is at half resolution and added through a nearest x2 upsampling (FPN top-down path)
+    int res_up;  // epilogue mode: 1 = residual at half resolution, added through a nearest x2 upsampling (FPN top-down
+                 // path); 2 = 2x2 / stride-2 transposed-convolution scatter
     int m_tiles, n_tiles;
 };
 
@@ -104,7 +105,11 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
 
 // WM x WN = 32x32 tiles per wave, waves arranged WAVES_M x WAVES_N (4 waves): BM = 32*WM*WAVES_M (128 or 64) output
 // pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup. BK = input channels per K slab (32 / 64).
-// DEFORM: 0 dense, 1 deformable v1, 2 deformable v2 (modulated).
+// DEFORM (A-operand loader): 0 dense, 1 deformable v1, 2 deformable v2 (modulated), 3 stem: the input is an NHWC image with
+// 4 channels (RGB + zero) and a K slab is one kernel ROW -- 8 consecutive input pixels x 4 channels = 32 contiguous floats --
+// so the 7x7/2 stem (Cin = 3) runs on the same MFMA pipeline with K = 7 x 32 instead of a 10x zero-padded K.
+// RESUP (epilogue): 0 plain, 1 residual read through a nearest x2 upsampling, 2 deconvolution scatter: the GEMM columns are
+// (dy, dx, co) of a 2x2 / stride-2 transposed convolution and each result is stored at output pixel (2h+dy, 2w+dx).
 //
 // Schedule of one slab (KS = BK/2 MFMA steps per 32x32 tile), pinned with sched_barrier because a wave that runs
 // alone on its SIMD (small feature maps) only keeps the MFMA pipe busy if everything else sits in the shadow of an MFMA:
@@ -132,6 +137,8 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr int BROWS = 256 / (BN / 4);      // B slab rows covered by one pass of the 256 threads
     static_assert(B_F4 >= 1 && B_F4 <= 4, "B staging");
     constexpr bool MOD = DEFORM == 2;
+    constexpr bool DEF = DEFORM == 1 || DEFORM == 2;
+    constexpr bool STEM = DEFORM == 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *As = reinterpret_cast<float *>(smem_raw);     // [2][BK][LDA]
     float *Bs = As + 2 * BK * LDA;                       // [2][BK][BN]
@@ -208,10 +215,11 @@ conv_igemm_f32_kernel(const ConvParams p)
 #define CV_LDX(O) (*reinterpret_cast<const float4 *>(xbase + (O)))
 #define CV_TAP_DENSE(R)                                                                                               \
     {                                                                                                                 \
-        const int hi = pix_h[R] + f_ki * p.dil, wi = pix_w[R] + f_kj * p.dil;                                         \
+        const int hi = pix_h[R] + f_ki * p.dil, wi = pix_w[R] + (STEM ? ch4 : f_kj * p.dil);                          \
         cv##R = pix_n[R] >= 0 && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;                                        \
         const int hc = min(max(hi, 0), sg.H - 1), wc = min(max(wi, 0), sg.W - 1), nc = max(pix_n[R], 0);             \
-        oa##R = 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + 4 * ch4);                                    \
+        oa##R = STEM ? 16u * (unsigned)((nc * sg.H + hc) * sg.W + wc)                                                 \
+                     : 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + 4 * ch4);                             \
     }
 #define CV_TAP_DEFORM(R)                                                                                              \
     d##R = dcn_desc(sg, pix_p[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, f_tap, ntap,                      \
@@ -319,7 +327,7 @@ conv_igemm_f32_kernel(const ConvParams p)
         }                                                                                                             \
     }
 
-    if (DEFORM) {
+    if (DEF) {
         CV_FETCH(c)
         CV_STASH_A(c, 0, 0) CV_STASH_A(c, 0, 1)
         if (PXT > 2) { CV_STASH_A(c, 0, 2) CV_STASH_A(c, 0, 3) }
@@ -373,53 +381,67 @@ conv_igemm_f32_kernel(const ConvParams p)
 
     // ---- fused epilogue: + bias, + residual, ReLU. Residual values are loaded 16 at a time, unconditionally
     // (clamped row), before any of them is used, so the loads overlap instead of serialising.
-    // res_up: the residual lives at half resolution and is read through a nearest x2 upsampling
-    // (F.interpolate(scale_factor=2, mode='nearest') of the FPN top-down path, fpn.py:34,90-96): src = (h >> 1, w >> 1).
+    // RESUP 1: the residual lives at half resolution and is read through a nearest x2 upsampling
+    //   (F.interpolate(scale_factor=2, mode='nearest') of the FPN top-down path, fpn.py:34,90-96): src = (h >> 1, w >> 1).
+    // RESUP 2: transposed 2x2 / stride-2 convolution (mask head, rcnn.py:60,84): column co = (dy*2+dx)*C + c of output
+    //   pixel (h, w) is channel c of output pixel (2h+dy, 2w+dx); bias is indexed by c.
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
-    constexpr bool res_up = RESUP != 0;
+    constexpr bool res_up = RESUP == 1, scatter = RESUP == 2;
     const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
+    const int Cr = p.Cout >> 2;   // scatter: real output channels
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int co = n0 + wn * (WN * 32) + 32 * j + aij;
-        const bool co_ok = co < p.Cout;
-        const int coc = co_ok ? co : 0;
-        const float bv = has_bias ? p.bias[coc] : 0.f;
+    for (int i = 0; i < WM; ++i) {
+        const long pbase = p0 + wm * (WM * 32) + 32 * i + 4 * akr;
+        // pixel coordinates of this thread's 16 rows (only for the two coordinate-dependent epilogues): one division for the
+        // first row; the other rows (offsets <= 27) are reached by increments with at most one line / image wrap when
+        // Wo >= 32 (otherwise divide per row)
+        long ridx[16];
+        if (RESUP != 0) {
+            const long pb = pbase < sg.M ? pbase : sg.M - 1;
+            const int n_b = (int)(pb / HoWo);
+            const int rem_b = (int)(pb - (long)n_b * HoWo);
+            const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+            const bool fast = sg.Wo >= 32;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const long pbase = p0 + wm * (WM * 32) + 32 * i + 4 * akr;
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                int n = n_b, h = h_b, w = w_b;
+                if (pbase + off < sg.M) {
+                    if (fast) {
+                        w += off;
+                        if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                        if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+                    } else {
+                        const long pp = pbase + off;
+                        n = (int)(pp / HoWo);
+                        const int rem = (int)(pp - (long)n * HoWo);
+                        h = rem / sg.Wo; w = rem - h * sg.Wo;
+                    }
+                }
+                ridx[r] = res_up ? ((long)n * Hr + (h >> 1)) * Wr + (w >> 1)
+                                 : ((long)n * 2 * sg.Ho + 2 * h) * (2 * sg.Wo) + 2 * w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + wn * (WN * 32) + 32 * j + aij;
+            const bool co_ok = co < p.Cout;
+            const int coc = co_ok ? co : 0;
+            int cb = coc;          // bias / output channel
+            long soff = 0;         // scatter: element offset of (dy, dx) inside the 2x upsampled map
+            if (scatter) {
+                const int q = coc / Cr;
+                cb = coc - q * Cr;
+                soff = ((long)(q >> 1) * (2 * sg.Wo) + (q & 1)) * Cr + cb;
+            }
+            const float bv = has_bias ? p.bias[cb] : 0.f;
             float rr[16];
-            if (has_res && !res_up) {
+            if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     long pp = pbase + (r & 3) + 8 * (r >> 2);
                     pp = pp < sg.M ? pp : sg.M - 1;
-                    rr[r] = sg.res[pp * p.Cout + coc];
-                }
-            } else if (has_res) {
-                // one division for the first row of this thread; the other 15 rows (offsets <= 27) are reached by
-                // increments with at most one line / image wrap when Wo >= 32 (otherwise divide per row)
-                const long pb = pbase < sg.M ? pbase : sg.M - 1;
-                const int n_b = (int)(pb / HoWo);
-                const int rem_b = (int)(pb - (long)n_b * HoWo);
-                const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
-                const bool fast = sg.Wo >= 32;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    int n = n_b, h = h_b, w = w_b;
-                    if (pbase + off < sg.M) {
-                        if (fast) {
-                            w += off;
-                            if (w >= sg.Wo) { w -= sg.Wo; ++h; }
-                            if (h >= sg.Ho) { h -= sg.Ho; ++n; }
-                        } else {
-                            const long pp = pbase + off;
-                            n = (int)(pp / HoWo);
-                            const int rem = (int)(pp - (long)n * HoWo);
-                            h = rem / sg.Wo; w = rem - h * sg.Wo;
-                        }
-                    }
-                    rr[r] = sg.res[(((long)n * Hr + (h >> 1)) * Wr + (w >> 1)) * p.Cout + coc];
+                    rr[r] = sg.res[(res_up ? ridx[r] : pp) * p.Cout + coc];
                 }
             }
 #pragma unroll
@@ -429,7 +451,10 @@ conv_igemm_f32_kernel(const ConvParams p)
                 if (has_bias) v = v + bv;
                 if (has_res) v = v + rr[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+                if (co_ok && pp < sg.M) {
+                    if (scatter) sg.out[ridx[r] * Cr + soff] = v;
+                    else sg.out[pp * p.Cout + co] = v;
+                }
             }
         }
     }
@@ -478,17 +503,20 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
     if ((tile == 2 || tile == 5) && !n64) tile = 3;
     if (tile == 4 && !n128) tile = n64 ? 5 : 3;
     if (tile == 6 && (!n64 || p.Cin % 64 != 0)) tile = n64 ? 5 : 3;
-    if (p.res_up) {  // nearest-upsampled residual (FPN top-down add): separate instances, dense only
-        UPS_REQUIRE(!DEFORM, "conv: residual_up is not available for deformable convolution");
-        return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 1>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 1>(st, p);
+    if (p.res_up) {  // coordinate-dependent epilogues (FPN top-down add, deconvolution scatter): separate instances, dense only
+        UPS_REQUIRE(DEFORM == 0, "conv: this epilogue is only available for dense convolution");
+        if (p.res_up == 1) return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 1>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 1>(st, p);
+        return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 2>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 2>(st, p);
     }
+    if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
+    constexpr int D = DEFORM == 3 ? 0 : DEFORM;  // (stem returned above; keeps its instantiations to two tiles)
     switch (tile) {
-    case 1: return conv_launch<2, 2, 2, 2, DEFORM>(st, p);      // 128 x 128
-    case 2: return conv_launch<1, 2, 4, 1, DEFORM>(st, p);      // 128 x 64
-    case 4: return conv_launch<1, 2, 2, 2, DEFORM>(st, p);      // 64 x 128
-    case 5: return conv_launch<1, 1, 2, 2, DEFORM>(st, p);      // 64 x 64
-    case 6: return conv_launch<1, 1, 2, 2, DEFORM, 64>(st, p);  // 64 x 64, 64-channel K slabs
-    default: return conv_launch<1, 1, 4, 1, DEFORM>(st, p);     // 128 x 32
+    case 1: return conv_launch<2, 2, 2, 2, D>(st, p);      // 128 x 128
+    case 2: return conv_launch<1, 2, 4, 1, D>(st, p);      // 128 x 64
+    case 4: return conv_launch<1, 2, 2, 2, D>(st, p);      // 64 x 128
+    case 5: return conv_launch<1, 1, 2, 2, D>(st, p);      // 64 x 64
+    case 6: return conv_launch<1, 1, 2, 2, D, 64>(st, p);  // 64 x 64, 64-channel K slabs
+    default: return conv_launch<1, 1, 4, 1, D>(st, p);     // 128 x 32
     }
 }
 
@@ -562,6 +590,84 @@ extern "C" int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const flo
                        ldw, bias, kh, kw, stride_h, pad_h, dil_h, relu);
     if (rc) return rc;
     return mask ? conv_dispatch<2>((hipStream_t)stream, p) : conv_dispatch<1>((hipStream_t)stream, p);
+}
+
+extern "C" int upsnet_conv2d_stem_nhwc4_f32(void *stream, const float *x, int batch, int height, int width, const float *wpack,
+                                            int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad, int relu,
+                                            float *out)
+{
+    UPS_REQUIRE(KW >= 1 && KW <= 8, "conv2d_stem_nhwc4_f32: kernel width must be <= 8 (got %d)", KW);
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    // geometry from the real kernel; the K walk sees KH taps of 32 "channels" (8 pixels x 4 channels of one kernel row)
+    int rc = conv_fill(p, "conv2d_stem_nhwc4_f32", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, 32, Cout, wpack, ldw, bias, KH, KW,
+                       stride, pad, 1, relu);
+    if (rc) return rc;
+    p.KW = 1;
+    return conv_dispatch<3>((hipStream_t)stream, p);
+}
+
+extern "C" int upsnet_deconv2x2_nhwc_f32(void *stream, const float *x, int batch, int height, int width, int Cin, const float *wpack,
+                                         int ldw, const float *bias, int Cout, int relu, float *out)
+{
+    UPS_REQUIRE(Cout > 0 && ldw >= 4 * Cout, "deconv2x2_nhwc_f32: ldw must cover 4*Cout columns");
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = conv_fill(p, "deconv2x2_nhwc_f32", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, 4 * Cout, wpack, ldw, bias, 1, 1, 1, 0,
+                       1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)batch * height * width * 4 * Cout < (1L << 31), "deconv2x2_nhwc_f32: output too large");
+    p.res_up = 2;
+    return conv_dispatch<0>((hipStream_t)stream, p);
+}
+
+// stem: weight [Cout, Cin<=4, KH, KW<=8] -> wpack [(ki*32 + kj*4 + c), ldw]; deconv: weight [Cin, Cout, 2, 2] ->
+// wpack [ci, (dy*2+dx)*Cout + co]; zero padded
+__global__ void conv_pack_weight_stem_kernel(const float *__restrict__ w, int cout, int cin, int kh, int kw, int ldw, float *__restrict__ wp)
+{
+    const long total = (long)ldw * 32 * kh;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int co = idx % ldw;
+        const int k = (idx / ldw) % 32, ki = idx / ((long)ldw * 32);
+        const int kj = k >> 2, c = k & 3;
+        wp[idx] = (co < cout && c < cin && kj < kw) ? w[(((long)co * cin + c) * kh + ki) * kw + kj] : 0.f;
+    }
+}
+
+__global__ void deconv2x2_pack_weight_kernel(const float *__restrict__ w, int cin, int cout, int ldw, float *__restrict__ wp)
+{
+    const long total = (long)ldw * cin;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int col = idx % ldw, ci = idx / ldw;
+        const int q = col / cout, co = col - q * cout;
+        wp[idx] = q < 4 ? w[((long)ci * cout + co) * 4 + q] : 0.f;
+    }
+}
+
+extern "C" int upsnet_conv_pack_weight_stem(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cout > 0 && cin >= 1 && cin <= 4 && kh >= 1 && kw >= 1 && kw <= 8 && ldw >= cout && ldw % 32 == 0,
+                "conv_pack_weight_stem: bad args (Cin <= 4, KW <= 8)");
+    const long total = (long)ldw * 32 * kh;
+    hipLaunchKernelGGL(conv_pack_weight_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       cout, cin, kh, kw, ldw, wpack);
+    UPS_CHECK_LAUNCH("conv_pack_weight_stem_kernel");
+    return 0;
+}
+
+extern "C" int upsnet_deconv2x2_pack_weight(void *stream, const float *weight, int cin, int cout, int ldw, float *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cin > 0 && cout > 0 && ldw >= 4 * cout && ldw % 32 == 0, "deconv2x2_pack_weight: bad args");
+    const long total = (long)ldw * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(deconv2x2_pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cin, cout, ldw, wpack);
+    UPS_CHECK_LAUNCH("deconv2x2_pack_weight_kernel");
+    return 0;
 }
 
 // weight [Cout, Cin, kh, kw] -> wpack [(tap*Cin + c), ldw], zero padded columns

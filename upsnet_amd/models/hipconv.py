@@ -54,5 +54,44 @@ def conv_multi(m, xs, relu=False):
     return [conv(m, x, relu=relu) for x in xs]
 
 
+def stem_supported(m, x):
+    return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and m.in_channels <= 4 and
+            m.kernel_size[1] <= 8 and m.groups == 1 and tuple(m.dilation) == (1, 1) and m.stride[0] == m.stride[1] and
+            m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
+
+
+def conv_stem(m, x, relu=False):
+    """The 7x7/2 stem (Cin = 3) on the MFMA kernel: x is the fp32 NCHW blob or already a [N,4,H,W] channels_last image."""
+    if not stem_supported(m, x):
+        y = m(x[:, :m.in_channels] if x.shape[1] != m.in_channels else x)
+        return F.relu(y, inplace=True) if relu else y
+    w = m.weight
+    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
+    ent = _cache.get(('stem', id(m)))
+    if ent is None or ent[0] != key:
+        ent = (key,) + ops.pack_stem_weight(w.detach())
+        _cache[('stem', id(m))] = ent
+    is_nhwc4 = x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    x4 = x if is_nhwc4 else ops.image_to_nhwc4(x)
+    return ops.conv2d_stem(x4, ent[1], ent[2], m.bias, m.out_channels, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0], relu=relu)
+
+
+def deconv2x2(m, x, relu=False):
+    """nn.ConvTranspose2d(k=2, s=2, p=0) (+ ReLU) as one MFMA GEMM with a scatter epilogue."""
+    ok = (ENABLED and isinstance(m, nn.ConvTranspose2d) and x.is_cuda and x.dtype == torch.float32 and tuple(m.kernel_size) == (2, 2) and
+          tuple(m.stride) == (2, 2) and tuple(m.padding) == (0, 0) and tuple(m.output_padding) == (0, 0) and m.groups == 1 and
+          tuple(m.dilation) == (1, 1) and m.in_channels % 32 == 0)
+    if not ok:
+        y = m(x)
+        return F.relu(y, inplace=True) if relu else y
+    w = m.weight
+    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
+    ent = _cache.get(('deconv', id(m)))
+    if ent is None or ent[0] != key:
+        ent = (key,) + ops.pack_deconv2x2_weight(w.detach())
+        _cache[('deconv', id(m))] = ent
+    return ops.deconv2x2(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
+
+
 def clear_cache():
     _cache.clear()

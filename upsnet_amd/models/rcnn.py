@@ -40,7 +40,7 @@ class MaskBranch(nn.Module):
         x = self.roi_pooling(feat, rois)
         for blk in (self.mask_conv1, self.mask_conv2, self.mask_conv3, self.mask_conv4):
             x = hipconv.conv(blk[0], x, relu=True)
-        return hipconv.conv(self.mask_score, self.mask_deconv1(x))
+        return hipconv.conv(self.mask_score, hipconv.deconv2x2(self.mask_deconv1[0], x, relu=True))
 
 
 class RCNN(nn.Module):

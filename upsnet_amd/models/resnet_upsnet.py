@@ -25,6 +25,7 @@ from ..operators.modules.mask_removal import MaskRemoval
 from ..operators.modules.mask_roi import MaskROI
 from ..operators.modules.pyramid_proposal import PyramidProposal
 from ..operators.modules.unary_logits import SegTerm
+from . import hipconv
 from .fcn import FCNHead
 from .fpn import FPN
 from .rcnn import RCNN, MaskBranch
@@ -87,8 +88,8 @@ class resnet_upsnet(resnet_rcnn):
 
     # ------------------------------------------------------------------ shared trunk
     def _pyramid(self, data):
-        x = data['data']
-        if getattr(self, '_channels_last', False):
+        x = data['data']   # fp32 NCHW blob (the reference's layout) or a [N,4,H,W] channels_last image from the input kernel
+        if getattr(self, '_channels_last', False) and x.shape[1] != 4 and not hipconv.stem_supported(self.resnet_backbone.conv1.conv1, x):
             x = x.contiguous(memory_format=torch.channels_last)
         res2, res3, res4, res5 = self.resnet_backbone(x)
         return self.fpn(res2, res3, res4, res5)

@@ -435,3 +435,92 @@ def panoptic_fuse_up(fcn_score, scale, num_stuff, mask_rois5, mask_logit, cls_id
                                         ptr(mask_logit), ptr(cls_idx.to(torch.int64).contiguous()), ptr(keep), ptr(num), ptr(real),
                                         int(min(m, 256)), ms, ptr(class_map), ptr(pan), ptr(sem)), "panoptic_fuse_up")
     return pan, sem
+
+
+# ----------------------------------------------------------------------------- stem / deconvolution / input blob
+def pack_stem_weight(weight):
+    """[Cout,Cin<=4,KH,KW<=8] -> ([KH*32, ldw], ldw): one K slab = one kernel row of 8 pixels x 4 channels."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cout, Cin, kh, kw = weight.shape
+    ldw = (Cout + 31) // 32 * 32
+    wp = torch.empty((kh * 32, ldw), dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_conv_pack_weight_stem(stream(), ptr(weight), Cout, Cin, kh, kw, ldw, ptr(wp)), "conv_pack_weight_stem")
+    return wp, ldw
+
+
+def image_to_nhwc4(x):
+    """fp32 [N,C<=4,H,W] -> physical [N,H,W,4] (returned as a logical [N,4,H,W] channels_last tensor)."""
+    require_cuda(x)
+    x = f32c(x)
+    N, C, H, W = x.shape
+    out = _nhwc_out(N, 4, H, W, x.device)
+    check(lib().upsnet_image_to_nhwc4(stream(), ptr(x), N, C, H, W, ptr(out)), "image_to_nhwc4")
+    return out
+
+
+def conv2d_stem(x4, wpack, ldw, bias, cout, kh, kw, stride, pad, relu=False):
+    """x4: logical [N,4,H,W] channels_last (from image_to_nhwc4 / prep_image_u8). Returns channels_last [N,Cout,Ho,Wo]."""
+    require_cuda(x4, wpack)
+    x4 = nhwc(x4.float())
+    N, C, H, W = x4.shape
+    if C != 4:
+        raise RuntimeError("conv2d_stem: input must have 4 channels (RGB + zero), got %d" % C)
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = _nhwc_out(N, cout, Ho, Wo, x4.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_stem_nhwc4_f32(stream(), ptr(x4), N, H, W, ptr(wpack), int(ldw), ptr(None if bias is None else f32c(bias)),
+                                             int(cout), int(kh), int(kw), int(stride), int(pad), int(bool(relu)), ptr(out)),
+          "conv2d_stem_nhwc4_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * 3 * kh * kw * N * Ho * Wo, 4.0 * (4 * N * H * W + cout * N * Ho * Wo + cout * 3 * kh * kw)))
+    return out
+
+
+def pack_deconv2x2_weight(weight):
+    """ConvTranspose2d weight [Cin,Cout,2,2] -> ([Cin, ldw], ldw) with columns (dy,dx,co)."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cin, Cout, kh, kw = weight.shape
+    if (kh, kw) != (2, 2):
+        raise RuntimeError("pack_deconv2x2_weight: kernel must be 2x2")
+    ldw = (4 * Cout + 31) // 32 * 32
+    wp = torch.empty((Cin, ldw), dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_deconv2x2_pack_weight(stream(), ptr(weight), Cin, Cout, ldw, ptr(wp)), "deconv2x2_pack_weight")
+    return wp, ldw
+
+
+def deconv2x2(x, wpack, ldw, bias, cout, relu=False):
+    """ConvTranspose2d(k=2, s=2, p=0) (+bias, +ReLU) on a logical NCHW tensor; returns channels_last [N,Cout,2H,2W]."""
+    require_cuda(x, wpack)
+    x = nhwc(x.float())
+    N, C, H, W = x.shape
+    out = _nhwc_out(N, cout, 2 * H, 2 * W, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_deconv2x2_nhwc_f32(stream(), ptr(x), N, H, W, C, ptr(wpack), int(ldw), ptr(None if bias is None else f32c(bias)),
+                                          int(cout), int(bool(relu)), ptr(out)), "deconv2x2_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * 4 * cout * C * N * H * W, 4.0 * (C * N * H * W + 4 * cout * N * H * W + 4 * cout * C)))
+    return out
+
+
+def prep_image_u8(image_hwc, pixel_means, im_scale, resized_hw, padded_hw, nhwc4=True):
+    """uint8 [H,W,3] device image -> padded fp32 blob: logical [1,4,Hp,Wp] channels_last (nhwc4) or [1,3,Hp,Wp] NCHW."""
+    import ctypes
+    require_cuda(image_hwc)
+    if image_hwc.dtype != torch.uint8 or image_hwc.dim() != 3 or image_hwc.shape[2] != 3:
+        raise RuntimeError("prep_image_u8: expected a uint8 [H,W,3] image")
+    im = image_hwc.contiguous()
+    H, W = im.shape[:2]
+    (Hr, Wr), (Hp, Wp) = resized_hw, padded_hw
+    means = (ctypes.c_double * 3)(*[float(m) for m in pixel_means])
+    out = _nhwc_out(1, 4, Hp, Wp, im.device) if nhwc4 else torch.empty((1, 3, Hp, Wp), dtype=torch.float32, device=im.device)
+    check(lib().upsnet_prep_image_u8(stream(), ptr(im), H, W, ctypes.cast(means, ctypes.c_void_p), float(im_scale), int(Hr), int(Wr),
+                                     int(Hp), int(Wp), int(bool(nhwc4)), ptr(out)), "prep_image_u8")
+    return out

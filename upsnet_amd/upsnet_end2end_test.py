@@ -103,7 +103,7 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
             model(get(w))
         torch.cuda.synchronize(device)
         if on_warmup_done is not None:
-            on_warmup_done()
+            on_warmup_done(model)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
