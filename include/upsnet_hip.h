@@ -259,6 +259,19 @@ int upsnet_panoptic_argmax(void *stream, const float *fcn_output, int num_seg, i
                            const float *seg_inst, const float *mask_energy, int k, int enable_void,
                            int64_t *pan_out);
 
+/* ============================== Unified panoptic result (the step after the path) ============================== */
+
+/* BaseDataset.get_unified_pan_result (upsnet/dataset/base_dataset.py:332-371) for one image, on the device:
+ *   pan [H,W] int64 panoptic label map of the network (stuff ids 0..id_last_stuff, instance j -> id_last_stuff+1+j, 255 void),
+ *   seg [H,W] int64 semantic argmax map, cls_inds [num_inst] int64 (1-based thing class of instance j),
+ *   id_last_stuff = num_seg_classes - num_classes, stuff_area_limit in pixels (reference default 4*64*64).
+ * pan_2ch uint8 [H,W,3]: channel 0 = category, channel 1 = instance id (enumerate index + 1, 0 for stuff/void), channel 2 = 0.
+ * workspace: upsnet_unified_pan_workspace_bytes() bytes of device memory (zeroed by the call). */
+size_t upsnet_unified_pan_workspace_bytes(void);
+int upsnet_unified_pan_result(void *stream, const int64_t *pan, const int64_t *seg, const int64_t *cls_inds, int num_inst,
+                              int height, int width, int id_last_stuff, int num_seg_classes, int stuff_area_limit,
+                              void *workspace, unsigned char *pan_2ch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,3 +317,40 @@ def panoptic_fuse_numpy(fcn_output, seg_inst, mask_energy, s_stuff, enable_void=
     for c in range(e.shape[0]):
         s = s + e[c]
     return np.argmax(e / s, 0).astype(np.int64)
+
+
+def get_unified_pan_result(seg, pan, cls_ind, num_seg_classes, num_classes, stuff_area_limit=4 * 64 * 64):
+    """BaseDataset.get_unified_pan_result for ONE image (upsnet/dataset/base_dataset.py:332-371), numpy restatement.
+    seg, pan: int [H,W]; cls_ind: 1-based thing classes of the instances. Returns uint8 [H,W,3]."""
+    seg, pan = np.asarray(seg), np.asarray(pan)
+    pan_seg, pan_ins = pan.copy(), pan.copy()
+    id_last_stuff = num_seg_classes - num_classes                           # :339
+    ids = np.unique(pan)
+    ids_ins = ids[ids > id_last_stuff]                                      # :341
+    pan_ins[pan_ins <= id_last_stuff] = 0
+    for idx, id_ in enumerate(ids_ins):                                     # :343
+        region = pan_ins == id_
+        if id_ == 255:
+            pan_seg[region] = 255
+            pan_ins[region] = 0
+            continue
+        cls, cnt = np.unique(seg[region], return_counts=True)               # :349
+        inst_cat = cls_ind[id_ - id_last_stuff - 1] + id_last_stuff
+        if cls[np.argmax(cnt)] == inst_cat:
+            pan_seg[region] = inst_cat
+            pan_ins[region] = idx + 1
+        elif np.max(cnt) / np.sum(cnt) >= 0.5 and cls[np.argmax(cnt)] <= id_last_stuff:   # :355
+            pan_seg[region] = cls[np.argmax(cnt)]
+            pan_ins[region] = 0
+        else:
+            pan_seg[region] = inst_cat
+            pan_ins[region] = idx + 1
+    for c in np.unique(pan_seg):                                            # :362-367
+        if c <= id_last_stuff:
+            area = pan_seg == c
+            if area.sum() < stuff_area_limit:
+                pan_seg[area] = 255
+    out = np.zeros(pan.shape + (3,), np.uint8)
+    out[:, :, 0] = pan_seg
+    out[:, :, 1] = pan_ins
+    return out

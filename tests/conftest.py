@@ -50,3 +50,38 @@ def gen_dets(rng, n, im_h=1024, im_w=2048, ties=True, cluster=True):
         s[rng.integers(0, n, k)] = s[rng.integers(0, n, 1)]
         s[rng.integers(0, n, k)] = np.float32(1.0)  # saturated scores
     return np.hstack([r, s[:, None]]).astype(np.float32)
+
+
+def gen_panoptic_maps(rng, H, W, k, num_stuff=11, num_things=8, void_frac=0.03, small_stuff=True):
+    """Synthetic (seg, pan, cls_ind) like the network's outputs: stuff stripes, k rectangular instances (ids num_stuff+j) whose
+    semantic votes are a mix of: own thing class majority / a stuff class majority >= 50 % / a split vote; some void; one tiny
+    stuff area (below stuff_area_limit) when small_stuff."""
+    seg = np.zeros((H, W), np.int64)
+    bands = np.sort(rng.choice(np.arange(8, W - 8), size=num_stuff - 1, replace=False))
+    for c, (a, b) in enumerate(zip(np.r_[0, bands], np.r_[bands, W])):
+        seg[:, a:b] = c
+    if small_stuff:
+        seg[:, :] = np.where(seg == num_stuff - 1, 0, seg)
+        seg[0:3, 0:5] = num_stuff - 1
+    pan = seg.copy()
+    cls_ind = rng.integers(1, num_things + 1, size=k).astype(np.int64)
+    for j in range(k):
+        h, w = int(rng.integers(6, H // 3)), int(rng.integers(6, W // 4))
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        pan[y:y + h, x:x + w] = num_stuff + j
+        mode = j % 4
+        thing = cls_ind[j] + num_stuff - 1
+        if mode == 0:        # agrees
+            seg[y:y + h, x:x + w] = thing
+        elif mode == 1:      # stuff majority >= 50 %
+            seg[y:y + h, x:x + w] = int(rng.integers(0, num_stuff - 1))
+            seg[y:y + h // 3, x:x + w] = thing
+        elif mode == 2:      # another thing class wins -> keeps the instance class
+            seg[y:y + h, x:x + w] = (cls_ind[j] % num_things) + num_stuff
+        else:                # split three ways, stuff plurality below 50 %
+            seg[y:y + h, x:x + w] = thing
+            seg[y:y + h, x:x + 2 * w // 5] = 1
+            seg[y:y + h, x + 2 * w // 5:x + 7 * w // 10] = (cls_ind[j] % num_things) + num_stuff
+    void = rng.random((H, W)) < void_frac
+    pan[void] = 255
+    return seg, pan, cls_ind

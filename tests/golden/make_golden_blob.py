@@ -71,6 +71,20 @@ def main():
     np.savez_compressed(path, **out)
     print('wrote', path, {k: v.shape for k, v in out.items()})
 
+    # ---- BaseDataset.get_unified_pan_result (base_dataset.py:332-371), Cityscapes class counts (19 seg / 9 det classes)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from conftest import gen_panoptic_maps
+    config.dataset = mg.EasyDict(num_classes=9, num_seg_classes=19)
+    out = {}
+    for tag, (H, W, k, limit) in {'a': (96, 160, 9, 300), 'b': (64, 200, 23, 4 * 64 * 64), 'c': (80, 120, 0, 200)}.items():
+        seg, pan, cls_ind = gen_panoptic_maps(rng, H, W, k)
+        res = BaseDataset.get_unified_pan_result(None, [seg], [pan], [cls_ind], stuff_area_limit=limit)[0]
+        out.update({tag + '_seg': seg.astype(np.uint8), tag + '_pan': pan.astype(np.uint8), tag + '_cls': cls_ind, tag + '_limit': np.array(limit),
+                    tag + '_out': res})
+    path = os.path.join(HERE, 'unified_pan.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: v.shape for k, v in out.items()})
+
 
 if __name__ == '__main__':
     main()

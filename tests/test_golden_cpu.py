@@ -86,3 +86,16 @@ def test_input_blob_golden_from_reference_python():
         blob, scale = oracle.prep_image(g[tag + "_im"], means, target, max_size)
         assert scale == 1.0
         np.testing.assert_array_equal(blob, g[tag + "_blob"])
+
+
+def test_unified_pan_result_golden_from_reference_python():
+    """oracle.ops.get_unified_pan_result == BaseDataset.get_unified_pan_result of the reference (majority vote, stuff re-labelling,
+    enumerate-index instance ids, void pass-through, stuff-area filter)."""
+    g = np.load(os.path.join(G, "unified_pan.npz"))
+    for tag in ("a", "b", "c"):
+        out = oops.get_unified_pan_result(g[tag + "_seg"].astype(np.int64), g[tag + "_pan"].astype(np.int64), g[tag + "_cls"], 19, 9,
+                                          int(g[tag + "_limit"]))
+        np.testing.assert_array_equal(out, g[tag + "_out"])
+    # the fixtures exercise every branch
+    o = g["a_out"]
+    assert (o[:, :, 0] == 255).any() and (o[:, :, 1] > 0).any() and len(np.unique(o[:, :, 1])) > 3

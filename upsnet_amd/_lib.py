@@ -48,6 +48,8 @@ _SIGNATURES = {
     "upsnet_deconv2x2_pack_weight": (c_int, [P, P, c_int, c_int, c_int, P]),
     "upsnet_prep_image_u8": (c_int, [P, P, c_int, c_int, P, c_double, c_int, c_int, c_int, c_int, c_int, P]),
     "upsnet_image_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "upsnet_unified_pan_workspace_bytes": (c_size_t, []),
+    "upsnet_unified_pan_result": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_fcn_score_combine": (c_int, [P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
 }

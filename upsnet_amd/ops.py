@@ -524,3 +524,20 @@ def prep_image_u8(image_hwc, pixel_means, im_scale, resized_hw, padded_hw, nhwc4
     check(lib().upsnet_prep_image_u8(stream(), ptr(im), H, W, ctypes.cast(means, ctypes.c_void_p), float(im_scale), int(Hr), int(Wr),
                                      int(Hp), int(Wp), int(bool(nhwc4)), ptr(out)), "prep_image_u8")
     return out
+
+
+def unified_pan_result(pan, seg, cls_inds, id_last_stuff, num_seg_classes, stuff_area_limit=4 * 64 * 64):
+    """get_unified_pan_result of ONE image on the device: pan / seg int64 [H,W] (or [1,H,W]), cls_inds int64 [k] -> uint8 [H,W,3]."""
+    require_cuda(pan, seg)
+    pan = pan.reshape(pan.shape[-2], pan.shape[-1]).to(torch.int64).contiguous()
+    seg = seg.reshape(seg.shape[-2], seg.shape[-1]).to(torch.int64).contiguous()
+    if pan.shape != seg.shape:
+        raise RuntimeError("unified_pan_result: pan %s and seg %s differ in shape" % (tuple(pan.shape), tuple(seg.shape)))
+    cls_inds = cls_inds.to(device=pan.device, dtype=torch.int64).contiguous().reshape(-1)
+    H, W = pan.shape
+    ws = torch.empty((int(lib().upsnet_unified_pan_workspace_bytes()),), dtype=torch.uint8, device=pan.device)
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=pan.device)
+    check(lib().upsnet_unified_pan_result(stream(), ptr(pan), ptr(seg), ptr(cls_inds) if cls_inds.numel() else None, int(cls_inds.numel()),
+                                          H, W, int(id_last_stuff), int(num_seg_classes), int(stuff_area_limit), ptr(ws), ptr(out)),
+          "unified_pan_result")
+    return out
