@@ -37,6 +37,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='upsnet50_cityscapes_1024x2048')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--input', default='f32', choices=['f32', 'u8'],
+                    help="f32 (default, the BASELINE workload): fp32 blob resident in HBM; u8: uint8 image resident, input kernel inside the step")
+    ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
     args = ap.parse_args()
@@ -67,7 +70,8 @@ def main():
 
     overlap = [True]
     sampled[0] = 1
-    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, on_step=on_step, on_warmup_done=on_warmup_done)
+    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, on_step=on_step, on_warmup_done=on_warmup_done,
+                      input_mode=args.input, post=args.post)
     ops.PROFILE['enabled'] = False
     res['model'].overlap_streams = overlap[0]
     if (args.steps) % PROFILE_EVERY == 0:
@@ -157,6 +161,8 @@ def main():
         'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
+                   'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
+                   'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
                    'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip) for every convolution incl. the 7x7 stem and the 2x2 '
                                   'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; max-pool + FC GEMMs on PyTorch-ROCm',
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '

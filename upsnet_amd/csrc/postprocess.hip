@@ -7,7 +7,7 @@
 // semantic class; the region keeps its thing class, or is re-labelled as stuff when a stuff class holds >= 50 % of it;
 // void (255) is passed through; finally stuff classes covering less than stuff_area_limit pixels become void.
 // Here, all on the device, integers only (bit-exact by construction):
-//   unipan_hist_kernel   one pass over (pan, seg): run-length-compressed atomic counts  hist[id][seg class], area[stuff id]
+//   unipan_hist_kernel   one pass over (pan, seg): run-length-compressed counts in an LDS-privatised table hist[id][seg class]
 //   unipan_decide_kernel one workgroup: majority vote (first maximum, like np.argmax), the three-way decision, rank of each
 //                        present id (the reference's enumerate index), stuff-area filter -> a 256-entry LUT id -> (cat, ins)
 //   unipan_apply_kernel  one pass: LUT lookup, uint8 [H,W,3] written (3rd channel zero)
@@ -19,26 +19,45 @@
 
 struct UniPanWs {
     int hist[UP_IDS][UP_IDS];   // [panoptic id][semantic class]
-    int area[UP_IDS];           // pixels of each panoptic id
     unsigned char lut_cat[UP_IDS], lut_ins[UP_IDS];
 };
 
+// LDS-privatised histogram: a workgroup owns 4096 consecutive pixels (thread -> UP_RUN consecutive ones, run-length compressed),
+// counts them in an LDS table [row][class] (row = panoptic id, void in the last row) and flushes the non-zero entries with one
+// global atomic each. Works for smooth label maps (one run per thread) and for noisy ones (LDS atomics, no global contention).
 __global__ void __launch_bounds__(256)
-unipan_hist_kernel(const int64_t *__restrict__ pan, const int64_t *__restrict__ seg, const long npix, UniPanWs *__restrict__ ws)
+unipan_hist_kernel(const int64_t *__restrict__ pan, const int64_t *__restrict__ seg, const long npix, const int nrow, const int ncls,
+                   UniPanWs *__restrict__ ws)
 {
+    extern __shared__ int s_hist[];   // [nrow][ncls]
+    const int n = nrow * ncls;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
     const long start = ((long)blockIdx.x * blockDim.x + threadIdx.x) * UP_RUN;
-    if (start >= npix) return;
     const long end = start + UP_RUN < npix ? start + UP_RUN : npix;
-    int cur_id = -1, cur_cls = -1, run = 0;
+    int key = -1, run = 0;
+#define UP_FLUSH()                                                                                             \
+    if (run) {                                                                                                 \
+        const int id = key >> 8, cls = key & 255;                                                              \
+        const int row = id == 255 ? nrow - 1 : id;                                                             \
+        if (row < nrow && cls < ncls && (id == 255 || id < nrow - 1)) atomicAdd(&s_hist[row * ncls + cls], run); \
+        else atomicAdd(&ws->hist[id][cls], run);   /* id / class outside the expected table */                \
+    }
     for (long i = start; i < end; ++i) {
-        const int id = (int)pan[i] & 255, cls = (int)seg[i] & 255;
-        if (id != cur_id || cls != cur_cls) {
-            if (run) { atomicAdd(&ws->hist[cur_id][cur_cls], run); atomicAdd(&ws->area[cur_id], run); }
-            cur_id = id; cur_cls = cls; run = 0;
-        }
+        const int k = (((int)pan[i] & 255) << 8) | ((int)seg[i] & 255);
+        if (k != key) { UP_FLUSH() key = k; run = 0; }
         ++run;
     }
-    if (run) { atomicAdd(&ws->hist[cur_id][cur_cls], run); atomicAdd(&ws->area[cur_id], run); }
+    UP_FLUSH()
+#undef UP_FLUSH
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = s_hist[i];
+        if (v) {
+            const int row = i / ncls, cls = i - row * ncls;
+            atomicAdd(&ws->hist[row == nrow - 1 ? 255 : row][cls], v);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(UP_IDS)
@@ -47,7 +66,8 @@ unipan_decide_kernel(UniPanWs *__restrict__ ws, const int64_t *__restrict__ cls_
 {
     __shared__ int s_present[UP_IDS], s_to_stuff[UP_IDS], s_total[UP_IDS], s_stuff_area[UP_IDS];
     const int t = threadIdx.x;
-    const int total = ws->area[t];
+    int total = 0;
+    for (int c = 0; c < UP_IDS; ++c) total += ws->hist[t][c];
     const bool is_ins = t > id_last_stuff;            // ids_ins = ids[ids > id_last_stuff]  (:342)
     const bool present = is_ins && total > 0;
     int to_stuff = -1;                                // stuff class this region is re-labelled to, or -1
@@ -122,7 +142,11 @@ extern "C" int upsnet_unified_pan_result(void *stream, const int64_t *pan, const
     const long npix = (long)height * width;
     UPS_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(UniPanWs), st));
     const long threads = (npix + UP_RUN - 1) / UP_RUN;
-    hipLaunchKernelGGL(unipan_hist_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pan, seg, npix, ws);
+    int nrow = id_last_stuff + 1 + num_inst + 1;   // stuff ids, instance ids, void
+    if ((size_t)nrow * num_seg_classes * sizeof(int) > 60 * 1024) nrow = (int)(60 * 1024 / sizeof(int) / num_seg_classes);  // rest: global atomics
+    if (nrow < 1) nrow = 1;
+    hipLaunchKernelGGL(unipan_hist_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), (size_t)nrow * num_seg_classes * sizeof(int), st,
+                       pan, seg, npix, nrow, num_seg_classes, ws);
     UPS_CHECK_LAUNCH("unipan_hist_kernel");
     hipLaunchKernelGGL(unipan_decide_kernel, dim3(1), dim3(UP_IDS), 0, st, ws, cls_inds, num_inst, id_last_stuff, num_seg_classes, stuff_area_limit);
     UPS_CHECK_LAUNCH("unipan_decide_kernel");

@@ -29,6 +29,13 @@ def make_image(height, width, seed=0, device='cpu'):
     return {'data': blob.to(device), 'im_info': im_info}
 
 
+def make_image_u8(height, width, seed=0, device='cpu'):
+    """The uint8 [H,W,3] source image of make_image(height, width, seed) (same pixel values, HWC)."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (1, 3, height, width), generator=g)
+    return img[0].permute(1, 2, 0).contiguous().to(torch.uint8).to(device)
+
+
 def build_model(symbol=None, seed=235, device='cuda', offset_std=0.01, cls_gain=None, pipeline='fused',
                 channels_last=True, fold_bn=True):
     """Construct the configured model with seeded synthetic weights, ready for inference."""
