@@ -115,6 +115,14 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         for w in range(warmup):
             model(get(w))
         torch.cuda.synchronize(device)
+        if world > 1 and gather:
+            # warm the communicator with a gather of the final shape (RCCL sets up its channels / buffers on first use of a
+            # collective at a given size; that one-off cost belongs to start-up, not to the timed loop)
+            hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))
+            dummy = [(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0) for j in range(steps)]
+            gather_results(dummy, world, device)
+            del dummy
+            torch.cuda.synchronize(device)
         if on_warmup_done is not None:
             on_warmup_done(model)
         if world > 1:
