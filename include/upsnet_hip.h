@@ -204,6 +204,16 @@ int upsnet_mask_roi(void *stream, const float *rois, const float *bbox_delta, co
                     float *boxes_out, float *scores_out, int64_t *cls_out, int *src_out, int *num_out,
                     void *workspace);
 
+/* The reference runs the mask head on the per-class detections AND on the class-agnostic "panoptic" detections
+ * (upsnet/models/resnet_upsnet.py:190,215). Both are selections from the same (ROI row, class) table, and every ROI goes
+ * through the mask head independently, so a panoptic detection that is also a per-class detection gets bit-identical
+ * logits. Given the src/cls outputs of two upsnet_mask_roi calls (set A, set B) this entry writes, for every b in B,
+ * map_out[b] = its row in the concatenation [A ; unmatched of B], compacts the unmatched boxes of B (in order) into
+ * extra_boxes [cap_b,5] and their count into num_extra (device int). One mask-head pass over [A ; extra] then serves both. */
+int upsnet_mask_roi_dedup(void *stream, const int *a_src, const int64_t *a_cls, const int *num_a, int cap_a, const int *b_src,
+                          const int64_t *b_cls, const float *b_boxes, const int *num_b, int cap_b, int *map_out,
+                          float *extra_boxes, int *num_extra);
+
 /* ============================== Panoptic head ============================== */
 
 /* Replaces MaskRemoval.forward's selection (upsnet/operators/modules/mask_removal.py:50-93):

@@ -101,3 +101,35 @@ def test_coco_r101_dcn_config_stagewise_parity():
         assert counts['n_rois'] <= 300 and out['panoptic_outputs'].shape == (1, 224, 352)
     finally:
         update_config_dict(CITYSCAPES_R50)
+
+
+def test_mask_head_dedup_is_bit_identical_to_two_passes(setup):
+    """The fused pipeline runs the mask head once over [per-class detections ; panoptic detections not among them] and reuses
+    rows for the duplicates; the reference-shaped pipeline runs it twice (resnet_upsnet.py:190,215). Same bits."""
+    model, data = setup
+    outs = {}
+    with torch.no_grad():
+        for pipeline in ("fused", "modules"):
+            model.pipeline = pipeline
+            model.taps = {}
+            o = model(data)
+            outs[pipeline] = (model.taps, o)
+    model.taps, model.pipeline = None, 'fused'
+    tf, of = outs["fused"]
+    tm, om = outs["modules"]
+    assert tf['pan_boxes'].shape[0] >= 2 and torch.equal(tf['pan_boxes'], tm['pan_boxes'])
+    assert torch.equal(tf['pan_logit'], tm['pan_logit'])
+    assert torch.equal(of['mask_probs'], om['mask_probs'])
+    assert torch.equal(of['panoptic_outputs'], om['panoptic_outputs'])
+    # the dedup actually removed work: panoptic detections are (mostly) a subset of the per-class detections
+    from upsnet_amd import ops
+    r, s, n = model.pyramid_proposal.forward_padded(tf['rpn_cls_prob'], tf['rpn_bbox_pred'], tf['im_info'])
+    d = model.mask_roi.forward_padded(r, tf['bbox_pred'], tf['cls_prob'], tf['im_info'], n)
+    p = model.mask_roi_panoptic.forward_padded(r, tf['bbox_pred'], tf['cls_prob'], tf['im_info'], n)
+    row, extra, n_extra = ops.mask_roi_dedup(d[3], d[2], d[4], p[3], p[2], p[0], p[4])
+    n_det, n_pan, n_extra = int(d[4].item()), int(p[4].item()), int(n_extra.item())
+    assert n_extra < n_pan
+    rows = row[:n_pan].cpu().numpy()
+    allb = torch.cat([d[0][:n_det], extra[:n_extra]], 0)
+    assert torch.equal(allb[torch.from_numpy(rows).long().cuda()], p[0][:n_pan])
+    assert sorted(rows[rows >= n_det].tolist()) == list(range(n_det, n_det + n_extra))

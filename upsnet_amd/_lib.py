@@ -50,6 +50,7 @@ _SIGNATURES = {
     "upsnet_image_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_unified_pan_workspace_bytes": (c_size_t, []),
     "upsnet_unified_pan_result": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "upsnet_mask_roi_dedup": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P]),
     "upsnet_fcn_score_combine": (c_int, [P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
 }

@@ -229,3 +229,54 @@ extern "C" int upsnet_mask_roi(void *stream, const float *rois, const float *bbo
     UPS_CHECK_LAUNCH("mroi_finalize_kernel");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The reference runs the mask head twice (resnet_upsnet.py:190,215): on the per-class detections and on the class-agnostic
+// "panoptic" detections. Both sets are selections from the same (ROI row, class) -> decoded-box table, so a panoptic
+// detection that is also a per-class detection would get bit-identical mask logits (every ROI goes through the mask head
+// independently). This kernel finds those duplicates by (source ROI, class): map[p] = row of panoptic detection p in the
+// concatenation [set A ; unmatched of set B], and the unmatched boxes of B are compacted in order.
+__global__ void __launch_bounds__(DET_T)
+mroi_dedup_kernel(const int *__restrict__ a_src, const int64_t *__restrict__ a_cls, const int *__restrict__ na_dev, const int cap_a,
+                  const int *__restrict__ b_src, const int64_t *__restrict__ b_cls, const float *__restrict__ b_boxes,
+                  const int *__restrict__ nb_dev, const int cap_b, int *__restrict__ map_out, float *__restrict__ extra_boxes,
+                  int *__restrict__ n_extra)
+{
+    __shared__ int sh[DET_T / 64 + 1];
+    const int tid = threadIdx.x;
+    const int na = min(*na_dev, cap_a), nb = min(*nb_dev, cap_b);
+    int cnt = 0;
+    for (int base = 0; base < nb; base += DET_T) {
+        const int p = base + tid;
+        int hit = -1;
+        if (p < nb) {
+            const int s = b_src[p];
+            const int64_t c = b_cls[p];
+            for (int j = 0; j < na; ++j)
+                if (a_src[j] == s && a_cls[j] == c) { hit = j; break; }
+        }
+        const bool extra = p < nb && hit < 0;
+        int tot;
+        const int pos = cnt + det_block_scan(extra, sh, &tot);
+        if (p < nb) map_out[p] = extra ? na + pos : hit;
+        if (extra) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) extra_boxes[(long)pos * 5 + q] = b_boxes[(long)p * 5 + q];
+        }
+        cnt += tot;
+    }
+    if (tid == 0) *n_extra = cnt;
+}
+
+extern "C" int upsnet_mask_roi_dedup(void *stream, const int *a_src, const int64_t *a_cls, const int *num_a, int cap_a, const int *b_src,
+                                     const int64_t *b_cls, const float *b_boxes, const int *num_b, int cap_b, int *map_out,
+                                     float *extra_boxes, int *num_extra)
+{
+    UPS_REQUIRE(a_src && a_cls && num_a && b_src && b_cls && b_boxes && num_b && map_out && extra_boxes && num_extra,
+                "mask_roi_dedup: null pointer");
+    UPS_REQUIRE(cap_a >= 0 && cap_b >= 0, "mask_roi_dedup: bad capacity");
+    hipLaunchKernelGGL(mroi_dedup_kernel, dim3(1), dim3(DET_T), 0, (hipStream_t)stream, a_src, a_cls, num_a, cap_a, b_src, b_cls, b_boxes,
+                       num_b, cap_b, map_out, extra_boxes, num_extra);
+    UPS_CHECK_LAUNCH("mroi_dedup_kernel");
+    return 0;
+}

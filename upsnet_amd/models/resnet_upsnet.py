@@ -154,17 +154,20 @@ class resnet_upsnet(resnet_rcnn):
         self._tap(rpn_cls_prob=rpn_cls_prob, rpn_bbox_pred=rpn_bbox_pred,
                   im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
         # both detection selections are launched back to back; ONE host read of the two counters
-        det_boxes, det_scores, det_cls, _, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
-        pan_boxes, pan_scores, pan_cls, _, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
-        n_det, n_pan = torch.cat([det_num, pan_num]).tolist()
+        det_boxes, det_scores, det_cls, det_src, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
+        pan_boxes, pan_scores, pan_cls, pan_src, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
+        # The two selections overlap heavily (same (ROI, class) -> box table): panoptic detections that are also per-class
+        # detections reuse the mask logits computed for those (bit-identical, every ROI goes through the head independently)
+        pan_row, extra_boxes, extra_num = ops.mask_roi_dedup(det_src, det_cls, det_num, pan_src, pan_cls, pan_boxes, pan_num)
+        n_det, n_pan, n_extra = torch.cat([det_num, pan_num, extra_num]).tolist()
         det_boxes, det_scores, det_cls = det_boxes[:n_det], det_scores[:n_det], det_cls[:n_det]
         pan_boxes, pan_scores, pan_cls = pan_boxes[:n_pan], pan_scores[:n_pan], pan_cls[:n_pan]
 
-        # one mask-head pass over both ROI sets (same weights)
-        mask_score = self.mask_branch(feats, torch.cat([det_boxes, pan_boxes], 0))
+        # one mask-head pass over the union of both ROI sets (same weights)
+        mask_score = self.mask_branch(feats, torch.cat([det_boxes, extra_boxes[:n_extra]], 0) if n_extra else det_boxes)
         mask_prob = torch.sigmoid(mask_score[:n_det])
         ms = config.network.mask_size
-        pan_logit = mask_score[n_det:].gather(1, pan_cls.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+        pan_logit = mask_score.index_select(0, pan_row[:n_pan].long()).gather(1, pan_cls.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
 
         self._tap(det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls, pan_boxes=pan_boxes, pan_scores=pan_scores,
                   pan_cls=pan_cls, pan_logit=pan_logit)

@@ -541,3 +541,17 @@ def unified_pan_result(pan, seg, cls_inds, id_last_stuff, num_seg_classes, stuff
                                           H, W, int(id_last_stuff), int(num_seg_classes), int(stuff_area_limit), ptr(ws), ptr(out)),
           "unified_pan_result")
     return out
+
+
+def mask_roi_dedup(a_src, a_cls, a_num, b_src, b_cls, b_boxes, b_num):
+    """Rows of the B detections inside [A ; unmatched of B] (matching on (source ROI, class)). Returns (map int32 [capB],
+    extra_boxes [capB,5], num_extra device int32 [1])."""
+    require_cuda(a_src, b_src, b_boxes)
+    cap_a, cap_b = a_src.shape[0], b_src.shape[0]
+    dev = b_boxes.device
+    mp = torch.empty((cap_b,), dtype=torch.int32, device=dev)
+    extra = torch.empty((cap_b, 5), dtype=torch.float32, device=dev)
+    n_extra = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib().upsnet_mask_roi_dedup(stream(), ptr(a_src), ptr(a_cls), ptr(a_num), cap_a, ptr(b_src), ptr(b_cls), ptr(f32c(b_boxes)),
+                                      ptr(b_num), cap_b, ptr(mp), ptr(extra), ptr(n_extra)), "mask_roi_dedup")
+    return mp, extra, n_extra
