@@ -155,7 +155,8 @@ def main():
     last = res['last_out']
     line = {
         'metric': 'images/sec (whole node), %s' % {'upsnet50_cityscapes_1024x2048': 'UPSNet-50 1024x2048',
-                                                   'upsnet101dcn_coco_800x1333': 'UPSNet-101-DCN 800x1333'}.get(args.workload, args.workload),
+                                                   'upsnet101dcn_coco_800x1333': 'UPSNet-101-DCN 800x1333',
+                                                   'upsnet101dcn_mixed_1024x2048_800x1333': 'UPSNet-101-DCN mixed 1024x2048 / 800x1333 stream'}.get(args.workload, args.workload),
         'value': round(value, 4), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
         'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

@@ -133,3 +133,34 @@ def test_mask_head_dedup_is_bit_identical_to_two_passes(setup):
     allb = torch.cat([d[0][:n_det], extra[:n_extra]], 0)
     assert torch.equal(allb[torch.from_numpy(rows).long().cuda()], p[0][:n_pan])
     assert sorted(rows[rows >= n_det].tolist()) == list(range(n_det, n_det + n_extra))
+
+
+def test_mixed_resolution_stream_r101_dcn():
+    """BASELINE.json configs[4] shape family: ONE UPSNet-101-DCN model object fed an alternating stream of Cityscapes-shaped and
+    COCO-shaped images (different padded sizes, different proposal counts): every step stage-wise identical to the oracle, and
+    identical to the same image run in isolation (no state leaks between resolutions: workspaces, packed weights, streams)."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN, CITYSCAPES_R50
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model(cls_gain=0.3)
+        imgs = [make_image(128, 256, seed=3, device='cuda'), make_image(100, 167, seed=4, device='cuda')]   # second pads to 128 x 192
+        first = {}
+        with torch.no_grad():
+            for step in range(4):
+                j = step % 2
+                model.taps = {}
+                out = model(imgs[j])
+                res = check_taps(model.taps, enable_void=True)
+                counts = res.pop('counts')
+                assert all(res.values()), (step, res, counts)
+                if j in first:
+                    assert torch.equal(out['panoptic_outputs'], first[j]['panoptic_outputs'])
+                    assert torch.equal(out['pred_boxes'], first[j]['pred_boxes'])
+                else:
+                    first[j] = out
+        model.taps = None
+        assert first[0]['panoptic_outputs'].shape == (1, 128, 256) and first[1]['panoptic_outputs'].shape == (1, 128, 192)
+    finally:
+        update_config_dict(CITYSCAPES_R50)

@@ -26,6 +26,8 @@ WORKLOADS = {
     # name: (config preset, unpadded H, W, cls_gain)
     'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 0.3),
     'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 0.3),
+    # BASELINE.json configs[4]: alternating Cityscapes-shaped / COCO-shaped images through one UPSNet-101-DCN
+    'upsnet101dcn_mixed_1024x2048_800x1333': (COCO_R101_DCN, (1024, 800), (2048, 1333), 0.3),
 }
 
 
@@ -90,18 +92,20 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
     every step too (the reference does it after the loop, on the host)."""
     rank, world, device = init_distributed()
     preset, H, W, gain = WORKLOADS[workload]
+    sizes = list(zip(H, W)) if isinstance(H, (tuple, list)) else [(H, W)]
+    H, W = max(h for h, _ in sizes), max(w for _, w in sizes)   # (label maps are padded to the largest size for the gather)
     update_config_dict(preset)
     model = build_model(cls_gain=gain, device=device, pipeline=pipeline)
     # each rank owns its images: image id = step * world + rank, seeded by id
     my_ids = [s * world + rank for s in range(steps)]
     if input_mode == 'u8':
         from .dataset.blob import get_image_blob
-        pool = [make_image_u8(H, W, seed=seed + j, device=device) for j in range(4)]  # 4 distinct uint8 images resident in HBM
+        pool = [make_image_u8(*sizes[j % len(sizes)], seed=seed + j, device=device) for j in range(4)]  # 4 distinct uint8 images resident in HBM
 
         def get(i):
             return get_image_blob(pool[i % 4], config.test.scales[0], config.test.max_size)
     else:
-        pool = [make_image(H, W, seed=seed + j, device=device) for j in range(4)]  # 4 distinct fp32 blobs resident in HBM
+        pool = [make_image(*sizes[j % len(sizes)], seed=seed + j, device=device) for j in range(4)]  # 4 distinct fp32 blobs resident in HBM
 
         def get(i):
             return pool[i % 4]
@@ -136,7 +140,11 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
                 out['pan_2ch'] = post_fn([out['fcn_outputs']], [out['panoptic_outputs']], [out['panoptic_cls_inds']])[0]
             torch.cuda.synchronize(device)
             net_timer.toc()
-            outs.append((i, out['panoptic_outputs'][0].to(torch.uint8), int(out['panoptic_cls_inds'].numel())))
+            lab = out['panoptic_outputs'][0].to(torch.uint8)
+            if len(sizes) > 1:  # mixed stream: common shape for the gather (255 = void outside the image)
+                hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))
+                lab = torch.nn.functional.pad(lab, (0, wp - lab.shape[1], 0, hp - lab.shape[0]), value=255)
+            outs.append((i, lab, int(out['panoptic_cls_inds'].numel())))
             if on_step is not None:
                 on_step(s, out, model)
         results = gather_results(outs, world, device) if gather else None
