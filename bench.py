@@ -165,7 +165,8 @@ def main():
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
                    'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip) for every convolution incl. the 7x7 stem and the 2x2 '
-                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; max-pool + FC GEMMs on PyTorch-ROCm',
+                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; large 3x3 layers (FPN P2/P3, RPN, res2/res3) as fused '
+                                  'Winograd F(2x2,3x3) instances of the same kernel (fp32); max-pool + FC GEMMs on PyTorch-ROCm',
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank, final RCCL all_gather',

@@ -120,6 +120,17 @@ int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const
                            const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
                            int relu, int residual_up);
 
+/* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2, 3x3) on the same MFMA kernel (16/36 of the multiplies of the
+ * direct form; all arithmetic fp32; differs from the direct kernel by fp32 rounding only, ~1e-6 relative -- cuDNN, the
+ * reference's convolution backend, uses the same algorithm). The input transform (a signed sum of four pixels per
+ * position) is the A-operand loader, the 16 per-position GEMMs run back to back in one workgroup, the output transform is
+ * folded into the accumulators. wpack [16*Cin, ldw] from upsnet_conv_pack_weight_winograd (weight [Cout,Cin,3,3]).
+ * Same calling convention as upsnet_conv2d_nhwc_f32 (multi-map launch, bias / residual / ReLU epilogue). */
+int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                                    float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                                    const float *wpack, int ldw, const float *bias, int Cout, int relu);
+int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
+
 /* 7x7/2 stem (upsnet/models/resnet.py:347-356, conv1 + frozen BN + ReLU): Cin <= 4 input given as NHWC with 4 channels
  * (x [N,H,W,4], 4th channel ignored by zero weights; see upsnet_image_to_nhwc4 / upsnet_prep_image_u8). One K slab of the
  * implicit GEMM is one kernel row: 8 consecutive pixels x 4 channels. wpack [KH*32, ldw] from upsnet_conv_pack_weight_stem

@@ -97,3 +97,35 @@ def test_conv_residual_nearest_upsample_fused(N, Cin, Cout, H, W):
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
     with pytest.raises(RuntimeError):
         ops.conv2d_nhwc(x, wp, ldw, b, Cout, 1, 1, 0, residual=r)   # shape mismatch without residual_up
+
+
+@pytest.mark.parametrize("shapes,Cin,Cout,relu,res,bias", [
+    ([(1, 32, 64)], 64, 64, True, False, True),
+    ([(1, 33, 47)], 32, 96, False, False, True),          # odd sizes: partial 2x2 tiles on the right / bottom edge
+    ([(2, 14, 14)], 256, 256, True, True, True),          # batch > 1, residual, tiles wrap rows every 7
+    ([(1, 17, 9)], 64, 18, False, False, False),          # Cout < 32 (128x32 tile instance)
+    ([(1, 64, 128), (1, 32, 64), (1, 16, 32), (1, 8, 16), (1, 4, 8)], 256, 256, True, False, True),   # 5 maps, one launch (RPN head)
+])
+def test_winograd_conv_vs_torch(shapes, Cin, Cout, relu, res, bias):
+    """Fused Winograd F(2x2,3x3) vs torch fp64 conv2d (1e-4) and vs the direct MFMA kernel (same tolerance, much closer in practice)."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + Cout + len(shapes))
+    xs = [torch.randn(n, Cin, h, w, device='cuda') for n, h, w in shapes]
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    rs = [torch.randn(x.shape[0], Cout, x.shape[2], x.shape[3], device='cuda') for x in xs] if res else None
+    wp, ldw = ops.pack_winograd_weight(w)
+    outs = ops.conv2d_winograd_multi(xs, wp, ldw, b, Cout, relu=relu, residuals=rs)
+    wd, ldd = ops.pack_conv_weight(w)
+    direct = ops.conv2d_nhwc_multi(xs, wd, ldd, b, Cout, 3, 1, 1, relu=relu, residuals=rs)
+    for i, (x, o, d) in enumerate(zip(xs, outs, direct)):
+        ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+        if res:
+            ref = ref + rs[i].double()
+        if relu:
+            ref = ref.clamp_min(0)
+        assert o.shape == ref.shape
+        np.testing.assert_allclose(o.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+        assert float((o - d).abs().max()) < 2e-5
+    again = ops.conv2d_winograd_multi(xs, wp, ldw, b, Cout, relu=relu, residuals=rs)
+    assert all(torch.equal(a, o) for a, o in zip(again, outs))   # fixed summation order: bit-repeatable

@@ -31,6 +31,7 @@ struct ConvSeg {
     const float *x, *res, *off, *mask;
     float *out;
     int N, H, W, Ho, Wo;
+    int OH, OW;  // Winograd: real output size (Ho, Wo then count 2x2 output tiles)
     int tile_start;
     long M;  // N*Ho*Wo
 };
@@ -103,6 +104,59 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
     return val;
 }
 
+// Winograd F(2x2, 3x3) loader (DEFORM == 4). The GEMM "pixel" is a 2x2 OUTPUT TILE and the "tap" is one of the 16 positions
+// xi = (i, j) of the transformed domain: V_xi = (B^T d B)[i][j] of the tile's 4x4 input patch d. Every row of
+// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] has two non-zeros, so V_xi is a signed sum of FOUR input pixels: the
+// loader is the deformable one with integer offsets and weights +-1 (0 outside the image = zero padding). The 16 per-position
+// GEMMs against U_xi = (G g G^T)[i][j] run back to back in one workgroup; after the K walk of a position its accumulator
+// is folded into the four output accumulators Y = A^T M A (coefficients 0 / +-1) -- 16/36 of the multiplies of the direct form.
+struct WinoDesc {
+    unsigned o1, o2, o3, o4;
+    float w1, w2, w3, w4;
+};
+
+__device__ static inline void wino_sel(const int i, int &a1, int &a2, float &s1, float &s2)
+{
+    a1 = i == 0 ? 0 : 1;
+    a2 = i == 3 ? 3 : 2;
+    s1 = i == 2 ? -1.f : 1.f;
+    s2 = (i == 0 || i == 3) ? -1.f : 1.f;
+}
+
+// (h0, w0): input coordinates of the patch origin (2*ty - 1, 2*tx - 1); nb: element offset of (image, channel group)
+__device__ static inline WinoDesc wino_desc(const ConvSeg &sg, const int pix_n, const int nb, const int h0, const int w0, const int i,
+                                            const int j, const int cin)
+{
+    int a1, a2, b1, b2;
+    float sa1, sa2, sb1, sb2;
+    wino_sel(i, a1, a2, sa1, sa2);
+    wino_sel(j, b1, b2, sb1, sb2);
+    const int H = sg.H, W = sg.W;
+    const int ha = h0 + a1, hb = h0 + a2, wa = w0 + b1, wb = w0 + b2;
+    const bool ok = pix_n >= 0;
+    const bool vha = ok && ha >= 0 && ha < H, vhb = ok && hb >= 0 && hb < H, vwa = wa >= 0 && wa < W, vwb = wb >= 0 && wb < W;
+    const int hac = min(max(ha, 0), H - 1), hbc = min(max(hb, 0), H - 1), wac = min(max(wa, 0), W - 1), wbc = min(max(wb, 0), W - 1);
+    WinoDesc d;
+    d.o1 = 4u * (unsigned)(nb + (hac * W + wac) * cin);
+    d.o2 = 4u * (unsigned)(nb + (hac * W + wbc) * cin);
+    d.o3 = 4u * (unsigned)(nb + (hbc * W + wac) * cin);
+    d.o4 = 4u * (unsigned)(nb + (hbc * W + wbc) * cin);
+    d.w1 = (vha && vwa) ? sa1 * sb1 : 0.f;
+    d.w2 = (vha && vwb) ? sa1 * sb2 : 0.f;
+    d.w3 = (vhb && vwa) ? sa2 * sb1 : 0.f;
+    d.w4 = (vhb && vwb) ? sa2 * sb2 : 0.f;
+    return d;
+}
+
+__device__ static inline float wino_blend1(const WinoDesc &d, const float v1, const float v2, const float v3, const float v4)
+{
+    float val = d.w1 * v1;
+    val = val + d.w2 * v2;
+    val = val + d.w3 * v3;
+    val = val + d.w4 * v4;
+    return val;
+}
+
 // WM x WN = 32x32 tiles per wave, waves arranged WAVES_M x WAVES_N (4 waves): BM = 32*WM*WAVES_M (128 or 64) output
 // pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup. BK = input channels per K slab (32 / 64).
 // DEFORM (A-operand loader): 0 dense, 1 deformable v1, 2 deformable v2 (modulated), 3 stem: the input is an NHWC image with
@@ -120,7 +174,7 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
 //   step KS-2     barrier (all fragment reads of this buffer are complete, all stashes visible)
 //   step KS-1     fragment reads of step 0 of slab s+1 from the other buffer
 template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK, int RESUP>
-__global__ void __launch_bounds__(256, (WM * WN <= 2 && BK == 32) ? 3 : 1)
+__global__ void __launch_bounds__(256, DEFORM == 4 ? 2 : ((WM * WN <= 2 && BK == 32) ? 3 : 1))
 conv_igemm_f32_kernel(const ConvParams p)
 {
     constexpr int BN = WAVES_N * WN * 32;
@@ -139,6 +193,8 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr bool MOD = DEFORM == 2;
     constexpr bool DEF = DEFORM == 1 || DEFORM == 2;
     constexpr bool STEM = DEFORM == 3;
+    constexpr bool WINO = DEFORM == 4;
+    static_assert(!WINO || (WM == 1 && WN == 1), "Winograd instances use one 32x32 tile per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *As = reinterpret_cast<float *>(smem_raw);     // [2][BK][LDA]
     float *Bs = As + 2 * BK * LDA;                       // [2][BK][BN]
@@ -211,6 +267,14 @@ conv_igemm_f32_kernel(const ConvParams p)
     bool xv0 = false, xv1 = false, xv2 = false, xv3 = false, yv0 = false, yv1 = false, yv2 = false, yv3 = false;
     float4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;  // deformable: [pixel][corner]
     DcnDesc d0, d1, d2, d3;
+    WinoDesc wd0, wd1, wd2, wd3;
+    floatx16 y00, y01, y10, y11;                                // Winograd: output accumulators Y = A^T M A
+    if (WINO) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
+    }
+    int c_cs = 0, c_i = 0, c_j = 0;                             // Winograd: (channel slab, position) of the slab being contracted
+    const int cin_slabs = p.Cin / BK;
 
 #define CV_LDX(O) (*reinterpret_cast<const float4 *>(xbase + (O)))
 #define CV_TAP_DENSE(R)                                                                                               \
@@ -259,9 +323,23 @@ conv_igemm_f32_kernel(const ConvParams p)
         CV_FETCH_B(x)                                                                                                 \
         CV_ADVANCE                                                                                                    \
     }
+#define CV_TAP_WINO(R)                                                                                                \
+    wd##R = wino_desc(sg, pix_n[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, pix_h[R], pix_w[R], f_ki, f_kj, p.Cin);
+#define CV_FETCH_WINO_PX(R)                                                                                           \
+    c##R##0 = CV_LDX(wd##R.o1); c##R##1 = CV_LDX(wd##R.o2); c##R##2 = CV_LDX(wd##R.o3); c##R##3 = CV_LDX(wd##R.o4);   \
+    wd##R.o1 += 4u * BK; wd##R.o2 += 4u * BK; wd##R.o3 += 4u * BK; wd##R.o4 += 4u * BK;
+#define CV_FETCH_WINO                                                                                                 \
+    {                                                                                                                 \
+        if (f_newtap) { CV_TAP_WINO(0) CV_TAP_WINO(1) if (PXT > 2) { CV_TAP_WINO(2) CV_TAP_WINO(3) } }                \
+        CV_FETCH_WINO_PX(0) CV_FETCH_WINO_PX(1)                                                                       \
+        if (PXT > 2) { CV_FETCH_WINO_PX(2) CV_FETCH_WINO_PX(3) }                                                      \
+        CV_FETCH_B(x)                                                                                                 \
+        CV_ADVANCE                                                                                                    \
+    }
 #define CV_FETCH_x CV_FETCH_DENSE(x)
 #define CV_FETCH_y CV_FETCH_DENSE(y)
 #define CV_FETCH_c CV_FETCH_DEFORM
+#define CV_FETCH_w CV_FETCH_WINO
 #define CV_FETCH(SET) CV_FETCH_##SET
 
 #define CV_STASH_PX(BUF, R, VX, VY, VZ, VW)                                                                           \
@@ -281,6 +359,11 @@ conv_igemm_f32_kernel(const ConvParams p)
                 dcn_blend1(d##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w, MOD))
+#define CV_STASH_A_w(BUF, R)                                                                                          \
+    CV_STASH_PX(BUF, R, wino_blend1(wd##R, (c##R##0).x, (c##R##1).x, (c##R##2).x, (c##R##3).x),                        \
+                wino_blend1(wd##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y),                                \
+                wino_blend1(wd##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z),                                \
+                wino_blend1(wd##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w))
 #define CV_STASH_A(SET, BUF, R) CV_STASH_A_##SET(BUF, R)
 #define CV_STASH_B_P(P, BUF)                                                                                          \
     {                                                                                                                 \
@@ -292,6 +375,7 @@ conv_igemm_f32_kernel(const ConvParams p)
 #define CV_STASH_B_x(BUF) CV_STASH_B_P(x, BUF)
 #define CV_STASH_B_y(BUF) CV_STASH_B_P(y, BUF)
 #define CV_STASH_B_c(BUF) CV_STASH_B_P(x, BUF)
+#define CV_STASH_B_w(BUF) CV_STASH_B_P(x, BUF)
 #define CV_STASH_B(SET, BUF) CV_STASH_B_##SET(BUF)
 
     float av[2][WM], bv[2][WN];  // MFMA fragments, double-buffered over k steps (carried across slabs)
@@ -325,9 +409,34 @@ conv_igemm_f32_kernel(const ConvParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);     \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
+        if (WINO && ++c_cs == cin_slabs) {  /* last slab of position (c_i, c_j): fold M into Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] */ \
+            const float ci0 = c_i < 3 ? 1.f : 0.f, ci1 = c_i == 0 ? 0.f : (c_i == 1 ? 1.f : -1.f);                    \
+            const float cj0 = c_j < 3 ? 1.f : 0.f, cj1 = c_j == 0 ? 0.f : (c_j == 1 ? 1.f : -1.f);                    \
+            const float k00 = ci0 * cj0, k01 = ci0 * cj1, k10 = ci1 * cj0, k11 = ci1 * cj1;                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
+                const float m_ = acc[0][0][r];                                                                        \
+                y00[r] = y00[r] + k00 * m_; y01[r] = y01[r] + k01 * m_;                                               \
+                y10[r] = y10[r] + k10 * m_; y11[r] = y11[r] + k11 * m_;                                               \
+                acc[0][0][r] = 0.f;                                                                                   \
+            }                                                                                                         \
+            c_cs = 0;                                                                                                 \
+            if (++c_j == 4) { c_j = 0; ++c_i; }                                                                       \
+        }                                                                                                             \
     }
 
-    if (DEF) {
+    if (WINO) {
+        CV_FETCH(w)
+        CV_STASH_A(w, 0, 0) CV_STASH_A(w, 0, 1)
+        if (PXT > 2) { CV_STASH_A(w, 0, 2) CV_STASH_A(w, 0, 3) }
+        CV_STASH_B(w, 0)
+        __syncthreads();
+        CV_FRAG(0, 0, 0)
+        for (int s = 0; s < nslabs; s += 2) {
+            CV_SLAB(0, w, w, s + 1 < nslabs, s + 1 < nslabs)
+            if (s + 1 >= nslabs) break;
+            CV_SLAB(1, w, w, s + 2 < nslabs, s + 2 < nslabs)
+        }
+    } else if (DEF) {
         CV_FETCH(c)
         CV_STASH_A(c, 0, 0) CV_STASH_A(c, 0, 1)
         if (PXT > 2) { CV_STASH_A(c, 0, 2) CV_STASH_A(c, 0, 3) }
@@ -364,6 +473,12 @@ conv_igemm_f32_kernel(const ConvParams p)
 #undef CV_FETCH_x
 #undef CV_FETCH_y
 #undef CV_FETCH_c
+#undef CV_FETCH_w
+#undef CV_TAP_WINO
+#undef CV_FETCH_WINO_PX
+#undef CV_FETCH_WINO
+#undef CV_STASH_A_w
+#undef CV_STASH_B_w
 #undef CV_FETCH
 #undef CV_STASH_PX
 #undef CV_STASH_A_DENSE
@@ -379,6 +494,52 @@ conv_igemm_f32_kernel(const ConvParams p)
 #undef CV_FRAG
 #undef CV_SLAB
 
+    if (WINO) {
+        // ---- Winograd epilogue: row r of the tile is the 2x2 output tile (n, ty, tx); + bias, + residual, ReLU, 4 stores
+        const bool has_res_w = sg.res != nullptr;
+        const int co = n0 + wn * 32 + aij;
+        const bool co_ok = co < p.Cout;
+        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+        const long pbase = p0 + wm * 32 + 4 * akr;
+        const long pb = pbase < sg.M ? pbase : sg.M - 1;
+        const int n_b = (int)(pb / HoWo);
+        const int rem_b = (int)(pb - (long)n_b * HoWo);
+        const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+        const bool fast = sg.Wo >= 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = (r & 3) + 8 * (r >> 2);
+            if (!(co_ok && pbase + off < sg.M)) continue;
+            int n = n_b, h = h_b, w = w_b;
+            if (fast) {
+                w += off;
+                if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+            } else {
+                const long pp = pbase + off;
+                n = (int)(pp / HoWo);
+                const int rem = (int)(pp - (long)n * HoWo);
+                h = rem / sg.Wo; w = rem - h * sg.Wo;
+            }
+            const int oy = 2 * h, ox = 2 * w;
+            const bool y1 = oy + 1 < sg.OH, x1 = ox + 1 < sg.OW;
+            const long o00 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
+            const long o01 = o00 + p.Cout, o10 = o00 + (long)sg.OW * p.Cout, o11 = o10 + p.Cout;
+            float v00 = y00[r] + bv, v01 = y01[r] + bv, v10 = y10[r] + bv, v11 = y11[r] + bv;
+            if (has_res_w) {
+                v00 = v00 + sg.res[o00];
+                if (x1) v01 = v01 + sg.res[o01];
+                if (y1) v10 = v10 + sg.res[o10];
+                if (x1 && y1) v11 = v11 + sg.res[o11];
+            }
+            if (p.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+            sg.out[o00] = v00;
+            if (x1) sg.out[o01] = v01;
+            if (y1) sg.out[o10] = v10;
+            if (x1 && y1) sg.out[o11] = v11;
+        }
+        return;
+    }
     // ---- fused epilogue: + bias, + residual, ReLU. Residual values are loaded 16 at a time, unconditionally
     // (clamped row), before any of them is used, so the loads overlap instead of serialising.
     // RESUP 1: the residual lives at half resolution and is read through a nearest x2 upsampling
@@ -509,7 +670,8 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
         return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 2>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 2>(st, p);
     }
     if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
-    constexpr int D = DEFORM == 3 ? 0 : DEFORM;  // (stem returned above; keeps its instantiations to two tiles)
+    if (DEFORM == 4) return n64 ? conv_launch<1, 1, 2, 2, 4>(st, p) : conv_launch<1, 1, 4, 1, 4>(st, p);
+    constexpr int D = DEFORM >= 3 ? 0 : DEFORM;  // (stem / Winograd returned above; keeps their instantiations to two tiles)
     switch (tile) {
     case 1: return conv_launch<2, 2, 2, 2, D>(st, p);      // 128 x 128
     case 2: return conv_launch<1, 2, 4, 1, D>(st, p);      // 128 x 64
@@ -541,6 +703,7 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
             UPS_REQUIRE(x[i] && out[i] && nb > 0 && height[i] > 0 && width[i] > 0, "%s: bad feature map %d", who, i);
             s.x = x[i]; s.out = out[i]; s.res = res ? res[i] : nullptr; s.off = off ? off[i] : nullptr; s.mask = mask ? mask[i] : nullptr;
             s.N = nb; s.H = height[i]; s.W = width[i];
+            s.OH = s.OW = 0;
             s.Ho = (height[i] + 2 * pad - (dil * (KH - 1) + 1)) / stride + 1;
             s.Wo = (width[i] + 2 * pad - (dil * (KW - 1) + 1)) / stride + 1;
             UPS_REQUIRE(s.Ho > 0 && s.Wo > 0, "%s: empty output for feature map %d", who, i);
@@ -550,7 +713,7 @@ static int conv_fill(ConvParams &p, const char *who, int nseg, const float *cons
             tiles += (int)((s.M + 127) / 128);
         } else {
             s.x = s.res = s.off = s.mask = nullptr; s.out = nullptr;
-            s.N = s.H = s.W = s.Ho = s.Wo = 0; s.M = 0; s.tile_start = 0x7fffffff;
+            s.N = s.H = s.W = s.Ho = s.Wo = s.OH = s.OW = 0; s.M = 0; s.tile_start = 0x7fffffff;
         }
     }
     p.m_tiles = tiles;
@@ -590,6 +753,70 @@ extern "C" int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const flo
                        ldw, bias, kh, kw, stride_h, pad_h, dil_h, relu);
     if (rc) return rc;
     return mask ? conv_dispatch<2>((hipStream_t)stream, p) : conv_dispatch<1>((hipStream_t)stream, p);
+}
+
+extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                                               float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                                               const float *wpack, int ldw, const float *bias, int Cout, int relu)
+{
+    ConvParams p;
+    // geometry of the 3x3 / stride 1 / pad 1 convolution first ...
+    int rc = conv_fill(p, "conv2d_winograd_nhwc_f32", nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout, wpack, ldw,
+                       bias, 3, 3, 1, 1, 1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)16 * Cin * ldw < (1L << 30), "conv2d_winograd_nhwc_f32: packed weight exceeds 4 GiB");
+    // ... then the GEMM "pixels" become 2x2 output tiles and the 16 "taps" the positions of the transformed domain
+    for (int i = 0; i < nseg; ++i) {
+        ConvSeg &s = p.seg[i];
+        s.OH = s.Ho; s.OW = s.Wo;
+        s.Ho = (s.OH + 1) / 2; s.Wo = (s.OW + 1) / 2;
+        s.M = (long)s.N * s.Ho * s.Wo;
+    }
+    p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1;
+    return conv_dispatch<4>((hipStream_t)stream, p);
+}
+
+// weight [Cout, Cin, 3, 3] -> U [(i*4+j)*Cin + c, ldw] = (G g G^T)[i][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void conv_pack_weight_winograd_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
+{
+    const long total = (long)ldw * cin;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int co = idx % ldw, c = idx / ldw;
+        float g[3][3], t[4][3], u[4][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = co < cout ? w[(((long)co * cin + c) * 3 + a) * 3 + b] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u[a][0] = t[a][0];
+            u[a][1] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+            u[a][2] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+            u[a][3] = t[a][2];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wp[((long)(a * 4 + b) * cin + c) * ldw + co] = u[a][b];
+    }
+}
+
+extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout && ldw % 32 == 0, "conv_pack_weight_winograd: bad args");
+    const long total = (long)ldw * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(conv_pack_weight_winograd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, ldw, wpack);
+    UPS_CHECK_LAUNCH("conv_pack_weight_winograd_kernel");
+    return 0;
 }
 
 extern "C" int upsnet_conv2d_stem_nhwc4_f32(void *stream, const float *x, int batch, int height, int width, const float *wpack,

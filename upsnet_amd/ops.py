@@ -555,3 +555,52 @@ def mask_roi_dedup(a_src, a_cls, a_num, b_src, b_cls, b_boxes, b_num):
     check(lib().upsnet_mask_roi_dedup(stream(), ptr(a_src), ptr(a_cls), ptr(a_num), cap_a, ptr(b_src), ptr(b_cls), ptr(f32c(b_boxes)),
                                       ptr(b_num), cap_b, ptr(mp), ptr(extra), ptr(n_extra)), "mask_roi_dedup")
     return mp, extra, n_extra
+
+
+# ----------------------------------------------------------------------------- Winograd F(2x2,3x3)
+def pack_winograd_weight(weight):
+    """[Cout,Cin,3,3] -> ([16*Cin, ldw], ldw): U_xi = (G g G^T)[i][j] per transformed-domain position."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise RuntimeError("pack_winograd_weight: kernel must be 3x3")
+    ldw = (Cout + 31) // 32 * 32
+    wp = torch.empty((16 * Cin, ldw), dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_conv_pack_weight_winograd(stream(), ptr(weight), Cout, Cin, ldw, ptr(wp)), "conv_pack_weight_winograd")
+    return wp, ldw
+
+
+def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None):
+    """3x3 / stride 1 / pad 1 convolution of up to 5 maps (shared weights) by fused Winograd F(2x2,3x3); same contract as
+    conv2d_nhwc_multi."""
+    require_cuda(wpack, *xs)
+    assert 1 <= len(xs) <= 5
+    xs = [nhwc(x.float()) for x in xs]
+    cin = xs[0].shape[1]
+    outs, ress = [], None
+    for x in xs:
+        N, C, H, W = x.shape
+        if C != cin:
+            raise RuntimeError("conv2d_winograd_multi: channel mismatch")
+        outs.append(_nhwc_out(N, cout, H, W, x.device))
+    if residuals is not None:
+        ress = [nhwc(r.float()) for r in residuals]
+        for r, o in zip(ress, outs):
+            if tuple(r.shape) != tuple(o.shape):
+                raise RuntimeError("conv2d_winograd: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_winograd_nhwc_f32(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None,
+                                                ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
+                                                int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
+                                                ptr(None if bias is None else f32c(bias)), int(cout), int(bool(relu))),
+          "conv2d_winograd_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
+        # algorithmic work of the convolution (direct-form flops), as for the direct kernel
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix,
+                                  4.0 * (cin * npix + cout * npix * (2 if ress is not None else 1) + cout * cin * 9)))
+    return outs
