@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from upsnet_amd import ops
+from upsnet_amd._lib import lib
 
 def timeit(fn, n=5):
     for _ in range(2): fn()

@@ -194,7 +194,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr bool DEF = DEFORM == 1 || DEFORM == 2;
     constexpr bool STEM = DEFORM == 3;
     constexpr bool WINO = DEFORM == 4;
-    static_assert(!WINO || (WM == 1 && WN == 1), "Winograd instances use one 32x32 tile per wave");
+    static_assert(!WINO || WM == 1, "Winograd instances use one 32-row tile per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *As = reinterpret_cast<float *>(smem_raw);     // [2][BK][LDA]
     float *Bs = As + 2 * BK * LDA;                       // [2][BK][BN]
@@ -268,10 +268,20 @@ conv_igemm_f32_kernel(const ConvParams p)
     float4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;  // deformable: [pixel][corner]
     DcnDesc d0, d1, d2, d3;
     WinoDesc wd0, wd1, wd2, wd3;
-    floatx16 y00, y01, y10, y11;                                // Winograd: output accumulators Y = A^T M A
+    float4 e00, e01, e02, e03, e10, e11, e12, e13;               // Winograd: second register set (2-slab prefetch), PXT == 2 only
+    float4 e20, e21, e22, e23, e30, e31, e32, e33;               // (never live: PXT == 2; named so that the shared slab macro compiles)
+    float cw21 = 0, cw22 = 0, cw23 = 0, cw24 = 0, cw31 = 0, cw32 = 0, cw33 = 0, cw34 = 0, ew21 = 0, ew22 = 0, ew23 = 0, ew24 = 0, ew31 = 0, ew32 = 0, ew33 = 0, ew34 = 0;
+    float cw01, cw02, cw03, cw04, cw11, cw12, cw13, cw14;        // blend weights captured with set c / set e at fetch time
+    float ew01, ew02, ew03, ew04, ew11, ew12, ew13, ew14;
+    static_assert(!WINO || PXT == 2, "Winograd instances stage two tiles per thread");
+    floatx16 yy[4][WINO ? WN : 1];                              // Winograd: output accumulators Y = A^T M A, [2p+q][n-tile]
     if (WINO) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yy[q][j][r] = 0.f;
     }
     int c_cs = 0, c_i = 0, c_j = 0;                             // Winograd: (channel slab, position) of the slab being contracted
     const int cin_slabs = p.Cin / BK;
@@ -325,21 +335,22 @@ conv_igemm_f32_kernel(const ConvParams p)
     }
 #define CV_TAP_WINO(R)                                                                                                \
     wd##R = wino_desc(sg, pix_n[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, pix_h[R], pix_w[R], f_ki, f_kj, p.Cin);
-#define CV_FETCH_WINO_PX(R)                                                                                           \
-    c##R##0 = CV_LDX(wd##R.o1); c##R##1 = CV_LDX(wd##R.o2); c##R##2 = CV_LDX(wd##R.o3); c##R##3 = CV_LDX(wd##R.o4);   \
+#define CV_FETCH_WINO_PX(P, R)                                                                                        \
+    P##R##0 = CV_LDX(wd##R.o1); P##R##1 = CV_LDX(wd##R.o2); P##R##2 = CV_LDX(wd##R.o3); P##R##3 = CV_LDX(wd##R.o4);   \
+    P##w##R##1 = wd##R.w1; P##w##R##2 = wd##R.w2; P##w##R##3 = wd##R.w3; P##w##R##4 = wd##R.w4;                       \
     wd##R.o1 += 4u * BK; wd##R.o2 += 4u * BK; wd##R.o3 += 4u * BK; wd##R.o4 += 4u * BK;
-#define CV_FETCH_WINO                                                                                                 \
+#define CV_FETCH_WINO(P, PB)                                                                                          \
     {                                                                                                                 \
-        if (f_newtap) { CV_TAP_WINO(0) CV_TAP_WINO(1) if (PXT > 2) { CV_TAP_WINO(2) CV_TAP_WINO(3) } }                \
-        CV_FETCH_WINO_PX(0) CV_FETCH_WINO_PX(1)                                                                       \
-        if (PXT > 2) { CV_FETCH_WINO_PX(2) CV_FETCH_WINO_PX(3) }                                                      \
-        CV_FETCH_B(x)                                                                                                 \
+        if (f_newtap) { CV_TAP_WINO(0) CV_TAP_WINO(1) }                                                               \
+        CV_FETCH_WINO_PX(P, 0) CV_FETCH_WINO_PX(P, 1)                                                                 \
+        CV_FETCH_B(PB)                                                                                                \
         CV_ADVANCE                                                                                                    \
     }
 #define CV_FETCH_x CV_FETCH_DENSE(x)
 #define CV_FETCH_y CV_FETCH_DENSE(y)
 #define CV_FETCH_c CV_FETCH_DEFORM
-#define CV_FETCH_w CV_FETCH_WINO
+#define CV_FETCH_w CV_FETCH_WINO(c, x)
+#define CV_FETCH_v CV_FETCH_WINO(e, y)
 #define CV_FETCH(SET) CV_FETCH_##SET
 
 #define CV_STASH_PX(BUF, R, VX, VY, VZ, VW)                                                                           \
@@ -359,11 +370,9 @@ conv_igemm_f32_kernel(const ConvParams p)
                 dcn_blend1(d##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w, MOD))
-#define CV_STASH_A_w(BUF, R)                                                                                          \
-    CV_STASH_PX(BUF, R, wino_blend1(wd##R, (c##R##0).x, (c##R##1).x, (c##R##2).x, (c##R##3).x),                        \
-                wino_blend1(wd##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y),                                \
-                wino_blend1(wd##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z),                                \
-                wino_blend1(wd##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w))
+#define CV_WBLEND(P, R, F) ((((P##w##R##1 * (P##R##0).F) + P##w##R##2 * (P##R##1).F) + P##w##R##3 * (P##R##2).F) + P##w##R##4 * (P##R##3).F)
+#define CV_STASH_A_w(BUF, R) CV_STASH_PX(BUF, R, CV_WBLEND(c, R, x), CV_WBLEND(c, R, y), CV_WBLEND(c, R, z), CV_WBLEND(c, R, w))
+#define CV_STASH_A_v(BUF, R) CV_STASH_PX(BUF, R, CV_WBLEND(e, R, x), CV_WBLEND(e, R, y), CV_WBLEND(e, R, z), CV_WBLEND(e, R, w))
 #define CV_STASH_A(SET, BUF, R) CV_STASH_A_##SET(BUF, R)
 #define CV_STASH_B_P(P, BUF)                                                                                          \
     {                                                                                                                 \
@@ -376,6 +385,7 @@ conv_igemm_f32_kernel(const ConvParams p)
 #define CV_STASH_B_y(BUF) CV_STASH_B_P(y, BUF)
 #define CV_STASH_B_c(BUF) CV_STASH_B_P(x, BUF)
 #define CV_STASH_B_w(BUF) CV_STASH_B_P(x, BUF)
+#define CV_STASH_B_v(BUF) CV_STASH_B_P(y, BUF)
 #define CV_STASH_B(SET, BUF) CV_STASH_B_##SET(BUF)
 
     float av[2][WM], bv[2][WN];  // MFMA fragments, double-buffered over k steps (carried across slabs)
@@ -413,28 +423,31 @@ conv_igemm_f32_kernel(const ConvParams p)
             const float ci0 = c_i < 3 ? 1.f : 0.f, ci1 = c_i == 0 ? 0.f : (c_i == 1 ? 1.f : -1.f);                    \
             const float cj0 = c_j < 3 ? 1.f : 0.f, cj1 = c_j == 0 ? 0.f : (c_j == 1 ? 1.f : -1.f);                    \
             const float k00 = ci0 * cj0, k01 = ci0 * cj1, k10 = ci1 * cj0, k11 = ci1 * cj1;                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
-                const float m_ = acc[0][0][r];                                                                        \
-                y00[r] = y00[r] + k00 * m_; y01[r] = y01[r] + k01 * m_;                                               \
-                y10[r] = y10[r] + k10 * m_; y11[r] = y11[r] + k11 * m_;                                               \
-                acc[0][0][r] = 0.f;                                                                                   \
-            }                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
+                    const float m_ = acc[0][j][r];                                                                    \
+                    yy[0][j][r] = yy[0][j][r] + k00 * m_; yy[1][j][r] = yy[1][j][r] + k01 * m_;                       \
+                    yy[2][j][r] = yy[2][j][r] + k10 * m_; yy[3][j][r] = yy[3][j][r] + k11 * m_;                       \
+                    acc[0][j][r] = 0.f;                                                                               \
+                }                                                                                                     \
             c_cs = 0;                                                                                                 \
             if (++c_j == 4) { c_j = 0; ++c_i; }                                                                       \
         }                                                                                                             \
     }
 
     if (WINO) {
-        CV_FETCH(w)
-        CV_STASH_A(w, 0, 0) CV_STASH_A(w, 0, 1)
-        if (PXT > 2) { CV_STASH_A(w, 0, 2) CV_STASH_A(w, 0, 3) }
-        CV_STASH_B(w, 0)
-        __syncthreads();
-        CV_FRAG(0, 0, 0)
-        for (int s = 0; s < nslabs; s += 2) {
-            CV_SLAB(0, w, w, s + 1 < nslabs, s + 1 < nslabs)
-            if (s + 1 >= nslabs) break;
-            CV_SLAB(1, w, w, s + 2 < nslabs, s + 2 < nslabs)
+        if constexpr (PXT == 2) {   // (two register sets, loads two slabs ahead -- like the dense instances)
+            CV_FETCH(w)
+            CV_STASH_A(w, 0, 0) CV_STASH_A(w, 0, 1)
+            CV_STASH_B(w, 0)
+            if (nslabs > 1) CV_FETCH(v)
+            __syncthreads();
+            CV_FRAG(0, 0, 0)
+            for (int s = 0; s < nslabs; s += 2) {
+                CV_SLAB(0, w, v, s + 2 < nslabs, s + 1 < nslabs)
+                if (s + 1 >= nslabs) break;
+                CV_SLAB(1, v, w, s + 3 < nslabs, s + 2 < nslabs)
+            }
         }
     } else if (DEF) {
         CV_FETCH(c)
@@ -474,6 +487,10 @@ conv_igemm_f32_kernel(const ConvParams p)
 #undef CV_FETCH_y
 #undef CV_FETCH_c
 #undef CV_FETCH_w
+#undef CV_FETCH_v
+#undef CV_STASH_A_v
+#undef CV_STASH_B_v
+#undef CV_WBLEND
 #undef CV_TAP_WINO
 #undef CV_FETCH_WINO_PX
 #undef CV_FETCH_WINO
@@ -497,9 +514,6 @@ conv_igemm_f32_kernel(const ConvParams p)
     if (WINO) {
         // ---- Winograd epilogue: row r of the tile is the 2x2 output tile (n, ty, tx); + bias, + residual, ReLU, 4 stores
         const bool has_res_w = sg.res != nullptr;
-        const int co = n0 + wn * 32 + aij;
-        const bool co_ok = co < p.Cout;
-        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
         const long pbase = p0 + wm * 32 + 4 * akr;
         const long pb = pbase < sg.M ? pbase : sg.M - 1;
         const int n_b = (int)(pb / HoWo);
@@ -507,36 +521,42 @@ conv_igemm_f32_kernel(const ConvParams p)
         const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
         const bool fast = sg.Wo >= 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int off = (r & 3) + 8 * (r >> 2);
-            if (!(co_ok && pbase + off < sg.M)) continue;
-            int n = n_b, h = h_b, w = w_b;
-            if (fast) {
-                w += off;
-                if (w >= sg.Wo) { w -= sg.Wo; ++h; }
-                if (h >= sg.Ho) { h -= sg.Ho; ++n; }
-            } else {
-                const long pp = pbase + off;
-                n = (int)(pp / HoWo);
-                const int rem = (int)(pp - (long)n * HoWo);
-                h = rem / sg.Wo; w = rem - h * sg.Wo;
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + wn * (WN * 32) + 32 * j + aij;
+            const bool co_ok = co < p.Cout;
+            const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                if (!(co_ok && pbase + off < sg.M)) continue;
+                int n = n_b, h = h_b, w = w_b;
+                if (fast) {
+                    w += off;
+                    if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                    if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+                } else {
+                    const long pp = pbase + off;
+                    n = (int)(pp / HoWo);
+                    const int rem = (int)(pp - (long)n * HoWo);
+                    h = rem / sg.Wo; w = rem - h * sg.Wo;
+                }
+                const int oy = 2 * h, ox = 2 * w;
+                const bool y1 = oy + 1 < sg.OH, x1 = ox + 1 < sg.OW;
+                const long o00 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
+                const long o01 = o00 + p.Cout, o10 = o00 + (long)sg.OW * p.Cout, o11 = o10 + p.Cout;
+                float v00 = yy[0][j][r] + bv, v01 = yy[1][j][r] + bv, v10 = yy[2][j][r] + bv, v11 = yy[3][j][r] + bv;
+                if (has_res_w) {
+                    v00 = v00 + sg.res[o00];
+                    if (x1) v01 = v01 + sg.res[o01];
+                    if (y1) v10 = v10 + sg.res[o10];
+                    if (x1 && y1) v11 = v11 + sg.res[o11];
+                }
+                if (p.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+                sg.out[o00] = v00;
+                if (x1) sg.out[o01] = v01;
+                if (y1) sg.out[o10] = v10;
+                if (x1 && y1) sg.out[o11] = v11;
             }
-            const int oy = 2 * h, ox = 2 * w;
-            const bool y1 = oy + 1 < sg.OH, x1 = ox + 1 < sg.OW;
-            const long o00 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
-            const long o01 = o00 + p.Cout, o10 = o00 + (long)sg.OW * p.Cout, o11 = o10 + p.Cout;
-            float v00 = y00[r] + bv, v01 = y01[r] + bv, v10 = y10[r] + bv, v11 = y11[r] + bv;
-            if (has_res_w) {
-                v00 = v00 + sg.res[o00];
-                if (x1) v01 = v01 + sg.res[o01];
-                if (y1) v10 = v10 + sg.res[o10];
-                if (x1 && y1) v11 = v11 + sg.res[o11];
-            }
-            if (p.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-            sg.out[o00] = v00;
-            if (x1) sg.out[o01] = v01;
-            if (y1) sg.out[o10] = v10;
-            if (x1 && y1) sg.out[o11] = v11;
         }
         return;
     }
@@ -670,7 +690,10 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
         return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 2>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 2>(st, p);
     }
     if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
-    if (DEFORM == 4) return n64 ? conv_launch<1, 1, 2, 2, 4>(st, p) : conv_launch<1, 1, 4, 1, 4>(st, p);
+    if (DEFORM == 4) {   // (64 tiles x 128 channels was measured: slower, 256 registers + spills)
+        UPS_REQUIRE(n64, "conv2d_winograd_nhwc_f32: Cout must round up to a multiple of 64 (ldw %% 64 == 0); use the direct kernel");
+        return conv_launch<1, 1, 2, 2, 4>(st, p);
+    }
     constexpr int D = DEFORM >= 3 ? 0 : DEFORM;  // (stem / Winograd returned above; keeps their instantiations to two tiles)
     switch (tile) {
     case 1: return conv_launch<2, 2, 2, 2, D>(st, p);      // 128 x 128

@@ -565,7 +565,7 @@ def pack_winograd_weight(weight):
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise RuntimeError("pack_winograd_weight: kernel must be 3x3")
-    ldw = (Cout + 31) // 32 * 32
+    ldw = (Cout + 63) // 64 * 64   # the Winograd instance tiles 64 output channels per workgroup
     wp = torch.empty((16 * Cin, ldw), dtype=torch.float32, device=weight.device)
     check(lib().upsnet_conv_pack_weight_winograd(stream(), ptr(weight), Cout, Cin, ldw, ptr(wp)), "conv_pack_weight_winograd")
     return wp, ldw
