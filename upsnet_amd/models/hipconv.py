@@ -50,7 +50,8 @@ def _winograd_plan(m):
 
 
 def _use_winograd(m, xs):
-    if not (WINOGRAD and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (1, 1)):
+    if not (WINOGRAD and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (1, 1) and
+            m.out_channels >= 64):   # (narrow heads -- DCN offsets, Cout = 18 -- are faster on the direct 128x32 instance)
         return False
     tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // 64) for x in xs)
     return tiles * (-(-m.out_channels // 64)) >= WINOGRAD_MIN_WORKGROUPS

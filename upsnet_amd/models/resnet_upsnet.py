@@ -126,9 +126,11 @@ class resnet_upsnet(resnet_rcnn):
         im_info = data['im_info']
         # x4 upsampling of the semantic logits is fused into the panoptic kernel (enable_void branch, rate 4)
         fuse_up = self.enable_void and self.fcn_head.upsample_rate == 4
-        # The semantic head (offset convs + deformable convs, ~2 ms of MFMA-bound work) depends only on the FPN outputs, not on
-        # the RPN / proposal / detection chain (which contains a dozen latency-bound single-workgroup kernels): it is issued on
-        # a side stream right after the FPN so the two overlap on the GPU; the main stream joins it before the panoptic fusion.
+        # The semantic head (offset convs + deformable convs, ~2 ms of MFMA-bound work) depends only on the FPN outputs; the
+        # proposal -> box head -> detection-selection chain (~2 ms, a dozen latency-bound single-workgroup kernels) depends only on
+        # the RPN. The RPN convolution (MFMA-bound itself) runs first on its own; then the semantic head is issued on a side
+        # stream so that it overlaps with that chain; the main stream joins it before the panoptic fusion.
+        _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
         main = torch.cuda.current_stream()
         side, ev_fork, ev_join = self._side_stream() if self.overlap_streams else (main, None, None)
         if side is not main:
@@ -146,7 +148,6 @@ class resnet_upsnet(resnet_rcnn):
                 ev_join.record(side)
                 (fcn_score if fuse_up else fcn_output).record_stream(main)
 
-        _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
         rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
         rcnn_output = self.rcnn(feats, rois, n_rois)
         cls_prob = F.softmax(rcnn_output['cls_score'], dim=1)
