@@ -11,6 +11,8 @@
 //
 // Arithmetic is the reference's, per channel, in fp32 without FMA contraction: every output value is
 // bit-identical to the CPU oracle.
+#include <stdlib.h>
+
 #include "common.h"
 #include "upsnet_hip.h"
 
@@ -236,6 +238,114 @@ fpn_roi_align_nhwc_kernel(const FpnFeat ft, const int channels, const float *__r
     }
 }
 
+static int roi_per_bin()  // 1: one wave per (roi, bin) (the older decomposition); A/B knob, env UPSNET_ROI_PER_BIN
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UPSNET_ROI_PER_BIN"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
+// One workgroup (4 waves) per ROI, sampling_ratio == 2: the ROI is decoded and its FPN level chosen once per wave instead of
+// once per bin; each wave walks bins wave, wave+4, ... with the 16 corner loads of the NEXT bin issued before the current one
+// is blended (two register sets), so a wave keeps 16-32 KiB of loads in flight. NHWC in, NHWC out, C <= 256 per pass.
+struct RoiBinG2 {
+    unsigned o[16];
+    float w[16];
+};
+
+__device__ static inline void roi_bin_setup_g2(const int c4n, const int height, const int width, const float roi_start_h,
+                                               const float roi_start_w, const float bin_size_h, const float bin_size_w, const int ph,
+                                               const int pw, RoiBinG2 &b)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int iy = s >> 1, ix = s & 1;
+        const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / 2.0f;
+        const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / 2.0f;
+        RoiTap t;
+        t.y_low = t.y_high = t.x_low = t.x_high = 0;
+        t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+        const bool ok = roi_tap(height, width, y, x, t);
+        b.o[4 * s + 0] = (unsigned)((t.y_low * width + t.x_low) * c4n);
+        b.o[4 * s + 1] = (unsigned)((t.y_low * width + t.x_high) * c4n);
+        b.o[4 * s + 2] = (unsigned)((t.y_high * width + t.x_low) * c4n);
+        b.o[4 * s + 3] = (unsigned)((t.y_high * width + t.x_high) * c4n);
+        b.w[4 * s + 0] = ok ? t.w1 : 0.f; b.w[4 * s + 1] = ok ? t.w2 : 0.f;
+        b.w[4 * s + 2] = ok ? t.w3 : 0.f; b.w[4 * s + 3] = ok ? t.w4 : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fpn_roi_align_nhwc_roi_kernel(const FpnFeat ft, const int channels, const float *__restrict__ rois, const int num_rois,
+                              const int *__restrict__ num_rois_dev, const int pooled_h, const int pooled_w,
+                              float *__restrict__ out, int *__restrict__ levels_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
+    const int c4n = channels >> 2;
+    const int nbins_all = pooled_h * pooled_w;
+    // blockIdx.y splits the bins of a ROI when there are few ROIs (mask head: 100-200 ROIs x 196 bins)
+    const int per = (nbins_all + gridDim.y - 1) / gridDim.y;
+    const int bin0 = blockIdx.y * per, nbins = min(nbins_all, bin0 + per);
+    float4 *o4 = reinterpret_cast<float4 *>(out + (long)n * nbins_all * channels);
+    if (n >= nvalid) {  // padded tail of a fixed-size roi buffer: defined output (zeros)
+        for (int i = bin0 * c4n + threadIdx.x; i < nbins * c4n; i += blockDim.x) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float *r = rois + (long)n * 5;
+    const float rx1 = r[1], ry1 = r[2], rx2 = r[3], ry2 = r[4];
+    const int lvl = fpn_level_of(rx1, ry1, rx2, ry2);
+    if (levels_out && threadIdx.x == 0 && blockIdx.y == 0) levels_out[n] = lvl;
+    const float spatial_scale = ft.scale[lvl];
+    const int height = ft.h[lvl], width = ft.w[lvl];
+    const float4 *__restrict__ feat = reinterpret_cast<const float4 *>(ft.ptr[lvl]);
+    const float roi_start_w = rx1 * spatial_scale, roi_start_h = ry1 * spatial_scale;
+    const float roi_end_w = rx2 * spatial_scale, roi_end_h = ry2 * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+        const float4 *f = feat + c4;
+        RoiBinG2 cur, nxt;
+        float4 v[16], u[16];
+        int bin = bin0 + wave;
+        if (bin < nbins) {
+            roi_bin_setup_g2(c4n, height, width, roi_start_h, roi_start_w, bin_size_h, bin_size_w, bin / pooled_w, bin % pooled_w, cur);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = f[cur.o[q]];
+        }
+        for (; bin < nbins; bin += 4) {
+            const int nb = bin + 4;
+            if (nb < nbins) {
+                roi_bin_setup_g2(c4n, height, width, roi_start_h, roi_start_w, bin_size_h, bin_size_w, nb / pooled_w, nb % pooled_w, nxt);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) u[q] = f[nxt.o[q]];
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {   // reference order: sample (iy, ix), corners 1..4 (roi_align_kernel.cu:199-231)
+                float4 val;
+                val.x = cur.w[4 * sq] * v[4 * sq].x; val.y = cur.w[4 * sq] * v[4 * sq].y; val.z = cur.w[4 * sq] * v[4 * sq].z; val.w = cur.w[4 * sq] * v[4 * sq].w;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    val.x = val.x + cur.w[4 * sq + q] * v[4 * sq + q].x; val.y = val.y + cur.w[4 * sq + q] * v[4 * sq + q].y;
+                    val.z = val.z + cur.w[4 * sq + q] * v[4 * sq + q].z; val.w = val.w + cur.w[4 * sq + q] * v[4 * sq + q].w;
+                }
+                acc.x += val.x; acc.y += val.y; acc.z += val.z; acc.w += val.w;
+            }
+            acc.x /= 4.0f; acc.y /= 4.0f; acc.z /= 4.0f; acc.w /= 4.0f;
+            o4[(long)bin * c4n + c4] = acc;
+            if (nb < nbins) {
+                cur = nxt;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = u[q];
+            }
+        }
+    }
+}
+
 extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
                                             const int feat_w[4], const float spatial_scale[4], int channels,
                                             const float *rois, int num_rois, const int *num_rois_dev,
@@ -250,6 +360,18 @@ extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const fea
     for (int i = 0; i < 4; ++i) {
         UPS_REQUIRE(feat_nhwc[i] && feat_h[i] > 0 && feat_w[i] > 0, "fpn_roi_align_forward: bad level %d", i);
         ft.ptr[i] = feat_nhwc[i]; ft.h[i] = feat_h[i]; ft.w[i] = feat_w[i]; ft.scale[i] = spatial_scale[i];
+    }
+    bool small = true;   // 32-bit float4 offsets
+    for (int i = 0; i < 4; ++i) small = small && (long)feat_h[i] * feat_w[i] * (channels >> 2) < (1L << 31);
+    if (sampling_ratio == 2 && small && roi_per_bin() == 0) {
+        const int nb = pooled_height * pooled_width;
+        int nsplit = (1536 + num_rois - 1) / num_rois;   // aim at >= 1536 workgroups, >= 8 bins each
+        if (nsplit > nb / 8) nsplit = nb / 8;
+        if (nsplit < 1) nsplit = 1;
+        hipLaunchKernelGGL(fpn_roi_align_nhwc_roi_kernel, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                           num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+        UPS_CHECK_LAUNCH("fpn_roi_align_nhwc_roi_kernel");
+        return 0;
     }
     long bins = (long)num_rois * pooled_height * pooled_width;
     int blocks = (int)((bins + 3) / 4);
