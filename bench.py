@@ -39,13 +39,18 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'],
                     help="f32 (default, the BASELINE workload): fp32 blob resident in HBM; u8: uint8 image resident, input kernel inside the step")
+    ap.add_argument('--conv-precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+                    help="fp32 (default, the headline configuration): exact fp32 products; bf16x3: bf16 matrix cores, 3-term split "
+                         "(fp32-equivalent to ~1e-5); bf16: BASELINE.json configs[2] (bf16 products, fp32 accumulation)")
     ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
     args = ap.parse_args()
 
     from upsnet_amd import ops
+    from upsnet_amd.models import hipconv
     from upsnet_amd.upsnet_end2end_test import upsnet_test
+    hipconv.PRECISION = args.conv_precision
 
     # kernel events are recorded on every PROFILE_EVERY-th timed image only (two events per launch are not free:
     # recording all ~75 conv launches of every image costs ~3 % of the step time)
@@ -160,7 +165,8 @@ def main():
         'value': round(value, 4), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
         'ms_per_img_p50': round(p50_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (3-term bf16 split of fp32 operands, fp32 accumulate; dense convs only)',
+                  'bf16': 'bf16 (dense convs: bf16 products, fp32 accumulate; rest f32)'}[args.conv_precision], 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',

@@ -131,6 +131,21 @@ int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x
                                     const float *wpack, int ldw, const float *bias, int Cout, int relu);
 int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
 
+/* Dense convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- BASELINE.json configs[2]
+ * ("bf16 compute / fp32 accumulate") and its fp32-equivalent 3-term split. OPT-IN: the fp32 kernel above is the default.
+ * Activations stay fp32 NHWC in HBM (same tensors as upsnet_conv2d_nhwc_f32) and are split to bf16 on the way into LDS.
+ *   wpack_lo == NULL : "bf16"   -- operands rounded to bf16, one MFMA per product
+ *   wpack_lo != NULL : "bf16x3" -- a = a_hi + a_lo, b = b_hi + b_lo; a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (error ~2^-16
+ *                      relative per product, fp32 accumulation): inside the 1e-4 fp32-logit tolerance
+ * wpack_hi / wpack_lo: bf16 [KH*KW*Cin/32][ldw][32] from upsnet_conv_pack_weight_bf16, ldw = Cout rounded up to 64.
+ * Same calling convention as upsnet_conv2d_nhwc_f32 (without residual_up). */
+int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], const float *const residual[], float *const out[],
+                            const int batch[], const int height[], const int width[], int Cin, const void *wpack_hi,
+                            const void *wpack_lo, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
+                            int relu);
+int upsnet_conv_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, void *wpack_hi,
+                                 void *wpack_lo);
+
 /* 7x7/2 stem (upsnet/models/resnet.py:347-356, conv1 + frozen BN + ReLU): Cin <= 4 input given as NHWC with 4 channels
  * (x [N,H,W,4], 4th channel ignored by zero weights; see upsnet_image_to_nhwc4 / upsnet_prep_image_u8). One K slab of the
  * implicit GEMM is one kernel row: 8 consecutive pixels x 4 channels. wpack [KH*32, ldw] from upsnet_conv_pack_weight_stem

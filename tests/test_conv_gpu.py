@@ -129,3 +129,35 @@ def test_winograd_conv_vs_torch(shapes, Cin, Cout, relu, res, bias):
         assert float((o - d).abs().max()) < 2e-5
     again = ops.conv2d_winograd_multi(xs, wp, ldw, b, Cout, relu=relu, residuals=rs)
     assert all(torch.equal(a, o) for a, o in zip(again, outs))   # fixed summation order: bit-repeatable
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,pad,relu,res", [
+    (1, 64, 64, 33, 47, 3, 1, 1, True, False),
+    (1, 256, 64, 40, 56, 1, 1, 0, True, False),
+    (1, 64, 256, 40, 56, 1, 1, 0, True, True),
+    (1, 256, 128, 41, 57, 1, 2, 0, False, False),
+    (2, 256, 256, 14, 14, 3, 1, 1, True, False),
+    (1, 512, 19, 24, 40, 1, 1, 0, False, False),
+    (1, 2048, 256, 8, 16, 1, 1, 0, False, False),
+])
+@pytest.mark.parametrize("split", [True, False])
+def test_conv_bf16_matrix_cores_vs_torch(N, Cin, Cout, H, W, k, stride, pad, relu, res, split):
+    """bf16 MFMA convolution: the 3-term split meets the fp32 tolerance (1e-4); plain bf16 (configs[2]) is checked at bf16 accuracy."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, k, k, device='cuda') / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    r = torch.randn_like(ref).float() if res else None
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    hi, lo, ldw = ops.pack_conv_weight_bf16(w, split=split)
+    out = ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, b, Cout, k, stride, pad, relu=relu, residuals=None if r is None else [r])[0]
+    assert out.shape == ref.shape
+    tol = 1e-4 if split else 3e-2
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol)
+    again = ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, b, Cout, k, stride, pad, relu=relu, residuals=None if r is None else [r])[0]
+    assert torch.equal(again, out)

@@ -164,3 +164,27 @@ def test_mixed_resolution_stream_r101_dcn():
         assert first[0]['panoptic_outputs'].shape == (1, 128, 256) and first[1]['panoptic_outputs'].shape == (1, 128, 192)
     finally:
         update_config_dict(CITYSCAPES_R50)
+
+
+@pytest.mark.parametrize("precision,min_agree", [("bf16x3", 0.999), ("bf16", 0.90)])
+def test_bf16_matrix_core_convs_end_to_end(setup, precision, min_agree):
+    """BASELINE.json configs[2] (and its fp32-equivalent 3-term split): dense convolutions on the bf16 matrix cores. Every custom-op
+    stage still reproduces the oracle bit-for-bit from its recorded inputs; the label map agrees with the fp32 run to the extent
+    the precision allows (bf16x3: essentially everywhere; bf16: most pixels -- random synthetic weights have no margin)."""
+    from oracle.forward import check_taps
+    from upsnet_amd.models import hipconv
+    model, data = setup
+    with torch.no_grad():
+        ref = model(data)
+        hipconv.PRECISION = precision
+        try:
+            model.taps = {}
+            out = model(data)
+            taps, model.taps = model.taps, None
+        finally:
+            hipconv.PRECISION = 'fp32'
+    res = check_taps(taps, enable_void=model.enable_void)
+    counts = res.pop('counts')
+    assert all(res.values()), (res, counts)
+    agree = float((out['fcn_outputs'] == ref['fcn_outputs']).float().mean())
+    assert agree >= min_agree, agree

@@ -19,6 +19,11 @@ ENABLED = True
 # kernel (1.3-1.7x faster there; same fp32 arithmetic class, ~1e-6 relative difference). Smaller layers stay on the direct form.
 WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_WORKGROUPS = 256
+# Arithmetic of the dense convolutions: 'fp32' (default; exact fp32 products on the fp32 MFMA, the configuration every headline
+# number is measured on), 'bf16x3' (bf16 matrix cores, 3-term split, fp32-equivalent to ~1e-5) or 'bf16' (BASELINE.json
+# configs[2]: bf16 products, fp32 accumulation). The stem, the deconvolution, the FPN top-down laterals and the deformable
+# convolutions always use the fp32 kernel.
+PRECISION = os.environ.get('UPSNET_CONV_PRECISION', 'fp32')
 _cache = {}
 
 
@@ -37,6 +42,16 @@ def supported(m, x):
     return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and
             ops.conv_supported(m.in_channels, m.kernel_size[0], m.kernel_size[1], m.groups, m.dilation) and
             m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
+
+
+def _bf16_plan(m):
+    w = m.weight
+    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version, PRECISION)
+    ent = _cache.get(('bf16', id(m)))
+    if ent is None or ent[0] != key:
+        ent = (key,) + ops.pack_conv_weight_bf16(w.detach(), split=(PRECISION == 'bf16x3'))
+        _cache[('bf16', id(m))] = ent
+    return ent[1], ent[2], ent[3]
 
 
 def _winograd_plan(m):
@@ -61,6 +76,10 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
     winograd=False pins the direct form (layers whose batch size varies at run time and whose results must not depend on it)."""
     if supported(m, x):
+        if PRECISION != 'fp32' and not residual_up:
+            hi, lo, ldw = _bf16_plan(m)
+            return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
+                                              relu=relu, residuals=None if residual is None else [residual])[0]
         if winograd and not residual_up and _use_winograd(m, [x]):
             wp, ldw = _winograd_plan(m)
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
@@ -78,6 +97,9 @@ def conv_multi(m, xs, relu=False):
     """The same conv module applied to several feature maps (FPN levels) in ONE launch."""
     xs = list(xs)
     if len(xs) <= 5 and all(supported(m, x) for x in xs):
+        if PRECISION != 'fp32':
+            hi, lo, ldw = _bf16_plan(m)
+            return ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu)
         if _use_winograd(m, xs):
             wp, ldw = _winograd_plan(m)
             return ops.conv2d_winograd_multi(xs, wp, ldw, m.bias, m.out_channels, relu=relu)

@@ -604,3 +604,52 @@ def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix,
                                   4.0 * (cin * npix + cout * npix * (2 if ress is not None else 1) + cout * cin * 9)))
     return outs
+
+
+# ----------------------------------------------------------------------------- bf16 matrix-core convolution (opt-in)
+def pack_conv_weight_bf16(weight, split=True):
+    """[Cout,Cin,kh,kw] fp32 -> (hi, lo, ldw): bf16 [kh*kw*Cin/32, ldw, 32] (as int16 storage), ldw = Cout rounded up to 64.
+    split=False ("bf16" mode) leaves lo = None."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    Cout, Cin, kh, kw = weight.shape
+    ldw = (Cout + 63) // 64 * 64
+    shape = (kh * kw * Cin // 32, ldw, 32)
+    hi = torch.empty(shape, dtype=torch.bfloat16, device=weight.device)
+    lo = torch.empty(shape, dtype=torch.bfloat16, device=weight.device) if split else None
+    check(lib().upsnet_conv_pack_weight_bf16(stream(), ptr(weight), Cout, Cin, kh, kw, ldw, ptr(hi), ptr(lo)), "conv_pack_weight_bf16")
+    return hi, lo, ldw
+
+
+def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None):
+    """conv2d_nhwc_multi on the bf16 matrix cores: wlo None -> plain bf16 products, else the 3-term split (fp32-equivalent)."""
+    require_cuda(whi, *xs)
+    assert 1 <= len(xs) <= 5
+    xs = [nhwc(x.float()) for x in xs]
+    cin = xs[0].shape[1]
+    outs, ress = [], None
+    for x in xs:
+        N, C, H, W = x.shape
+        if C != cin:
+            raise RuntimeError("conv2d_nhwc_bf16_multi: channel mismatch")
+        outs.append(_nhwc_out(N, cout, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, x.device))
+    if residuals is not None:
+        ress = [nhwc(r.float()) for r in residuals]
+        for r, o in zip(ress, outs):
+            if tuple(r.shape) != tuple(o.shape):
+                raise RuntimeError("conv2d_nhwc_bf16: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_nhwc_bf16(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None, ptr_array(outs),
+                                        int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
+                                        int_array([x.shape[3] for x in xs]), int(cin), ptr(whi), ptr(wlo), int(ldw),
+                                        ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride), int(pad),
+                                        int(bool(relu))), "conv2d_nhwc_bf16")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
+        nin = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        PROFILE['events'].append(('conv_bf16', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
+                                  4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1)) + 2.0 * cout * cin * ksize * ksize))
+    return outs
