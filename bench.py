@@ -54,7 +54,7 @@ def main():
 
     # kernel events are recorded on every PROFILE_EVERY-th timed image only (two events per launch are not free:
     # recording all ~75 conv launches of every image costs ~3 % of the step time)
-    PROFILE_EVERY = 5
+    PROFILE_EVERY = 10
     ops.PROFILE['events'] = []
     sampled = [0]
 
@@ -158,6 +158,18 @@ def main():
                         'n_inst': out_cpu['n_inst']}
 
     last = res['last_out']
+    # after the timed region: the last image once more, eagerly (no HIP graph, no side stream) -- the label map of the timed
+    # run must be identical (guards the graph replay / stream overlap machinery, not the kernels: those have their own tests)
+    model = res['model']
+    g, o = model.use_graph, model.overlap_streams
+    model.use_graph, model.overlap_streams = False, False
+    with torch.no_grad():
+        chk = model(res['image'])
+    model.use_graph, model.overlap_streams = g, o
+    same = bool(torch.equal(chk['panoptic_outputs'], last['panoptic_outputs']) and torch.equal(chk['pred_boxes'], last['pred_boxes']))
+    agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
+    if agree < 0.99 or chk['pred_boxes'].shape != last['pred_boxes'].shape:   # (bit-identical in practice; the FC GEMMs are a library)
+        raise RuntimeError("bench: the timed run's outputs differ from an eager re-run of the same image (label agreement %.4f)" % agree)
     line = {
         'metric': 'images/sec (whole node), %s' % {'upsnet50_cityscapes_1024x2048': 'UPSNet-50 1024x2048',
                                                    'upsnet101dcn_coco_800x1333': 'UPSNet-101-DCN 800x1333',
@@ -176,7 +188,9 @@ def main():
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank, final RCCL all_gather',
-                   'streams': 'semantic head on a side stream, concurrent with the proposal/detection chain (serial on the %d roofline-sampled images)' % n_sampled,
+                   'streams': 'static-shape part of the forward (trunk, semantic head on a side stream concurrent with the proposal/detection '
+                              'chain) replayed as one HIP graph; the %d roofline-sampled images run eagerly and serially' % n_sampled,
+                   'hip_graph': bool(g), 'verified_vs_eager_rerun': same,
                    'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
         'roofline': roofline, 'cpu_baseline': cpu_baseline,
     }

@@ -188,3 +188,25 @@ def test_bf16_matrix_core_convs_end_to_end(setup, precision, min_agree):
     assert all(res.values()), (res, counts)
     agree = float((out['fcn_outputs'] == ref['fcn_outputs']).float().mean())
     assert agree >= min_agree, agree
+
+
+def test_hip_graph_replay_equals_eager(setup):
+    """The static-shape part of the forward (trunk, semantic head on the side stream, proposal / detection chain) is captured as a
+    HIP graph on the third image of a shape; replays must equal the eager forward on every output, for changing images of that
+    shape and when another shape is interleaved."""
+    from upsnet_amd.synthetic import make_image
+    model, _ = setup
+    imgs = [make_image(256, 512, seed=11 + j, device='cuda') for j in range(3)] + [make_image(192, 320, seed=20, device='cuda')]
+    keys = ('panoptic_outputs', 'pred_boxes', 'cls_probs', 'cls_inds', 'mask_probs', 'panoptic_cls_inds', 'fcn_outputs')
+    with torch.no_grad():
+        model.use_graph = False
+        eager = [{k: v.clone() for k, v in model(im).items()} for im in imgs]
+        model.use_graph = True
+        model._graphs.clear()
+        order = [0, 1, 2, 3, 0, 3, 1, 3, 2, 3, 0]     # shape A captured at its 3rd visit, shape B (index 3) at its 3rd
+        for step, j in enumerate(order):
+            out = model(imgs[j])
+            for k in keys:
+                assert torch.equal(out[k], eager[j][k]), (step, j, k)
+        assert sum(1 for e in model._graphs.values() if 'graph' in e) == 2
+    model._graphs.clear()

@@ -15,6 +15,7 @@ Two execution styles produce identical results:
 """
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,6 +44,9 @@ class resnet_upsnet(resnet_rcnn):
         # semantic head on a side stream, concurrent with the detection chain (a CU-masked side stream that keeps a few CUs
         # free for the latency-bound kernels was measured too: 66-75 img/s vs 80-81, so it is an ordinary stream)
         self.overlap_streams = os.environ.get('UPSNET_OVERLAP', '1') != '0'
+        # the static-shape part of the forward (everything before the first host read) replayed as one HIP graph
+        self.use_graph = os.environ.get('UPSNET_GRAPH', '1') != '0'
+        self._graphs = {}
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
         self.num_classes = config.dataset.num_classes
         self.num_seg_classes = config.dataset.num_seg_classes
@@ -107,6 +111,18 @@ class resnet_upsnet(resnet_rcnn):
             _SIDE[dev] = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
         return _SIDE[dev]
 
+    def __deepcopy__(self, memo):
+        """Deep copies (oracle.forward.cpu_copy) carry the weights, not the captured HIP graphs."""
+        import copy
+        graphs, self._graphs = self._graphs, {}
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            new.__dict__ = copy.deepcopy(self.__dict__, memo)
+        finally:
+            self._graphs = graphs
+        return new
+
     def _tap(self, **kw):
         if self.taps is not None:
             self.taps.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else
@@ -120,33 +136,33 @@ class resnet_upsnet(resnet_rcnn):
         return self._forward_fused(data)
 
     # ------------------------------------------------------------------ MI355X pipeline
-    def _forward_fused(self, data):
-        pyramid = self._pyramid(data)
+    def _phase1(self, x, im_info):
+        """Everything up to the first host read (static shapes: fixed-capacity ROI / detection buffers + device counters), on the
+        current stream + the side stream; returns device tensors only. Capturable as one HIP graph."""
+        pyramid = self._pyramid({'data': x})
         feats = list(pyramid[:4])
-        im_info = data['im_info']
         # x4 upsampling of the semantic logits is fused into the panoptic kernel (enable_void branch, rate 4)
         fuse_up = self.enable_void and self.fcn_head.upsample_rate == 4
         # The semantic head (offset convs + deformable convs, ~2 ms of MFMA-bound work) depends only on the FPN outputs; the
         # proposal -> box head -> detection-selection chain (~2 ms, a dozen latency-bound single-workgroup kernels) depends only on
         # the RPN. The RPN convolution (MFMA-bound itself) runs first on its own; then the semantic head is issued on a side
-        # stream so that it overlaps with that chain; the main stream joins it before the panoptic fusion.
+        # stream so that it overlaps with that chain; the main stream joins it at the end of this phase.
         _, rpn_bbox_pred, rpn_cls_prob = rpn_forward_levels(self.rpn, list(pyramid))
         main = torch.cuda.current_stream()
         side, ev_fork, ev_join = self._side_stream() if self.overlap_streams else (main, None, None)
+        capturing = torch.cuda.is_current_stream_capturing()
         if side is not main:
             ev_fork.record(main)
             side.wait_event(ev_fork)
         with torch.cuda.stream(side):
             if fuse_up:
-                fcn_score = self.fcn_head.forward_score(*feats)
-                fcn_output = None
-                H, W = fcn_score.shape[2] * 4, fcn_score.shape[3] * 4
+                fcn = self.fcn_head.forward_score(*feats)
             else:
-                fcn_output = self.fcn_head(*feats)['fcn_output']
-                H, W = fcn_output.shape[2:]
+                fcn = self.fcn_head(*feats)['fcn_output']
             if side is not main:
                 ev_join.record(side)
-                (fcn_score if fuse_up else fcn_output).record_stream(main)
+                if not capturing:
+                    fcn.record_stream(main)
 
         rois, _, n_rois = self.pyramid_proposal.forward_padded(rpn_cls_prob, rpn_bbox_pred, im_info)
         rcnn_output = self.rcnn(feats, rois, n_rois)
@@ -154,15 +170,64 @@ class resnet_upsnet(resnet_rcnn):
         bbox_pred = rcnn_output['bbox_pred']
         self._tap(rpn_cls_prob=rpn_cls_prob, rpn_bbox_pred=rpn_bbox_pred,
                   im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
-        # both detection selections are launched back to back; ONE host read of the two counters
+        # both detection selections are launched back to back; ONE host read of the counters (in forward)
         det_boxes, det_scores, det_cls, det_src, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
         pan_boxes, pan_scores, pan_cls, pan_src, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
         # The two selections overlap heavily (same (ROI, class) -> box table): panoptic detections that are also per-class
         # detections reuse the mask logits computed for those (bit-identical, every ROI goes through the head independently)
         pan_row, extra_boxes, extra_num = ops.mask_roi_dedup(det_src, det_cls, det_num, pan_src, pan_cls, pan_boxes, pan_num)
-        n_det, n_pan, n_extra = torch.cat([det_num, pan_num, extra_num]).tolist()
-        det_boxes, det_scores, det_cls = det_boxes[:n_det], det_scores[:n_det], det_cls[:n_det]
-        pan_boxes, pan_scores, pan_cls = pan_boxes[:n_pan], pan_scores[:n_pan], pan_cls[:n_pan]
+        nums = torch.cat([det_num, pan_num, extra_num])
+        if side is not main:
+            main.wait_event(ev_join)
+        return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
+                    pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums)
+
+    def _phase1_graphed(self, x, im_info_host):
+        """HIP-graph replay of _phase1 for this input shape / im_info: the ~150 launches of the trunk, the semantic head (side
+        stream) and the proposal / detection chain cost one hipGraphLaunch on the host. The first two images of a shape run
+        eagerly (weight packing, function attributes, library handles), the third is captured."""
+        key = (tuple(x.shape), x.dtype, x.is_contiguous(), tuple(float(v) for v in np.asarray(im_info_host).reshape(-1)))
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {'seen': 0}
+        if 'graph' not in ent:
+            ent['seen'] += 1
+            if ent['seen'] <= 2:
+                return None
+            static_x = x.clone()
+            static_im = torch.from_numpy(np.asarray(im_info_host, dtype=np.float32).reshape(-1)[:3].copy()).to(x.device)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    out = self._phase1(static_x, static_im)
+            except Exception as e:   # capture not possible on this stack: stay eager, say so once
+                import warnings
+                warnings.warn("upsnet_amd: HIP graph capture failed (%s); running eagerly" % (e,))
+                self.use_graph = False
+                return None
+            ent.update(graph=g, x=static_x, im_info=static_im, out=out)   # (the graph reads both static inputs by address)
+        ent['x'].copy_(x)
+        ent['graph'].replay()
+        return ent['out']
+
+    def _forward_fused(self, data):
+        x, im_info = data['data'], data['im_info']
+        st = None
+        if self.use_graph and self.taps is None and not ops.PROFILE['enabled'] and x.is_cuda:
+            st = self._phase1_graphed(x, im_info)
+        graphed = st is not None
+        if st is None:
+            st = self._phase1(x, im_info)
+        feats, fuse_up = st['feats'], st['fuse_up']
+        fcn_score, fcn_output = (st['fcn'], None) if fuse_up else (None, st['fcn'])
+        H, W = (fcn_score.shape[2] * 4, fcn_score.shape[3] * 4) if fuse_up else fcn_output.shape[2:]
+        n_det, n_pan, n_extra = st['nums'].tolist()
+        det_boxes, det_scores, det_cls = st['det_boxes'][:n_det], st['det_scores'][:n_det], st['det_cls'][:n_det]
+        if graphed:   # results handed to the caller must not alias the graph's static buffers (overwritten by the next replay)
+            det_boxes, det_scores, det_cls = det_boxes.clone(), det_scores.clone(), det_cls.clone()
+        pan_boxes, pan_scores, pan_cls = st['pan_boxes'][:n_pan], st['pan_scores'][:n_pan], st['pan_cls'][:n_pan]
+        pan_row, extra_boxes = st['pan_row'], st['extra_boxes']
 
         # one mask-head pass over the union of both ROI sets (same weights)
         mask_score = self.mask_branch(feats, torch.cat([det_boxes, extra_boxes[:n_extra]], 0) if n_extra else det_boxes)
@@ -175,8 +240,6 @@ class resnet_upsnet(resnet_rcnn):
         keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
         cmap = self.seg_term.class_map.to(pan_boxes.device)
-        if side is not main:
-            main.wait_event(ev_join)
         if fuse_up:
             self._tap(fcn_score=fcn_score)
         else:
