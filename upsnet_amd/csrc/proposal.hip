@@ -5,9 +5,12 @@
 // times with a malloc + H2D + D2H each; modules/pyramid_proposal.py:61-67 then re-sorts on the GPU.
 //
 // Here: (1) prop_key_kernel turns every anchor score into a unique sortable 64-bit key in the
-// reference's (h, w, a) enumeration order; (2) a tournament of LDS bitonic sorts (8192-key chunks,
-// each emits its top-k) reduces every level to its sorted top pre_nms_top_n -- rule (ii) of the
-// oracle: (score desc, anchor index asc); (3) prop_decode_kernel applies bbox_transform + clip_boxes
+// reference's (h, w, a) enumeration order; (2) an exact radix SELECT finds each level's k-th largest key
+// (k = pre_nms_top_n): six digit passes (5 x 11 + 9 bits) of many small workgroups -- 8 KiB LDS histogram each,
+// merged with global atomics -- and a one-workgroup-per-level pick kernel in between; the k survivors are
+// compacted and sorted (one 1024-key LDS bitonic sort per level) -- rule (ii) of the oracle: (score desc, anchor
+// index asc). Passes become no-ops as soon as a level's threshold is decided (normally after the 32 score bits);
+// (3) prop_decode_kernel applies bbox_transform + clip_boxes
 // to the survivors only; (4) the batched NMS of nms.hip handles all levels at once; (5)
 // prop_merge_kernel concatenates the kept boxes per level and ranks them (score desc, concatenation
 // index asc). No host synchronisation anywhere.
@@ -32,11 +35,27 @@ struct PropLevels {
     int nlev, A;
 };
 
+// selection state of one level
+struct PropSel {
+    ups_u64 prefix;      // decided high bits of the k-th largest key (lower bits zero)
+    unsigned need;       // how many keys are still to be taken from the keys that match `prefix`
+    unsigned done;       // threshold final: every key >= prefix is selected
+    unsigned cnt;        // compaction counter
+    unsigned pad;
+};
+
+#define PROP_BINS 2048
+
 // scores [A,H,W] (NCHW) -> keys at (h*W + w)*A + a
 __global__ void __launch_bounds__(256)
-prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys)
+prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys, PropSel *__restrict__ sel, const int k)
 {
     const int l = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PropSel st;
+        st.prefix = 0; st.need = (unsigned)k; st.done = 0; st.cnt = 0; st.pad = 0;
+        sel[l] = st;
+    }
     const int n = lv.n[l], A = lv.A;
     const long hw = (long)lv.H[l] * lv.W[l];
     const float *__restrict__ s = lv.cls[l];
@@ -49,79 +68,110 @@ prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys)
     }
 }
 
-struct PropStage {
-    long in_off[PROP_MAXLEV], out_off[PROP_MAXLEV];
-    int n_in[PROP_MAXLEV];
-    int chunk_start[PROP_MAXLEV + 1];
-    int nlev, k;
-};
+// digit histogram of the keys that still match the decided prefix; hi = shift + bits of this pass (64 in pass 0)
+__global__ void __launch_bounds__(256)
+prop_hist_kernel(const PropLevels lv, const ups_u64 *__restrict__ keys, const PropSel *__restrict__ sel, unsigned *__restrict__ hist,
+                 const int shift, const int hi)
+{
+    __shared__ unsigned s_hist[PROP_BINS];
+    const int l = blockIdx.y;
+    const PropSel st = sel[l];
+    if (st.done) return;
+    for (int i = threadIdx.x; i < PROP_BINS; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    const int n = lv.n[l];
+    const ups_u64 *__restrict__ src = keys + lv.key_off[l];
+    const unsigned mask = (1u << (hi - shift)) - 1u;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)blockDim.x * gridDim.x) {
+        const ups_u64 key = src[i];
+        if (hi >= 64 || ((key ^ st.prefix) >> hi) == 0) atomicAdd(&s_hist[(unsigned)(key >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PROP_BINS; i += blockDim.x) {
+        const unsigned v = s_hist[i];
+        if (v) atomicAdd(&hist[(long)l * PROP_BINS + i], v);
+    }
+}
 
-// one workgroup per chunk: top k of <= PROP_CH unique keys, sorted descending, zero-padded.
-// k <= PROP_SELK: exact radix select of the k-th largest key (8 passes of 8 bits over the keys in LDS, per-wave
-// private histograms), compaction of the k survivors, bitonic sort of just those; otherwise a full bitonic sort.
-#define PROP_SELK 2048
-__global__ void __launch_bounds__(1024)
-prop_topk_stage_kernel(const PropStage st, const ups_u64 *__restrict__ in, ups_u64 *__restrict__ out)
+// one workgroup per level: the bin that holds the k-th largest key among the matching ones; clears the histogram
+__global__ void __launch_bounds__(256)
+prop_pick_kernel(PropSel *__restrict__ sel, unsigned *__restrict__ hist, const int shift, const int last)
+{
+    __shared__ unsigned s_hist[PROP_BINS], s_part[256];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    unsigned *h = hist + (long)l * PROP_BINS;
+    PropSel st = sel[l];
+    unsigned part = 0;
+    for (int q = 0; q < PROP_BINS / 256; ++q) {
+        const unsigned v = h[tid * (PROP_BINS / 256) + q];
+        s_hist[tid * (PROP_BINS / 256) + q] = v;
+        part += v;
+        h[tid * (PROP_BINS / 256) + q] = 0;
+    }
+    s_part[tid] = part;
+    __syncthreads();
+    if (st.done) return;
+    unsigned above = 0;   // keys in the bins of higher threads
+    for (int u = tid + 1; u < 256; ++u) above += s_part[u];
+    if (tid == 0 && above + part < st.need) {   // fewer matching keys than needed (level smaller than k): take everything
+        st.done = 1;
+        sel[l] = st;
+    }
+    if (above < st.need && st.need <= above + part) {   // the wanted key is in one of this thread's bins
+        unsigned cum = above;
+        for (int q = PROP_BINS / 256 - 1; q >= 0; --q) {
+            const int bin = tid * (PROP_BINS / 256) + q;
+            const unsigned v = s_hist[bin];
+            if (cum + v >= st.need) {
+                st.prefix |= (ups_u64)bin << shift;
+                st.need -= cum;
+                if (v == st.need || last) st.done = 1;   // the whole bin is wanted: all lower bits are free
+                sel[l] = st;
+                break;
+            }
+            cum += v;
+        }
+    }
+}
+
+// survivors (key >= threshold) -> out[l][0..k), unordered; one atomic per wave
+__global__ void __launch_bounds__(256)
+prop_compact_kernel(const PropLevels lv, const ups_u64 *__restrict__ keys, PropSel *__restrict__ sel, ups_u64 *__restrict__ out,
+                    const int k)
+{
+    const int l = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = lv.n[l];
+    const ups_u64 thr = sel[l].prefix;
+    const ups_u64 *__restrict__ src = keys + lv.key_off[l];
+    ups_u64 *__restrict__ dst = out + lv.key_off[l];
+    const long stride = (long)blockDim.x * gridDim.x;
+    for (long i0 = (long)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const long i = i0 + threadIdx.x;
+        const ups_u64 key = i < n ? src[i] : 0ULL;
+        const bool take = key != 0ULL && key >= thr;
+        const unsigned long long bal = __ballot(take);
+        if (bal) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&sel[l].cnt, (unsigned)__builtin_popcountll(bal));
+            base = __shfl(base, 0);
+            const unsigned pos = base + (unsigned)__builtin_popcountll(bal & ((1ULL << lane) - 1ULL));
+            if (take && pos < (unsigned)k) dst[pos] = key;
+        }
+    }
+}
+
+// one workgroup per level: sort the (<= k) survivors descending, zero-pad to k
+__global__ void __launch_bounds__(256)
+prop_sortk_kernel(const PropLevels lv, const PropSel *__restrict__ sel, ups_u64 *__restrict__ out, const int k, const int M)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);            // [PROP_CH]
-    ups_u64 *sel = keys + PROP_CH;                                     // [PROP_SELK]
-    unsigned *whist = reinterpret_cast<unsigned *>(sel + PROP_SELK);   // [16 waves][256]
-    __shared__ unsigned hist[256];
-    __shared__ ups_u64 s_prefix;
-    __shared__ unsigned s_need, s_cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-    int l = 0;
-    for (int q = 1; q < st.nlev; ++q) if ((int)blockIdx.x >= st.chunk_start[q]) l = q;
-    const int chunk = blockIdx.x - st.chunk_start[l];
-    const long base = (long)chunk * PROP_CH;
-    const int cn = (int)min((long)PROP_CH, (long)st.n_in[l] - base);
-    const int k = st.k;
-    const ups_u64 *__restrict__ src = in + st.in_off[l] + base;
-    ups_u64 *__restrict__ dst = out + st.out_off[l] + (long)chunk * k;
-    if (cn <= k || k > PROP_SELK) {
-        const int M = ups_next_pow2(cn < 64 ? 64 : cn);
-        for (int i = tid; i < M; i += blockDim.x) keys[i] = i < cn ? src[i] : 0ULL;
-        ups_block_sort_desc(keys, M);
-        for (int i = tid; i < k; i += blockDim.x) dst[i] = i < cn ? keys[i] : 0ULL;
-        return;
-    }
-    for (int i = tid; i < cn; i += blockDim.x) keys[i] = src[i];
-    if (tid == 0) { s_prefix = 0; s_need = (unsigned)k; s_cnt = 0; }
-    __syncthreads();
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        for (int i = lane; i < 256; i += 64) whist[wave * 256 + i] = 0;
-        __syncthreads();
-        const ups_u64 prefix = s_prefix;
-        for (int i = tid; i < cn; i += blockDim.x) {
-            const ups_u64 key = keys[i];
-            if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&whist[wave * 256 + (unsigned)((key >> shift) & 255ULL)], 1u);
-        }
-        __syncthreads();
-        if (tid < 256) { unsigned t = 0; for (int w = 0; w < nwave; ++w) t += whist[w * 256 + tid]; hist[tid] = t; }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned need = s_need;
-            int b = 255;
-            for (; b > 0; --b) { if (hist[b] >= need) break; need -= hist[b]; }
-            s_prefix = prefix | ((ups_u64)b << shift);
-            s_need = need;
-        }
-        __syncthreads();
-    }
-    const ups_u64 thr = s_prefix;   // the k-th largest key (keys are unique)
-    for (int i = tid; i < cn; i += blockDim.x) {
-        const ups_u64 key = keys[i];
-        // zero keys are padding from the previous stage (never selected; real keys are unique and non-zero)
-        if (key >= thr && key != 0ULL) { const unsigned pos = atomicAdd(&s_cnt, 1u); if (pos < (unsigned)PROP_SELK) sel[pos] = key; }
-    }
-    __syncthreads();
-    const int M2 = ups_next_pow2(k < 64 ? 64 : k);
-    const int got = (int)min(s_cnt, (unsigned)k);   // == k unless fewer than k real keys exist
-    for (int i = got + tid; i < M2; i += blockDim.x) sel[i] = 0ULL;
-    ups_block_sort_desc(sel, M2);
-    for (int i = tid; i < k; i += blockDim.x) dst[i] = sel[i];
+    ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);
+    const int l = blockIdx.x;
+    const int c = (int)min(sel[l].cnt, (unsigned)k);
+    ups_u64 *__restrict__ buf = out + lv.key_off[l];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) keys[i] = i < c ? buf[i] : 0ULL;
+    ups_block_sort_desc(keys, M);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) buf[i] = keys[i];
 }
 
 // bbox_transform + clip_boxes + _filter_boxes on each level's sorted top-k keys (found via lv.key_off)
@@ -213,7 +263,7 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PropPlan {
     long key_total;      // keys per ping-pong buffer
-    size_t off_keys0, off_keys1, off_boxes, off_scores, off_pre, off_counts, off_keep, off_keepcnt, off_nms, total;
+    size_t off_keys0, off_keys1, off_boxes, off_scores, off_pre, off_counts, off_keep, off_keepcnt, off_hist, off_sel, off_nms, total;
 };
 
 static PropPlan prop_plan(int nlev, const int *H, const int *W, int A, int pre_n)
@@ -236,6 +286,8 @@ static PropPlan prop_plan(int nlev, const int *H, const int *W, int A, int pre_n
     p.off_counts = o; o += 256;
     p.off_keep = o; o += al256((size_t)nlev * pre_n * 4);
     p.off_keepcnt = o; o += 256;
+    p.off_hist = o; o += al256((size_t)nlev * PROP_BINS * 4);
+    p.off_sel = o; o += al256((size_t)nlev * sizeof(PropSel));
     p.off_nms = o; o += upsnet_nms_workspace_bytes(nlev, pre_n);
     p.total = o + 256;
     return p;
@@ -295,44 +347,38 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     }
     int gx = (maxn + 255) / 256;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(prop_key_kernel, dim3(gx, nlev), dim3(256), 0, st, lv, kbuf[0]);
+    unsigned *hist = (unsigned *)(ws + plan.off_hist);
+    PropSel *sel = (PropSel *)(ws + plan.off_sel);
+    UPS_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)nlev * PROP_BINS * 4, st));
+    hipLaunchKernelGGL(prop_key_kernel, dim3(gx, nlev), dim3(256), 0, st, lv, kbuf[0], sel, pre_n);
     UPS_CHECK_LAUNCH("prop_key_kernel");
 
-    // tournament: repeat until every level is a single sorted chunk of k = pre_n keys
-    const size_t stage_smem = (size_t)PROP_CH * 8 + (size_t)PROP_SELK * 8 + 16 * 256 * 4;
-    {
+    // exact radix select of every level's pre_n-th largest key: 64 bits in digits of 11,11,11,11,11,9
+    int gh = (maxn + 256 * 8 - 1) / (256 * 8);   // ~8 keys per thread
+    if (gh > 512) gh = 512;
+    if (gh < 1) gh = 1;
+    static const int digit_shift[6] = {53, 42, 31, 20, 9, 0}, digit_hi[6] = {64, 53, 42, 31, 20, 9};
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(prop_hist_kernel, dim3(gh, nlev), dim3(256), 0, st, lv, kbuf[0], sel, hist, digit_shift[pass], digit_hi[pass]);
+        UPS_CHECK_LAUNCH("prop_hist_kernel");
+        hipLaunchKernelGGL(prop_pick_kernel, dim3(nlev), dim3(256), 0, st, sel, hist, digit_shift[pass], pass == 5 ? 1 : 0);
+        UPS_CHECK_LAUNCH("prop_pick_kernel");
+    }
+    hipLaunchKernelGGL(prop_compact_kernel, dim3(gh, nlev), dim3(256), 0, st, lv, kbuf[0], sel, kbuf[1], pre_n);
+    UPS_CHECK_LAUNCH("prop_compact_kernel");
+    const int M2 = ups_next_pow2(pre_n < 64 ? 64 : pre_n);
+    if ((size_t)M2 * 8 > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_topk_stage_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_smem));
+            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_sortk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              PROP_CH * 8));
             attr_set = true;
         }
     }
-    int cur = 0;
-    int n_in[PROP_MAXLEV];
-    for (int l = 0; l < nlev; ++l) n_in[l] = lv.n[l];
-    for (int iter = 0; iter < 8; ++iter) {
-        PropStage sg;
-        sg.nlev = nlev; sg.k = pre_n;
-        int chunks_total = 0;
-        bool more = false;
-        for (int l = 0; l < nlev; ++l) {
-            sg.in_off[l] = seg_off[l]; sg.out_off[l] = seg_off[l];
-            sg.n_in[l] = n_in[l];
-            sg.chunk_start[l] = chunks_total;
-            int c = (n_in[l] + PROP_CH - 1) / PROP_CH;
-            chunks_total += c;
-            n_in[l] = c * pre_n;
-            if (c > 1) more = true;
-        }
-        sg.chunk_start[nlev] = chunks_total;
-        hipLaunchKernelGGL(prop_topk_stage_kernel, dim3(chunks_total), dim3(1024), stage_smem, st, sg, kbuf[cur],
-                           kbuf[cur ^ 1]);
-        UPS_CHECK_LAUNCH("prop_topk_stage_kernel");
-        cur ^= 1;
-        if (!more) break;
-    }
-    // after the last stage every level holds exactly one chunk: pre_n sorted keys at seg_off[l]
+    hipLaunchKernelGGL(prop_sortk_kernel, dim3(nlev), dim3(256), (size_t)M2 * 8, st, lv, sel, kbuf[1], pre_n, M2);
+    UPS_CHECK_LAUNCH("prop_sortk_kernel");
+    const int cur = 1;
+    // every level now holds its pre_n sorted keys (zero padded) at key_off[l] of kbuf[1]
     hipLaunchKernelGGL(prop_decode_kernel, dim3((pre_n + 255) / 256, nlev), dim3(256), 0, st, lv, kbuf[cur], pre_n, im_info,
                        min_size, boxes, scores, pre_removed, counts);
     UPS_CHECK_LAUNCH("prop_decode_kernel");
