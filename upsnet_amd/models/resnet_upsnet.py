@@ -151,6 +151,9 @@ class resnet_upsnet(resnet_rcnn):
         main = torch.cuda.current_stream()
         side, ev_fork, ev_join = self._side_stream() if self.overlap_streams else (main, None, None)
         capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and side is not main:
+            # events recorded inside a capture belong to that graph: never share them with the eager path
+            ev_fork, ev_join = torch.cuda.Event(), torch.cuda.Event()
         if side is not main:
             ev_fork.record(main)
             side.wait_event(ev_fork)
@@ -180,7 +183,8 @@ class resnet_upsnet(resnet_rcnn):
         if side is not main:
             main.wait_event(ev_join)
         return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
-                    pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums)
+                    pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
+                    _events=(ev_fork, ev_join))
 
     def _phase1_graphed(self, x, im_info_host):
         """HIP-graph replay of _phase1 for this input shape / im_info: the ~150 launches of the trunk, the semantic head (side
