@@ -24,17 +24,27 @@ WINOGRAD_MIN_WORKGROUPS = 256
 # configs[2]: bf16 products, fp32 accumulation). The stem, the deconvolution, the FPN top-down laterals and the deformable
 # convolutions always use the fp32 kernel.
 PRECISION = os.environ.get('UPSNET_CONV_PRECISION', 'fp32')
-_cache = {}
+
+
+def _plans(m):
+    """Packed-weight cache of ONE module, stored on the module itself. (A process-wide dict keyed by id(module) is unsafe: the id
+    -- and with the caching allocator even the weight's address -- of a freed model's layer can be reused by a different layer
+    of a later model, and a stale pack of another shape makes the kernel read out of bounds.)"""
+    d = m.__dict__.get('_hip_plans')
+    if d is None:
+        d = m.__dict__['_hip_plans'] = {}
+    return d
+
 
 
 def _plan(m):
     w = m.weight
-    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
-    ent = _cache.get(id(m))
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('direct')
     if ent is None or ent[0] != key:
         wp, ldw = ops.pack_conv_weight(w.detach())
         ent = (key, wp, ldw)
-        _cache[id(m)] = ent
+        _plans(m)['direct'] = ent
     return ent[1], ent[2]
 
 
@@ -46,21 +56,21 @@ def supported(m, x):
 
 def _bf16_plan(m):
     w = m.weight
-    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version, PRECISION)
-    ent = _cache.get(('bf16', id(m)))
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version, PRECISION)
+    ent = _plans(m).get('bf16')
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_conv_weight_bf16(w.detach(), split=(PRECISION == 'bf16x3'))
-        _cache[('bf16', id(m))] = ent
+        _plans(m)['bf16'] = ent
     return ent[1], ent[2], ent[3]
 
 
 def _winograd_plan(m):
     w = m.weight
-    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
-    ent = _cache.get(('wino', id(m)))
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('wino')
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_winograd_weight(w.detach())
-        _cache[('wino', id(m))] = ent
+        _plans(m)['wino'] = ent
     return ent[1], ent[2]
 
 
@@ -120,11 +130,11 @@ def conv_stem(m, x, relu=False):
         y = m(x[:, :m.in_channels] if x.shape[1] != m.in_channels else x)
         return F.relu(y, inplace=True) if relu else y
     w = m.weight
-    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
-    ent = _cache.get(('stem', id(m)))
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('stem')
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_stem_weight(w.detach())
-        _cache[('stem', id(m))] = ent
+        _plans(m)['stem'] = ent
     is_nhwc4 = x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last)
     x4 = x if is_nhwc4 else ops.image_to_nhwc4(x)
     return ops.conv2d_stem(x4, ent[1], ent[2], m.bias, m.out_channels, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0], relu=relu)
@@ -139,13 +149,16 @@ def deconv2x2(m, x, relu=False):
         y = m(x)
         return F.relu(y, inplace=True) if relu else y
     w = m.weight
-    key = (w.data_ptr(), w._version, None if m.bias is None else m.bias._version)
-    ent = _cache.get(('deconv', id(m)))
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('deconv')
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_deconv2x2_weight(w.detach())
-        _cache[('deconv', id(m))] = ent
+        _plans(m)['deconv'] = ent
     return ops.deconv2x2(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
 
 
-def clear_cache():
-    _cache.clear()
+def clear_cache(model=None):
+    """Drop the packed weights of every layer of `model` (they are rebuilt on next use)."""
+    if model is not None:
+        for m in model.modules():
+            m.__dict__.pop('_hip_plans', None)
