@@ -88,6 +88,7 @@ class resnet_upsnet(resnet_rcnn):
         if channels_last:
             self.to(memory_format=torch.channels_last)
         self._channels_last = channels_last
+        self.invalidate_graphs()
         return self
 
     # ------------------------------------------------------------------ shared trunk
@@ -122,6 +123,15 @@ class resnet_upsnet(resnet_rcnn):
         finally:
             self._graphs = graphs
         return new
+
+    def invalidate_graphs(self):
+        """Drop the captured HIP graphs (they hold the addresses of the packed weights of capture time). Called by
+        load_state_dict / prepare_inference; call it yourself after modifying parameters in place."""
+        self._graphs = {}
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_graphs()
+        return super().load_state_dict(*args, **kwargs)
 
     def _tap(self, **kw):
         if self.taps is not None:
