@@ -120,6 +120,15 @@ int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const x[], const
                            const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
                            int relu, int residual_up);
 
+/* upsnet_conv2d_nhwc_f32 for ONE small feature map (res4 / res5: 2048-8192 pixels = too few 64x64 tiles to fill 256 CUs): the
+ * K walk is split over ksplit (2..8) workgroups per tile, raw partial sums go to `workspace`
+ * (upsnet_conv2d_splitk_workspace_bytes) and a second kernel adds them in a fixed order with the bias / residual / ReLU
+ * epilogue -- deterministic, differs from the unsplit kernel only by fp32 summation order. */
+size_t upsnet_conv2d_splitk_workspace_bytes(int batch, int height, int width, int Cout, int KH, int KW, int stride, int pad, int ksplit);
+int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
+                                  int Cin, const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride,
+                                  int pad, int relu, int ksplit, void *workspace);
+
 /* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2, 3x3) on the same MFMA kernel (16/36 of the multiplies of the
  * direct form; all arithmetic fp32; differs from the direct kernel by fp32 rounding only, ~1e-6 relative -- cuDNN, the
  * reference's convolution backend, uses the same algorithm). The input transform (a signed sum of four pixels per

@@ -161,3 +161,28 @@ def test_conv_bf16_matrix_cores_vs_torch(N, Cin, Cout, H, W, k, stride, pad, rel
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol)
     again = ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, b, Cout, k, stride, pad, relu=relu, residuals=None if r is None else [r])[0]
     assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,ksplit,relu,res", [
+    (1, 256, 256, 64, 128, 3, 1, 2, True, False), (1, 512, 512, 32, 64, 3, 1, 4, True, False), (1, 2048, 512, 32, 64, 1, 1, 4, True, False),
+    (1, 1024, 256, 17, 23, 1, 1, 3, False, True), (2, 64, 128, 9, 9, 3, 2, 2, True, True),
+])
+def test_conv_splitk_vs_unsplit(N, Cin, Cout, H, W, k, stride, ksplit, relu, res):
+    """Split-K instances (small maps): same result as the unsplit kernel up to fp32 summation order, 1e-4 vs fp64; bit-repeatable."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, k, k, device='cuda') / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=k // 2)
+    r = torch.randn_like(ref).float() if res else None
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    wp, ldw = ops.pack_conv_weight(w)
+    out = ops.conv2d_nhwc_splitk(x, wp, ldw, b, Cout, k, stride, k // 2, ksplit, relu=relu, residual=r)
+    one = ops.conv2d_nhwc(x, wp, ldw, b, Cout, k, stride, k // 2, relu=relu, residual=r)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert float((out - one).abs().max()) < 2e-5
+    assert torch.equal(out, ops.conv2d_nhwc_splitk(x, wp, ldw, b, Cout, k, stride, k // 2, ksplit, relu=relu, residual=r))

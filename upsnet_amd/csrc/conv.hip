@@ -182,10 +182,13 @@ conv_igemm_f32_kernel(const ConvParams p)
     // XCD-aware tile order. Workgroup b is observed to run on XCD b % 8 (speed only, never correctness). Each XCD gets
     // a CONTIGUOUS range of m-tiles (so the 3x3 / bilinear halos of vertically adjacent tiles hit the same 4 MiB L2)
     // and all n-tiles of an m-tile (they share the A panel) stay on that XCD.
-    int m_t, n_t;
+    int m_t, n_t, kz;
     {
-        const int bid = blockIdx.x, nt = p.n_tiles;
+        const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
+        const int base_grid = 8 * per * nt;
+        kz = RESUP == 3 ? (int)blockIdx.x / base_grid : 0;   // split-K part of this workgroup
+        const int bid = (int)blockIdx.x - kz * base_grid;
         const int q = bid >> 3;
         n_t = q % nt;
         const int local = q / nt;
@@ -215,7 +218,10 @@ conv_igemm_f32_kernel(const ConvParams p)
             pix_p[r] = pp;
         } else { pix_n[r] = -1; pix_h[r] = 0; pix_w[r] = 0; pix_p[r] = -1; }
     }
-    const int nslabs = ntap * (p.Cin / BK);
+    const int nslabs_all = ntap * (p.Cin / BK);
+    const int s_per = RESUP == 3 ? (nslabs_all + p.ksplit - 1) / p.ksplit : nslabs_all;
+    const int s_begin = kz * s_per;
+    const int nslabs = max(min(nslabs_all - s_begin, s_per), 0);   // slabs walked by this workgroup (split-K: its share)
 
     floatx16 acc[WM][WN];
 #pragma unroll
@@ -238,6 +244,14 @@ conv_igemm_f32_kernel(const ConvParams p)
     unsigned oa0 = 0, oa1 = 0, oa2 = 0, oa3 = 0;               // dense: byte offset of this thread's float4 per pixel
     bool cv0 = false, cv1 = false, cv2 = false, cv3 = false;   // dense: tap inside the image
     int f_cs = 0, f_tap = 0, f_ki = 0, f_kj = 0;               // (channel slab, tap) of the NEXT slab to fetch
+    if (RESUP == 3) {   // split-K: start the K walk at slab s_begin
+        const int cslabs = p.Cin / BK;
+        f_tap = s_begin / cslabs;
+        f_cs = (s_begin - f_tap * cslabs) * BK;
+        f_ki = f_tap / p.KW;
+        f_kj = f_tap - f_ki * p.KW;
+        ob += (unsigned)s_begin * (unsigned)BK * ldw4;
+    }
     bool f_newtap = true;
     float4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;             // dense register set X
     float4 ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3;             // dense register set Y
@@ -270,7 +284,7 @@ conv_igemm_f32_kernel(const ConvParams p)
         cv##R = pix_n[R] >= 0 && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;                                        \
         const int hc = min(max(hi, 0), sg.H - 1), wc = min(max(wi, 0), sg.W - 1), nc = max(pix_n[R], 0);             \
         oa##R = STEM ? 16u * (unsigned)((nc * sg.H + hc) * sg.W + wc)                                                 \
-                     : 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + 4 * ch4);                             \
+                     : 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + f_cs + 4 * ch4);                      \
     }
 #define CV_TAP_DEFORM(R)                                                                                              \
     d##R = dcn_desc(sg, pix_p[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, f_tap, ntap,                      \
@@ -537,6 +551,31 @@ conv_igemm_f32_kernel(const ConvParams p)
         }
         return;
     }
+    if (RESUP == 3) {
+        // ---- split-K: raw partial sums to the workspace; bias / residual / ReLU are applied by conv_splitk_reduce_kernel
+        if (nslabs <= 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        float *part = p.partial + ((long)kz * p.m_total + (long)sg.tile_start * BM) * p.Cout;   // maps are concatenated tile-aligned
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int co = n0 + wn * (WN * 32) + 32 * j + aij;
+                const long pbase = p0 + wm * (WM * 32) + 32 * i + 4 * akr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long pp = pbase + (r & 3) + 8 * (r >> 2);
+                    if (co < p.Cout && pp < sg.M) part[pp * p.Cout + co] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     // ---- fused epilogue: + bias, + residual, ReLU. Residual values are loaded 16 at a time, unconditionally
     // (clamped row), before any of them is used, so the loads overlap instead of serialising.
     // RESUP 1: the residual lives at half resolution and is read through a nearest x2 upsampling
@@ -634,7 +673,8 @@ static int conv_launch(hipStream_t st, ConvParams &p)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;  // see the XCD-aware tile order in the kernel
+    p.m_total = (long)p.m_tiles * BM;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * (RESUP == 3 ? p.ksplit : 1);  // see the XCD-aware tile order in the kernel
     hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, DEFORM, BK, RESUP>), dim3(grid), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("conv_igemm_f32_kernel");
     return 0;
@@ -665,6 +705,10 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
         UPS_REQUIRE(DEFORM == 0, "conv: this epilogue is only available for dense convolution");
         if (p.res_up == 1) return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 1>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 1>(st, p);
         return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 2>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 2>(st, p);
+    }
+    if (p.ksplit > 1) {   // split-K instances (dense, 64x64 tile): partial sums to the workspace
+        UPS_REQUIRE(DEFORM == 0 && n64, "conv: split-K needs a dense convolution with ldw %% 64 == 0");
+        return conv_launch<1, 1, 2, 2, 0, CV_BK, 3>(st, p);
     }
     if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
     if (DEFORM == 4) {   // (64 tiles x 128 channels was measured: slower, 256 registers + spills)
@@ -715,6 +759,63 @@ extern "C" int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const flo
                        ldw, bias, kh, kw, stride_h, pad_h, dil_h, relu);
     if (rc) return rc;
     return mask ? conv_dispatch<2>((hipStream_t)stream, p) : conv_dispatch<1>((hipStream_t)stream, p);
+}
+
+// split-K reduction + the fused epilogue: out = relu?(sum_z partial[z] + bias + residual), float4 along the channels
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_kernel(const float *__restrict__ partial, const int ksplit, const long m_total, const long M, const int Cout,
+                          const float *__restrict__ bias, const float *__restrict__ res, const int relu, float *__restrict__ out)
+{
+    const int c4n = Cout >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * c4n) return;
+    const long pp = idx / c4n;
+    const int c4 = (int)(idx - pp * c4n);
+    float4 a = reinterpret_cast<const float4 *>(partial + pp * Cout)[c4];
+    for (int z = 1; z < ksplit; ++z) {   // fixed order: bit-repeatable
+        const float4 b = reinterpret_cast<const float4 *>(partial + ((long)z * m_total + pp) * Cout)[c4];
+        a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+    }
+    if (bias) { const float4 b = reinterpret_cast<const float4 *>(bias)[c4]; a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w; }
+    if (res) { const float4 b = reinterpret_cast<const float4 *>(res + pp * Cout)[c4]; a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w; }
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    reinterpret_cast<float4 *>(out + pp * Cout)[c4] = a;
+}
+
+extern "C" size_t upsnet_conv2d_splitk_workspace_bytes(int batch, int height, int width, int Cout, int KH, int KW, int stride, int pad,
+                                                       int ksplit)
+{
+    const long Ho = (height + 2 * pad - KH) / stride + 1, Wo = (width + 2 * pad - KW) / stride + 1;
+    const long M = (long)batch * Ho * Wo;
+    const long m_pad = (M + 63) / 64 * 64;
+    return (size_t)ksplit * m_pad * Cout * sizeof(float);
+}
+
+extern "C" int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
+                                             int Cin, const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride,
+                                             int pad, int relu, int ksplit, void *workspace)
+{
+    const float *xs[1] = {x}, *rs[1] = {residual};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = conv_fill(p, "conv2d_nhwc_f32_splitk", 1, xs, residual ? rs : nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw,
+                       bias, KH, KW, stride, pad, 1, relu);
+    if (rc) return rc;
+    const int nslabs = KH * KW * (Cin / CV_BK);
+    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8, "conv2d_nhwc_f32_splitk: ksplit must be 2..8 and a workspace given");
+    UPS_REQUIRE(((nslabs + ksplit - 1) / ksplit) * (ksplit - 1) < nslabs, "conv2d_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, ksplit);
+    UPS_REQUIRE(Cout % 4 == 0, "conv2d_nhwc_f32_splitk: Cout must be a multiple of 4");
+    p.ksplit = ksplit;
+    p.partial = (float *)workspace;
+    rc = conv_dispatch<0>((hipStream_t)stream, p);
+    if (rc) return rc;
+    const long M = p.seg[0].M;
+    const long n = M * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.partial, ksplit,
+                       p.m_total, M, Cout, bias, residual, relu, out);
+    UPS_CHECK_LAUNCH("conv_splitk_reduce_kernel");
+    return 0;
 }
 
 extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],

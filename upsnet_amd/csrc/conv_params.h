@@ -25,6 +25,9 @@ struct ConvParams {
     int res_up;  // epilogue mode: 1 = residual at half resolution, added through a nearest x2 upsampling (FPN top-down
                  // path); 2 = 2x2 / stride-2 transposed-convolution scatter
     int m_tiles, n_tiles;
+    int ksplit;        // split-K: the K walk is divided over `ksplit` workgroups per tile; each writes raw partial sums
+    float *partial;    // [ksplit][sum of M over the maps][Cout] (workspace), reduced by conv_splitk_reduce_kernel
+    long m_total;      // sum of M over the maps
 };
 
 // Validates the arguments of a convolution entry point and fills the per-map descriptors (output geometry, pixel counts).
@@ -41,6 +44,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
     UPS_REQUIRE((long)KH * KW * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
     p.w = wpack; p.bias = bias; p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu; p.res_up = 0;
+    p.ksplit = 1; p.partial = nullptr; p.m_total = 0;
     int tiles = 0;
     for (int i = 0; i < CV_MAXSEG; ++i) {
         ConvSeg &s = p.seg[i];

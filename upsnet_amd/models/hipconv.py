@@ -19,6 +19,7 @@ ENABLED = True
 # kernel (1.3-1.7x faster there; same fp32 arithmetic class, ~1e-6 relative difference). Smaller layers stay on the direct form.
 WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_WORKGROUPS = 256
+SPLITK = os.environ.get('UPSNET_SPLITK', '1') != '0'
 # Arithmetic of the dense convolutions: 'fp32' (default; exact fp32 products on the fp32 MFMA, the configuration every headline
 # number is measured on), 'bf16x3' (bf16 matrix cores, 3-term split, fp32-equivalent to ~1e-5) or 'bf16' (BASELINE.json
 # configs[2]: bf16 products, fp32 accumulation). The stem, the deconvolution, the FPN top-down laterals and the deformable
@@ -82,6 +83,22 @@ def _use_winograd(m, xs):
     return tiles * (-(-m.out_channels // 64)) >= WINOGRAD_MIN_WORKGROUPS
 
 
+def _ksplit(m, x, ldw):
+    """Split-K factor for maps with too few 64x64 tiles to fill the chip (measured, tools/bench_splitk.py: pays only below
+    ~256 workgroups with a long K walk -- res5 3x3, FPN P5)."""
+    if not SPLITK or ldw % 64 or m.out_channels % 4:
+        return 1
+    k, st, pd = m.kernel_size[0], m.stride[0], m.padding[0]
+    pix = x.shape[0] * ((x.shape[2] + 2 * pd - k) // st + 1) * ((x.shape[3] + 2 * pd - k) // st + 1)
+    blocks = -(-pix // 64) * (ldw // 64)
+    slabs = k * k * m.in_channels // 32
+    if blocks <= 128 and slabs >= 32:
+        return 4
+    if blocks <= 256 and slabs >= 128:
+        return 3
+    return 1
+
+
 def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
     winograd=False pins the direct form (layers whose batch size varies at run time and whose results must not depend on it)."""
@@ -95,6 +112,10 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0]
         wp, ldw = _plan(m)
+        ks = 1 if residual_up else _ksplit(m, x, ldw)
+        if ks > 1:
+            return ops.conv2d_nhwc_splitk(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], ks,
+                                          relu=relu, residual=residual)
         return ops.conv2d_nhwc(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                relu=relu, residual=residual, residual_up=residual_up)
     y = m(x)

@@ -653,3 +653,30 @@ def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, re
         PROFILE['events'].append(('conv_bf16', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
                                   4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1)) + 2.0 * cout * cin * ksize * ksize))
     return outs
+
+
+def conv2d_nhwc_splitk(x, wpack, ldw, bias, cout, ksize, stride, pad, ksplit, relu=False, residual=None):
+    """conv2d_nhwc for one small map with the K walk split over `ksplit` workgroups per tile (+ a reduce/epilogue kernel)."""
+    require_cuda(x, wpack)
+    x = nhwc(x.float())
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    out = _nhwc_out(N, cout, Ho, Wo, x.device)
+    res = None
+    if residual is not None:
+        res = nhwc(residual.float())
+        if tuple(res.shape) != tuple(out.shape):
+            raise RuntimeError("conv2d_nhwc_splitk: residual shape %s != %s" % (tuple(res.shape), tuple(out.shape)))
+    ws = _ws(lib().upsnet_conv2d_splitk_workspace_bytes(N, H, W, int(cout), int(ksize), int(ksize), int(stride), int(pad), int(ksplit)), x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_nhwc_f32_splitk(stream(), ptr(x), ptr(res), ptr(out), N, H, W, C, ptr(wpack), int(ldw),
+                                              ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride),
+                                              int(pad), int(bool(relu)), int(ksplit), ptr(ws)), "conv2d_nhwc_f32_splitk")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * Ho * Wo
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * C * ksize * ksize * npix,
+                                  4.0 * (C * N * H * W + cout * npix * (2 if res is not None else 1) + cout * C * ksize * ksize)))
+    return out
