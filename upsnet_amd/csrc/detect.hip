@@ -150,6 +150,12 @@ mroi_finalize_kernel(const int P, const int nmax, const int max_det, const float
             cnt += tot;
         }
     }
+    // rows [cnt, max_det) are defined (zero boxes): callers may run fixed-size work (the mask head inside the HIP graph) on
+    // the first max_det rows without reading the counter first
+    for (int i = max(cnt, 1) + tid; i < max_det && i < P * nmax; i += DET_T) {
+        for (int q = 0; q < 5; ++q) boxes_out[(long)i * 5 + q] = 0.f;
+        scores_out[i] = 0.f; cls_out[i] = 0; src_out[i] = -1;
+    }
     if (tid == 0) {
         if (cnt == 0) {  // mask_roi.py:135-141
             for (int q = 0; q < 5; ++q) boxes_out[q] = 0.f;

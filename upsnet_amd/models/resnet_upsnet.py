@@ -47,6 +47,7 @@ class resnet_upsnet(resnet_rcnn):
         # the static-shape part of the forward (everything before the first host read) replayed as one HIP graph
         self.use_graph = os.environ.get('UPSNET_GRAPH', '1') != '0'
         self._graphs = {}
+        self.early_mask_head = os.environ.get('UPSNET_EARLY_MASK', '1') != '0'
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
         self.num_classes = config.dataset.num_classes
         self.num_seg_classes = config.dataset.num_seg_classes
@@ -133,6 +134,12 @@ class resnet_upsnet(resnet_rcnn):
         self.invalidate_graphs()
         return super().load_state_dict(*args, **kwargs)
 
+    def _ev_det(self):
+        dev = torch.cuda.current_device()
+        if ('det', dev) not in _SIDE:
+            _SIDE[('det', dev)] = torch.cuda.Event()
+        return _SIDE[('det', dev)]
+
     def _tap(self, **kw):
         if self.taps is not None:
             self.taps.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else
@@ -185,6 +192,22 @@ class resnet_upsnet(resnet_rcnn):
                   im_info=im_info, rois=rois, n_rois=n_rois, cls_prob=cls_prob, bbox_pred=bbox_pred)
         # both detection selections are launched back to back; ONE host read of the counters (in forward)
         det_boxes, det_scores, det_cls, det_src, det_num = self.mask_roi.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
+        # The mask head of the per-class detections starts as soon as they exist -- on the side stream (idle once the semantic
+        # head is done), on the fixed first max_det rows of the padded buffer (rows past the count are zero boxes), i.e. before
+        # the host knows the counts: it overlaps with the second selection, the dedup and the host read instead of following them
+        max_det = min(int(config.test.max_det), det_boxes.shape[0])
+        mask_det = None
+        if self.early_mask_head and max_det > 0:
+            if side is not main:
+                ev_det = torch.cuda.Event() if capturing else self._ev_det()
+                ev_det.record(main)
+                side.wait_event(ev_det)
+            with torch.cuda.stream(side):
+                mask_det = self.mask_branch(feats, det_boxes[:max_det])
+                if side is not main:
+                    ev_join.record(side)   # (re-recorded: the join now also covers the mask head)
+                    if not capturing:
+                        mask_det.record_stream(main)
         pan_boxes, pan_scores, pan_cls, pan_src, pan_num = self.mask_roi_panoptic.forward_padded(rois, bbox_pred, cls_prob, im_info, n_rois)
         # The two selections overlap heavily (same (ROI, class) -> box table): panoptic detections that are also per-class
         # detections reuse the mask logits computed for those (bit-identical, every ROI goes through the head independently)
@@ -194,7 +217,7 @@ class resnet_upsnet(resnet_rcnn):
             main.wait_event(ev_join)
         return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
                     pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
-                    _events=(ev_fork, ev_join))
+                    mask_det=mask_det, max_det=max_det, _events=(ev_fork, ev_join))
 
     def _phase1_graphed(self, x, im_info_host):
         """HIP-graph replay of _phase1 for this input shape / im_info: the ~150 launches of the trunk, the semantic head (side
@@ -243,8 +266,13 @@ class resnet_upsnet(resnet_rcnn):
         pan_boxes, pan_scores, pan_cls = st['pan_boxes'][:n_pan], st['pan_scores'][:n_pan], st['pan_cls'][:n_pan]
         pan_row, extra_boxes = st['pan_row'], st['extra_boxes']
 
-        # one mask-head pass over the union of both ROI sets (same weights)
-        mask_score = self.mask_branch(feats, torch.cat([det_boxes, extra_boxes[:n_extra]], 0) if n_extra else det_boxes)
+        # one mask-head pass over the union of both ROI sets (same weights); the per-class detections' part normally already
+        # ran in phase 1 (every ROI goes through the head independently: same bits)
+        mask_det = st['mask_det']
+        if mask_det is not None and n_det <= st['max_det']:
+            mask_score = mask_det[:n_det] if not n_extra else torch.cat([mask_det[:n_det], self.mask_branch(feats, extra_boxes[:n_extra])], 0)
+        else:
+            mask_score = self.mask_branch(feats, torch.cat([det_boxes, extra_boxes[:n_extra]], 0) if n_extra else det_boxes)
         mask_prob = torch.sigmoid(mask_score[:n_det])
         ms = config.network.mask_size
         pan_logit = mask_score.index_select(0, pan_row[:n_pan].long()).gather(1, pan_cls.view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
