@@ -254,10 +254,12 @@ int upsnet_mask_roi_dedup(void *stream, const int *a_src, const int64_t *a_cls, 
 /* Replaces MaskRemoval.forward's selection (upsnet/operators/modules/mask_removal.py:50-93):
  *   mask_rois [m,4], cls_prob [m], mask_logit [m,ms,ms], cls_idx [m] int64 (1-based; 0 = dummy)
  *   keep_inds [m] int64 out (visiting order), num_keep device int32 (>=1: the reference's [0] fallback)
- *   real_keep device int32: 0 when the fallback fired (then the single mask plane is all zeros). */
+ *   real_keep device int32: 0 when the fallback fired (then the single mask plane is all zeros).
+ *   m_dev (optional device int32): the arrays have capacity m and *m_dev (<= m) valid rows -- lets the call sit inside a
+ *   HIP graph before the host knows the detection count; NULL: all m rows are valid. */
 size_t upsnet_mask_removal_workspace_bytes(int m, int num_thing_classes, int height, int width);
 int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_prob, const float *mask_logit,
-                        const int64_t *cls_idx, int m, int mask_size, int num_thing_classes, int height, int width,
+                        const int64_t *cls_idx, int m, const int *m_dev, int mask_size, int num_thing_classes, int height, int width,
                         double fraction_threshold, int64_t *keep_inds, int *num_keep, int *real_keep,
                         void *workspace);
 

@@ -31,6 +31,8 @@ __device__ static inline int det_block_scan(int v, int *sh, int *total)
     return base + within;
 }
 
+#define MROI_FILL 256   // rows of the output buffers that are always defined (zero boxes past the count)
+
 // problem p: class j = p+1 (class-wise) or the single class-agnostic problem.
 __global__ void __launch_bounds__(DET_T)
 mroi_candidates_kernel(const float *__restrict__ rois, const float *__restrict__ delta, const float *__restrict__ prob,
@@ -150,9 +152,9 @@ mroi_finalize_kernel(const int P, const int nmax, const int max_det, const float
             cnt += tot;
         }
     }
-    // rows [cnt, max_det) are defined (zero boxes): callers may run fixed-size work (the mask head inside the HIP graph) on
+    // rows [cnt, max(max_det, MROI_FILL)) are defined (zero boxes): callers may run fixed-size work (the mask head inside the HIP graph) on
     // the first max_det rows without reading the counter first
-    for (int i = max(cnt, 1) + tid; i < max_det && i < P * nmax; i += DET_T) {
+    for (int i = max(cnt, 1) + tid; i < max(max_det, MROI_FILL) && i < P * nmax; i += DET_T) {
         for (int q = 0; q < 5; ++q) boxes_out[(long)i * 5 + q] = 0.f;
         scores_out[i] = 0.f; cls_out[i] = 0; src_out[i] = -1;
     }
@@ -271,6 +273,7 @@ mroi_dedup_kernel(const int *__restrict__ a_src, const int64_t *__restrict__ a_c
         }
         cnt += tot;
     }
+    for (int p = nb + tid; p < cap_b && p < MROI_FILL; p += DET_T) map_out[p] = 0;   // defined rows past the count
     if (tid == 0) *n_extra = cnt;
 }
 

@@ -97,10 +97,11 @@ __device__ static inline long pan_block_sum(long v, long *sh)
 //    (mask_removal.py:82), OR the kept bitmap into the class occupancy. The per-instance critical path is a few
 //    microseconds of 64-bit AND/popcount instead of a full resample of the box.
 __global__ void __launch_bounds__(256)
-mask_bits_kernel(const float *__restrict__ rois, const float *__restrict__ logits, const int m, const int ms, const int H,
-                 const int W, const int WW, unsigned long long *__restrict__ bits, int *__restrict__ mask_sum)
+mask_bits_kernel(const float *__restrict__ rois, const float *__restrict__ logits, const int m_cap, const int *__restrict__ m_dev,
+                 const int ms, const int H, const int W, const int WW, unsigned long long *__restrict__ bits, int *__restrict__ mask_sum)
 {
     __shared__ float s_logit[PAN_MAXMS * PAN_MAXMS];
+    if ((int)blockIdx.x >= (m_dev ? min(m_cap, *m_dev) : m_cap)) return;   // fixed-capacity launch, device-side count
     const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = tid; q < ms * ms; q += blockDim.x) s_logit[q] = logits[(long)inst * ms * ms + q];
     __syncthreads();
@@ -124,10 +125,11 @@ mask_bits_kernel(const float *__restrict__ rois, const float *__restrict__ logit
 // grid = num_thing_classes, block = PAN_T
 __global__ void __launch_bounds__(PAN_T)
 mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ prob, const int64_t *__restrict__ cls_idx,
-                    const int m, const int H, const int W, const int WW, const double fraction_threshold,
-                    const unsigned long long *__restrict__ bits, const int *__restrict__ mask_sum,
+                    const int m_cap, const int *__restrict__ m_dev, const int H, const int W, const int WW,
+                    const double fraction_threshold, const unsigned long long *__restrict__ bits, const int *__restrict__ mask_sum,
                     unsigned long long *__restrict__ occbits, int *__restrict__ sorted_idx, uint8_t *__restrict__ kept_flag)
 {
+    const int m = m_dev ? min(m_cap, *m_dev) : m_cap;
     __shared__ ups_u64 s_keys[PAN_MAXINST];
     __shared__ int s_my[PAN_MAXINST];
     __shared__ float s_box[PAN_MAXINST][4];
@@ -191,11 +193,12 @@ mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ pr
 }
 
 __global__ void __launch_bounds__(256)
-mask_removal_finalize_kernel(const int64_t *__restrict__ cls_idx, const int m, const int *__restrict__ sorted_idx,
-                             const uint8_t *__restrict__ kept_flag, int64_t *__restrict__ keep_inds, int *__restrict__ num_keep,
-                             int *__restrict__ real_keep)
+mask_removal_finalize_kernel(const int64_t *__restrict__ cls_idx, const int m_cap, const int *__restrict__ m_dev,
+                             const int *__restrict__ sorted_idx, const uint8_t *__restrict__ kept_flag, int64_t *__restrict__ keep_inds,
+                             int *__restrict__ num_keep, int *__restrict__ real_keep)
 {
     if (threadIdx.x != 0) return;
+    const int m = m_dev ? min(m_cap, *m_dev) : m_cap;
     int k = 0;
     const bool dummy = (m == 1 && cls_idx[0] == 0);  // mask_removal.py:55-57
     if (!dummy)
@@ -224,7 +227,7 @@ static MrPlan mr_plan(int m, int ncls, int H, int W)
 extern "C" size_t upsnet_mask_removal_workspace_bytes(int m, int ncls, int H, int W) { return mr_plan(m, ncls, H, W).total; }
 
 extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_prob, const float *mask_logit,
-                                   const int64_t *cls_idx, int m, int mask_size, int ncls, int H, int W,
+                                   const int64_t *cls_idx, int m, const int *m_dev, int mask_size, int ncls, int H, int W,
                                    double fraction_threshold, int64_t *keep_inds, int *num_keep, int *real_keep,
                                    void *workspace)
 {
@@ -242,12 +245,12 @@ extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const f
     UPS_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)ncls * H * pl.WW * 8, st));
     UPS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)m * 4, st));
     UPS_CHECK_HIP(hipMemsetAsync(kept, 0, (size_t)m, st));
-    hipLaunchKernelGGL(mask_bits_kernel, dim3(m, 32), dim3(256), 0, st, mask_rois, mask_logit, m, mask_size, H, W, pl.WW, bits, sums);
+    hipLaunchKernelGGL(mask_bits_kernel, dim3(m, 32), dim3(256), 0, st, mask_rois, mask_logit, m, m_dev, mask_size, H, W, pl.WW, bits, sums);
     UPS_CHECK_LAUNCH("mask_bits_kernel");
-    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, cls_idx, m, H, W, pl.WW,
+    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, cls_idx, m, m_dev, H, W, pl.WW,
                        fraction_threshold, bits, sums, occ, sorted_idx, kept);
     UPS_CHECK_LAUNCH("mask_removal_kernel");
-    hipLaunchKernelGGL(mask_removal_finalize_kernel, dim3(1), dim3(64), 0, st, cls_idx, m, sorted_idx, kept, keep_inds, num_keep,
+    hipLaunchKernelGGL(mask_removal_finalize_kernel, dim3(1), dim3(64), 0, st, cls_idx, m, m_dev, sorted_idx, kept, keep_inds, num_keep,
                        real_keep);
     UPS_CHECK_LAUNCH("mask_removal_finalize_kernel");
     return 0;

@@ -134,6 +134,12 @@ class resnet_upsnet(resnet_rcnn):
         self.invalidate_graphs()
         return super().load_state_dict(*args, **kwargs)
 
+    def _class_map_dev(self, dev):
+        cm = getattr(self, '_cmap_dev', None)
+        if cm is None or cm.device != dev:
+            cm = self._cmap_dev = self.seg_term.class_map.to(dev)
+        return cm
+
     def _ev_det(self):
         dev = torch.cuda.current_device()
         if ('det', dev) not in _SIDE:
@@ -153,7 +159,7 @@ class resnet_upsnet(resnet_rcnn):
         return self._forward_fused(data)
 
     # ------------------------------------------------------------------ MI355X pipeline
-    def _phase1(self, x, im_info):
+    def _phase1(self, x, im_info, tail=False):
         """Everything up to the first host read (static shapes: fixed-capacity ROI / detection buffers + device counters), on the
         current stream + the side stream; returns device tensors only. Capturable as one HIP graph."""
         pyramid = self._pyramid({'data': x})
@@ -215,7 +221,22 @@ class resnet_upsnet(resnet_rcnn):
         nums = torch.cat([det_num, pan_num, extra_num])
         if side is not main:
             main.wait_event(ev_join)
-        return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
+        tail_out = None
+        if tail and fuse_up and mask_det is not None:
+            # The rest of the forward on fixed-capacity buffers + device counters, so that it can live in the same HIP graph:
+            # assumes the common case (every panoptic detection is also a per-class detection, <= max_det detections, <= 256
+            # panoptic detections); the host checks the counters after the replay and redoes this part eagerly otherwise.
+            K = min(256, pan_boxes.shape[0])
+            pb, ps, pc = pan_boxes[:K], pan_scores[:K], pan_cls[:K]
+            row = pan_row[:K].clamp(0, max_det - 1).long()
+            ms = config.network.mask_size
+            pan_logit = mask_det.index_select(0, row).gather(1, pc.clamp(0, mask_det.shape[1] - 1).view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+            H, W = fcn.shape[2] * 4, fcn.shape[3] * 4
+            keep, num_keep, real_keep = self.mask_removal.select(pb[:, 1:], ps, pan_logit, pc, (H, W), num_dev=pan_num)
+            num_stuff = self.num_seg_classes - (self.num_classes - 1)
+            panoptic, sem = ops.panoptic_fuse_up(fcn, 4, num_stuff, pb, pan_logit, pc, keep, num_keep, real_keep, self._class_map_dev(pb.device))
+            tail_out = dict(keep=keep, panoptic=panoptic, sem=sem, counters=torch.cat([nums, num_keep]))
+        return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, tail=tail_out, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
                     pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
                     mask_det=mask_det, max_det=max_det, _events=(ev_fork, ev_join))
 
@@ -237,7 +258,7 @@ class resnet_upsnet(resnet_rcnn):
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g):
-                    out = self._phase1(static_x, static_im)
+                    out = self._phase1(static_x, static_im, tail=True)
             except Exception as e:   # capture not possible on this stack: stay eager, say so once
                 import warnings
                 warnings.warn("upsnet_amd: HIP graph capture failed (%s); running eagerly" % (e,))
@@ -259,7 +280,20 @@ class resnet_upsnet(resnet_rcnn):
         feats, fuse_up = st['feats'], st['fuse_up']
         fcn_score, fcn_output = (st['fcn'], None) if fuse_up else (None, st['fcn'])
         H, W = (fcn_score.shape[2] * 4, fcn_score.shape[3] * 4) if fuse_up else fcn_output.shape[2:]
-        n_det, n_pan, n_extra = st['nums'].tolist()
+        t = st.get('tail')
+        if t is not None:   # whole forward was in the graph: ONE host read
+            n_det, n_pan, n_extra, k = t['counters'].tolist()
+            if n_extra == 0 and n_det <= st['max_det'] and n_pan <= min(256, st['pan_boxes'].shape[0]):
+                keep = t['keep'][:k]
+                pan_cls, pan_scores = st['pan_cls'][:n_pan], st['pan_scores'][:n_pan]
+                return {
+                    'cls_probs': st['det_scores'][:n_det].clone(), 'pred_boxes': st['det_boxes'][:n_det].clone(),
+                    'mask_probs': torch.sigmoid(st['mask_det'][:n_det]), 'fcn_outputs': t['sem'].clone(),
+                    'cls_inds': st['det_cls'][:n_det].clone(), 'panoptic_cls_inds': pan_cls[keep], 'panoptic_cls_probs': pan_scores[keep],
+                    'panoptic_outputs': t['panoptic'].clone(),
+                }
+        else:
+            n_det, n_pan, n_extra = st['nums'].tolist()
         det_boxes, det_scores, det_cls = st['det_boxes'][:n_det], st['det_scores'][:n_det], st['det_cls'][:n_det]
         if graphed:   # results handed to the caller must not alias the graph's static buffers (overwritten by the next replay)
             det_boxes, det_scores, det_cls = det_boxes.clone(), det_scores.clone(), det_cls.clone()
@@ -281,7 +315,7 @@ class resnet_upsnet(resnet_rcnn):
                   pan_cls=pan_cls, pan_logit=pan_logit)
         keep, num_keep, real_keep = self.mask_removal.select(pan_boxes[:, 1:], pan_scores, pan_logit, pan_cls, (H, W))
         num_stuff = self.num_seg_classes - (self.num_classes - 1)
-        cmap = self.seg_term.class_map.to(pan_boxes.device)
+        cmap = self._class_map_dev(pan_boxes.device)
         if fuse_up:
             self._tap(fcn_score=fcn_score)
         else:

@@ -17,9 +17,11 @@ class MaskRemoval(nn.Module):
         super(MaskRemoval, self).__init__()
         self.fraction_threshold = fraction_threshold
 
-    def select(self, mask_rois, cls_prob, mask_prob, cls_idx, im_shape):
+    def select(self, mask_rois, cls_prob, mask_prob, cls_idx, im_shape, num_dev=None):
+        """Selection only: (keep_inds, num_keep, real_keep) device tensors. num_dev: device count of valid rows when the inputs
+        are fixed-capacity buffers."""
         return ops.mask_removal(mask_rois.detach(), cls_prob.detach(), mask_prob.detach(), cls_idx,
-                                config.dataset.num_classes - 1, im_shape, self.fraction_threshold)
+                                config.dataset.num_classes - 1, im_shape, self.fraction_threshold, m_dev=num_dev)
 
     def forward(self, mask_rois, cls_prob, mask_prob, cls_idx, im_shape):
         keep, num, real = self.select(mask_rois, cls_prob, mask_prob, cls_idx, im_shape)

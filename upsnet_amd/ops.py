@@ -267,8 +267,9 @@ def mask_roi(rois, bbox_delta, cls_prob, im_info, class_agnostic, score_thresh, 
 
 
 # ----------------------------------------------------------------------------- panoptic head
-def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, im_shape, fraction_threshold=0.3):
-    """Device-side MaskRemoval selection. Returns (keep_inds [m] int64, num_keep, real_keep) device tensors."""
+def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, im_shape, fraction_threshold=0.3, m_dev=None):
+    """Device-side MaskRemoval selection. Returns (keep_inds [m] int64, num_keep, real_keep) device tensors.
+    m_dev: optional device int32 count of valid rows (the arrays then have fixed capacity m)."""
     require_cuda(mask_rois4, cls_prob, mask_logit, cls_idx)
     mask_rois4, cls_prob = f32c(mask_rois4), f32c(cls_prob).reshape(-1)
     m = mask_rois4.shape[0]
@@ -281,7 +282,7 @@ def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, i
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     real = torch.empty((1,), dtype=torch.int32, device=dev)
     ws = _ws(lib().upsnet_mask_removal_workspace_bytes(m, num_thing_classes, H, W), dev)
-    check(lib().upsnet_mask_removal(stream(), ptr(mask_rois4), ptr(cls_prob), ptr(mask_logit), ptr(cls_idx), m, ms,
+    check(lib().upsnet_mask_removal(stream(), ptr(mask_rois4), ptr(cls_prob), ptr(mask_logit), ptr(cls_idx), m, ptr(m_dev), ms,
                                     int(num_thing_classes), H, W, float(fraction_threshold), ptr(keep), ptr(num), ptr(real),
                                     ptr(ws)), "mask_removal")
     return keep, num, real
