@@ -210,3 +210,32 @@ def test_hip_graph_replay_equals_eager(setup):
                 assert torch.equal(out[k], eager[j][k]), (step, j, k)
         assert sum(1 for e in model._graphs.values() if 'graph' in e) == 2
     model._graphs.clear()
+
+
+def test_hip_graph_fallback_when_assumptions_fail(setup):
+    """The in-graph tail assumes every panoptic detection is also a per-class detection (and <= max_det / <= 256 rows). With a
+    very low panoptic score threshold that is false: the forward must notice after its single host read and redo the tail
+    eagerly -- same outputs as the eager forward."""
+    from upsnet_amd.synthetic import make_image
+    model, _ = setup
+    img = make_image(256, 512, seed=31, device='cuda')
+    keys = ('panoptic_outputs', 'pred_boxes', 'cls_probs', 'cls_inds', 'mask_probs', 'panoptic_cls_inds', 'fcn_outputs')
+    old, old_det = model.mask_roi_panoptic.score_thresh, model.mask_roi.score_thresh
+    model.mask_roi_panoptic.score_thresh = 0.02
+    model.mask_roi.score_thresh = 0.97   # few per-class detections, many panoptic ones: most of them are "extra" rows
+    try:
+        with torch.no_grad():
+            model.use_graph = False
+            ref = {k: v.clone() for k, v in model(img).items()}
+            model.use_graph = True
+            model._graphs.clear()
+            for step in range(5):
+                out = model(img)
+                for k in keys:
+                    assert torch.equal(out[k], ref[k]), (step, k)
+            ent = next(iter(model._graphs.values()))
+            n_det, n_pan, n_extra, _ = ent['out']['tail']['counters'].tolist()
+            assert n_extra > 0 or n_pan > 256 or n_det > ent['out']['max_det'], (n_det, n_pan, n_extra)   # the fallback was exercised
+    finally:
+        model.mask_roi_panoptic.score_thresh, model.mask_roi.score_thresh = old, old_det
+        model._graphs.clear()
