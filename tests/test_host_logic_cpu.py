@@ -114,3 +114,38 @@ def test_fc6_weight_relayout_matches_nchw_flatten():
     nhwc = pooled.contiguous(memory_format=torch.channels_last)
     got = torch.nn.functional.linear(nhwc.permute(0, 2, 3, 1).reshape(5, -1), r._fc6_weight_nhwc(), r.fc6[0].bias)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_blob_geometry_host_mirror_equals_oracle():
+    """dataset/blob.py restates prep_im_for_blob's scale rule + im_list_to_blob's padding exactly like the oracle (base_dataset.py:155-170, 909-913)."""
+    import oracle
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.dataset.blob import blob_geometry
+    for (H, W, target, max_size) in [(1024, 2048, 1024, 2048), (480, 640, 800, 1333), (427, 640, 800, 1333), (1333, 500, 800, 1333),
+                                     (375, 1242, 800, 1333), (50, 75, 50, 100), (37, 53, 64, 96)]:
+        assert blob_geometry(H, W, target, max_size) == oracle.blob_geometry(H, W, target, max_size), (H, W)
+    # the COCO setting: short side 800 unless the long side would exceed 1333
+    s, (hr, wr), (hp, wp) = blob_geometry(480, 640, 800, 1333)
+    assert abs(s - 800 / 480) < 1e-12 and (hr, wr) == (800, 1067) and (hp, wp) == (800, 1088)
+    s, (hr, wr), _ = blob_geometry(375, 1242, 800, 1333)
+    assert abs(s - 1333 / 1242) < 1e-12 and wr == 1333
+
+
+def test_conv_instance_selection_rules():
+    """hipconv picks the kernel instance by shape only (never by data): Winograd for 3x3/s1 layers with >= 256 workgroups of
+    2x2-tile work and >= 64 output channels, split-K for <= 256 direct workgroups with a long K walk, direct otherwise."""
+    import torch
+    import torch.nn as nn
+    from upsnet_amd.models import hipconv
+    c3 = nn.Conv2d(256, 256, 3, padding=1)
+    x = lambda n, h, w, c=256: torch.empty(n, c, h, w, device='meta')
+    assert hipconv._use_winograd(c3, [x(1, 256, 512)]) and hipconv._use_winograd(c3, [x(1, 128, 256)])      # FPN P2, P3
+    assert not hipconv._use_winograd(c3, [x(1, 64, 128)]) and not hipconv._use_winograd(c3, [x(1, 32, 64)])  # P4, P5: too few tiles
+    assert hipconv._use_winograd(c3, [x(1, 256 >> l, 512 >> l) for l in range(5)])                            # RPN over 5 levels
+    assert not hipconv._use_winograd(nn.Conv2d(256, 18, 3, padding=1), [x(1, 256, 512)])                      # narrow head
+    assert not hipconv._use_winograd(nn.Conv2d(256, 256, 3, stride=2, padding=1), [x(1, 256, 512)])           # strided
+    assert not hipconv._use_winograd(nn.Conv2d(256, 256, 1), [x(1, 256, 512)])
+    assert hipconv._ksplit(nn.Conv2d(512, 512, 3, padding=1), x(1, 32, 64, 512), 512) == 3                    # res5 conv2: 256 workgroups
+    assert hipconv._ksplit(c3, x(1, 32, 64), 256) == 4                                                        # FPN P5: 128 workgroups
+    assert hipconv._ksplit(c3, x(1, 64, 128), 256) == 1 and hipconv._ksplit(nn.Conv2d(256, 1024, 1), x(1, 64, 128), 1024) == 1
