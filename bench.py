@@ -52,9 +52,10 @@ def main():
     from upsnet_amd.upsnet_end2end_test import upsnet_test
     hipconv.PRECISION = args.conv_precision
 
-    # kernel events are recorded on every PROFILE_EVERY-th timed image only (two events per launch are not free:
-    # recording all ~75 conv launches of every image costs ~3 % of the step time)
-    PROFILE_EVERY = 10
+    # kernel events are recorded on ONE timed image (the first): that image runs eagerly and without stream overlap -- two events
+    # per launch, ~190 dispatches instead of one graph replay -- so it is ~2 ms slower than the others and every sampled image
+    # lowers `value`; one image = 76 convolution launches is enough for the per-kernel roofline
+    PROFILE_EVERY = 1 << 30
     ops.PROFILE['events'] = []
     sampled = [0]
 
