@@ -47,6 +47,7 @@ class resnet_upsnet(resnet_rcnn):
         # the static-shape part of the forward (everything before the first host read) replayed as one HIP graph
         self.use_graph = os.environ.get('UPSNET_GRAPH', '1') != '0'
         self._graphs = {}
+        self.graph_outputs_alias = os.environ.get('UPSNET_GRAPH_ALIAS', '1') != '0'
         self.early_mask_head = os.environ.get('UPSNET_EARLY_MASK', '1') != '0'
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
         self.num_classes = config.dataset.num_classes
@@ -235,7 +236,9 @@ class resnet_upsnet(resnet_rcnn):
             keep, num_keep, real_keep = self.mask_removal.select(pb[:, 1:], ps, pan_logit, pc, (H, W), num_dev=pan_num)
             num_stuff = self.num_seg_classes - (self.num_classes - 1)
             panoptic, sem = ops.panoptic_fuse_up(fcn, 4, num_stuff, pb, pan_logit, pc, keep, num_keep, real_keep, self._class_map_dev(pb.device))
-            tail_out = dict(keep=keep, panoptic=panoptic, sem=sem, counters=torch.cat([nums, num_keep]))
+            kk = keep[:K].clamp(0, K - 1)
+            tail_out = dict(keep=keep, panoptic=panoptic, sem=sem, counters=torch.cat([nums, num_keep]),
+                            mask_prob=torch.sigmoid(mask_det), kept_cls=pc.index_select(0, kk), kept_scores=ps.index_select(0, kk))
         return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, tail=tail_out, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
                     pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
                     mask_det=mask_det, max_det=max_det, _events=(ev_fork, ev_join))
@@ -284,14 +287,15 @@ class resnet_upsnet(resnet_rcnn):
         if t is not None:   # whole forward was in the graph: ONE host read
             n_det, n_pan, n_extra, k = t['counters'].tolist()
             if n_extra == 0 and n_det <= st['max_det'] and n_pan <= min(256, st['pan_boxes'].shape[0]):
-                keep = t['keep'][:k]
-                pan_cls, pan_scores = st['pan_cls'][:n_pan], st['pan_scores'][:n_pan]
-                return {
-                    'cls_probs': st['det_scores'][:n_det].clone(), 'pred_boxes': st['det_boxes'][:n_det].clone(),
-                    'mask_probs': torch.sigmoid(st['mask_det'][:n_det]), 'fcn_outputs': t['sem'].clone(),
-                    'cls_inds': st['det_cls'][:n_det].clone(), 'panoptic_cls_inds': pan_cls[keep], 'panoptic_cls_probs': pan_scores[keep],
-                    'panoptic_outputs': t['panoptic'].clone(),
+                # every output is a view into the graph's buffers: no launch after the replay. They are valid until the next
+                # forward() of this model (the usual contract of graph-replayed inference); graph_outputs_alias = False
+                # (UPSNET_GRAPH_ALIAS=0) returns private copies instead.
+                out = {
+                    'cls_probs': st['det_scores'][:n_det], 'pred_boxes': st['det_boxes'][:n_det], 'mask_probs': t['mask_prob'][:n_det],
+                    'fcn_outputs': t['sem'], 'cls_inds': st['det_cls'][:n_det], 'panoptic_cls_inds': t['kept_cls'][:k],
+                    'panoptic_cls_probs': t['kept_scores'][:k], 'panoptic_outputs': t['panoptic'],
                 }
+                return out if self.graph_outputs_alias else {key: v.clone() for key, v in out.items()}
         else:
             n_det, n_pan, n_extra = st['nums'].tolist()
         det_boxes, det_scores, det_cls = st['det_boxes'][:n_det], st['det_scores'][:n_det], st['det_cls'][:n_det]
