@@ -260,7 +260,9 @@ class resnet_upsnet(resnet_rcnn):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                # (thread_local: other threads of the process -- e.g. the RCCL watchdog of torch.distributed -- may call the runtime
+                # while this thread captures)
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     out = self._phase1(static_x, static_im, tail=True)
             except Exception as e:   # capture not possible on this stack: stay eager, say so once
                 import warnings
