@@ -319,6 +319,17 @@ int upsnet_unified_pan_result(void *stream, const int64_t *pan, const int64_t *s
                               int height, int width, int id_last_stuff, int num_seg_classes, int stuff_area_limit,
                               void *workspace, unsigned char *pan_2ch);
 
+/* im_post (upsnet/upsnet_end2end_test.py:95-152) without the full-image pass per detection: for detection d the mask
+ * probability of its class (mask_prob [n, C, M, M]; C == 1: class-agnostic) is zero-padded to (M+2)^2, resized (cv2
+ * INTER_LINEAR) to the box expanded by (M+2)/M and truncated to int32 (expand_boxes, bbox_transform.py:365-381), thresholded
+ * at 0.5 and pasted into an im_height x im_width mask -- of which only the run-length encoding is produced:
+ * transitions[d, 0..transition_count[d]) are the column-major pixel indices (x * im_height + y) at which the mask value changes,
+ * ascending (the first one starts the first run of ones). pycocotools' counts are the differences of [0, transitions..., H*W].
+ * transition_count[d] > cap signals overflow (retry with a larger cap). pred_boxes [n,4] in image coordinates. */
+int upsnet_im_post_rle(void *stream, const float *pred_boxes, const float *mask_prob, const int64_t *cls_inds, int num_det,
+                       int num_mask_channels, int mask_size, int im_height, int im_width, int cap, unsigned *transitions,
+                       int *transition_count);
+
 #ifdef __cplusplus
 }
 #endif

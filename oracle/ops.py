@@ -354,3 +354,80 @@ def get_unified_pan_result(seg, pan, cls_ind, num_seg_classes, num_classes, stuf
     out[:, :, 0] = pan_seg
     out[:, :, 1] = pan_ins
     return out
+
+
+# ----------------------------------------------------------------------------- im_post (instance masks -> COCO RLE)
+def expand_boxes(boxes, scale):
+    """upsnet/bbox/bbox_transform.py:365-381 (float32 arithmetic on a float32 input, float64 result array)."""
+    boxes = np.asarray(boxes, np.float32)
+    w_half = (boxes[:, 2] - boxes[:, 0]) * .5
+    h_half = (boxes[:, 3] - boxes[:, 1]) * .5
+    x_c = (boxes[:, 2] + boxes[:, 0]) * .5
+    y_c = (boxes[:, 3] + boxes[:, 1]) * .5
+    w_half *= scale
+    h_half *= scale
+    out = np.zeros(boxes.shape)
+    out[:, 0] = x_c - w_half
+    out[:, 2] = x_c + w_half
+    out[:, 1] = y_c - h_half
+    out[:, 3] = y_c + h_half
+    return out
+
+
+def rle_counts(mask):
+    """pycocotools rleEncode (common/maskApi.c, pycocotools 2.0 -- third-party, not in /root/reference: published algorithm
+    restated): column-major run lengths, alternating zeros / ones, starting with the (possibly empty) run of zeros."""
+    flat = np.asarray(mask, np.uint8).reshape(-1, order='F')
+    counts, prev, run = [], 0, 0
+    for v in flat:
+        if v != prev:
+            counts.append(run)
+            run, prev = 0, v
+        run += 1
+    counts.append(run)
+    return counts
+
+
+def rle_to_string(counts):
+    """pycocotools rleToString (maskApi.c): delta coding against the count two back (from the 4th on), 5 data bits per char with
+    a continuation bit 0x20 and sign extension, offset 48."""
+    out = []
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(chr(ch + 48))
+    return ''.join(out)
+
+
+def im_post(pred_boxes, pred_masks, cls_inds, im_h, im_w):
+    """Per detection: the image-size binary mask of upsnet_end2end_test.py:95-139 (zero-padded 28x28 -> 30x30, expand_boxes by
+    30/28 truncated to int32, cv2.resize INTER_LINEAR stand-in, > 0.5, paste). Returns a list of uint8 [im_h, im_w] masks."""
+    from . import resize_bilinear
+    pred_boxes = np.asarray(pred_boxes, np.float32).reshape(-1, 4)
+    M = pred_masks.shape[-1]
+    scale = (M + 2.0) / M
+    ref_boxes = expand_boxes(pred_boxes, scale).astype(np.int32)
+    padded = np.zeros((M + 2, M + 2), np.float32)
+    out = []
+    for d in range(pred_boxes.shape[0]):
+        ch = int(cls_inds[d]) if pred_masks.shape[1] > 1 else 0
+        padded[1:-1, 1:-1] = pred_masks[d, ch]
+        rb = ref_boxes[d]
+        w = max(int(rb[2] - rb[0] + 1), 1)
+        h = max(int(rb[3] - rb[1] + 1), 1)
+        mask = (resize_bilinear(padded, w, h) > 0.5).astype(np.uint8)
+        im_mask = np.zeros((im_h, im_w), np.uint8)
+        x_0, x_1 = max(int(rb[0]), 0), min(int(rb[2]) + 1, im_w)
+        y_0, y_1 = max(int(rb[1]), 0), min(int(rb[3]) + 1, im_h)
+        if x_1 > x_0 and y_1 > y_0:
+            im_mask[y_0:y_1, x_0:x_1] = mask[(y_0 - rb[1]):(y_1 - rb[1]), (x_0 - rb[0]):(x_1 - rb[0])]
+        out.append(im_mask)
+    return out

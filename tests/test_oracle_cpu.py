@@ -165,3 +165,38 @@ def test_fcn_score_combine_matches_torch_sequence():
     parts = [F.conv2d(ys[l], wgt[:, l * C:(l + 1) * C])[0].permute(1, 2, 0).contiguous().numpy() for l in range(4)]
     out = oracle.fcn_score_combine(parts, b.numpy())
     np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def _rle_from_string(s):
+    """pycocotools rleFrString, for the round-trip check."""
+    counts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return counts
+
+
+def test_rle_counts_and_string_round_trip():
+    rng = np.random.default_rng(3)
+    assert oops.rle_counts(np.zeros((4, 5), np.uint8)) == [20]
+    assert oops.rle_counts(np.ones((2, 3), np.uint8)) == [0, 6]
+    m = np.zeros((3, 4), np.uint8)
+    m[1, 0] = m[2, 0] = m[0, 1] = 1          # column-major: 0 1 1 | 1 0 0 | 0 0 0 | 0 0 0
+    assert oops.rle_counts(m) == [1, 3, 8]
+    assert oops.rle_to_string([3, 2, 4]) == "324"
+    for _ in range(20):
+        mask = (rng.random((rng.integers(1, 40), rng.integers(1, 40))) < rng.random()).astype(np.uint8)
+        c = oops.rle_counts(mask)
+        assert sum(c) == mask.size and _rle_from_string(oops.rle_to_string(c)) == c
+    big = [0, 5000, 123456, 7, 2000000, 1]
+    assert _rle_from_string(oops.rle_to_string(big)) == big

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "upsnet_conv_pack_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_conv2d_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv2d_nhwc_f32_splitk": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "upsnet_im_post_rle": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_fcn_score_combine": (c_int, [P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_panoptic_argmax": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
 }

@@ -12,6 +12,7 @@
 //                        present id (the reference's enumerate index), stuff-area filter -> a 256-entry LUT id -> (cat, ins)
 //   unipan_apply_kernel  one pass: LUT lookup, uint8 [H,W,3] written (3rd channel zero)
 #include "common.h"
+#include "resize.h"
 #include "upsnet_hip.h"
 
 #define UP_IDS 256
@@ -154,5 +155,115 @@ extern "C" int upsnet_unified_pan_result(void *stream, const int64_t *pan, const
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(unipan_apply_kernel, dim3(blocks), dim3(256), 0, st, pan, npix, ws, pan_2ch);
     UPS_CHECK_LAUNCH("unipan_apply_kernel");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// im_post (upsnet/upsnet_end2end_test.py:95-152): per detection, the 28x28 mask probability of its class is zero-padded to
+// 30x30, resized (cv2 INTER_LINEAR) to the box expanded by 30/28 and truncated to integers, thresholded at 0.5, pasted into a
+// full-image uint8 mask and run-length encoded column-major by pycocotools. The reference does this on the host, one
+// detection at a time, over the whole image (2 M pixels per detection at Cityscapes size).
+// Here: one workgroup per detection evaluates only the box region and emits the RLE directly as the sorted list of
+// column-major pixel indices at which the mask value changes (first entry = start of the first run of ones); the run lengths
+// are the differences of that list (host: upsnet_amd/dataset/rle.py, which also does pycocotools' string compression).
+// Pass 1 counts the transitions per column, a workgroup prefix sum gives the offsets, pass 2 writes the positions.
+#define IMP_T 256
+#define IMP_MAXMS 34   // padded mask side (28 + 2 in every config)
+
+struct ImpBox { int bx0, by0, w, h, x_0, x_1, y_0, y_1; };
+
+__device__ static inline int imp_column(const float *__restrict__ s_pad, const int ps, const ImpBox &b, const int x, const int H,
+                                        unsigned prev, unsigned *__restrict__ out, const long col_base)
+{
+    // transitions of column x: rows y_0..y_1-1 from the resized mask, everything else zero; `prev` = value of the pixel before
+    // the column's first row in column-major order; returns the count, writes the positions when out != nullptr
+    int n = 0;
+    unsigned cur = prev;
+    if (b.y_0 > 0 && cur) { if (out) out[n] = (unsigned)col_base; ++n; cur = 0; }   // previous column ended set at row H-1, this one starts with zero rows
+    for (int y = b.y_0; y < b.y_1; ++y) {
+        const unsigned v = pan_resize_at(s_pad, ps, b.w, b.h, x - b.bx0, y - b.by0) > 0.5f ? 1u : 0u;
+        if (v != cur) { if (out) out[n] = (unsigned)(col_base + y); ++n; cur = v; }
+    }
+    if (b.y_1 < H && cur) { if (out) out[n] = (unsigned)(col_base + b.y_1); ++n; }
+    return n;
+}
+
+__global__ void __launch_bounds__(IMP_T)
+im_post_rle_kernel(const float *__restrict__ boxes, const float *__restrict__ mask_prob, const int64_t *__restrict__ cls_inds,
+                   const int num_ch, const int ms, const int H, const int W, const int cap, unsigned *__restrict__ trans,
+                   int *__restrict__ trans_cnt)
+{
+    __shared__ float s_pad[IMP_MAXMS * IMP_MAXMS];
+    __shared__ int s_scan[IMP_T];
+    __shared__ int s_carry;
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const int ps = ms + 2;
+    const int ch = num_ch > 1 ? (int)cls_inds[d] : 0;
+    const float *src = mask_prob + ((long)d * num_ch + ch) * ms * ms;
+    for (int i = tid; i < ps * ps; i += IMP_T) {
+        const int py = i / ps, px = i - py * ps;
+        s_pad[i] = (py >= 1 && py <= ms && px >= 1 && px <= ms) ? src[(py - 1) * ms + (px - 1)] : 0.f;
+    }
+    if (tid == 0) s_carry = 0;
+    // expand_boxes (bbox_transform.py:365-381) in float32, then astype(int32) (truncation)
+    const float scale = (float)(((double)ms + 2.0) / (double)ms);
+    const float bx1 = boxes[d * 4 + 0], by1 = boxes[d * 4 + 1], bx2 = boxes[d * 4 + 2], by2 = boxes[d * 4 + 3];
+    float w_half = (bx2 - bx1) * .5f, h_half = (by2 - by1) * .5f;
+    const float x_c = (bx2 + bx1) * .5f, y_c = (by2 + by1) * .5f;
+    w_half = w_half * scale; h_half = h_half * scale;
+    const int rx1 = (int)(x_c - w_half), rx2 = (int)(x_c + w_half), ry1 = (int)(y_c - h_half), ry2 = (int)(y_c + h_half);
+    ImpBox b;
+    b.w = max(rx2 - rx1 + 1, 1); b.h = max(ry2 - ry1 + 1, 1);
+    b.bx0 = rx1; b.by0 = ry1;
+    b.x_0 = max(rx1, 0); b.x_1 = min(rx2 + 1, W);
+    b.y_0 = max(ry1, 0); b.y_1 = min(ry2 + 1, H);
+    __syncthreads();
+    unsigned *out = trans + (long)d * cap;
+    const bool touch = b.y_1 == H;   // only then the last pixel of a column (row H-1) can be set and precede the next column
+    if (b.x_1 <= b.x_0 || b.y_1 <= b.y_0) { if (tid == 0) trans_cnt[d] = 0; return; }
+    for (int x0 = b.x_0; x0 < b.x_1; x0 += IMP_T) {
+        const int x = x0 + tid;
+        const bool act = x < b.x_1;
+        unsigned prev = 0;
+        if (act && touch && x > b.x_0) prev = pan_resize_at(s_pad, ps, b.w, b.h, x - 1 - b.bx0, H - 1 - b.by0) > 0.5f ? 1u : 0u;
+        const int n = act ? imp_column(s_pad, ps, b, x, H, prev, nullptr, (long)x * H) : 0;
+        // exclusive prefix sum over the chunk of columns
+        s_scan[tid] = n;
+        __syncthreads();
+        for (int o = 1; o < IMP_T; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int base = s_carry + s_scan[tid] - n;
+        if (act && n && base + n <= cap) imp_column(s_pad, ps, b, x, H, prev, out + base, (long)x * H);
+        __syncthreads();
+        if (tid == IMP_T - 1) s_carry += s_scan[tid];
+        __syncthreads();
+    }
+    // a run of ones reaching row H-1 of the last box column ends where column x_1 (all zeros) starts
+    if (tid == 0) {
+        int total = s_carry;
+        if (touch && b.x_1 < W) {
+            const unsigned last = pan_resize_at(s_pad, ps, b.w, b.h, b.x_1 - 1 - b.bx0, H - 1 - b.by0) > 0.5f ? 1u : 0u;
+            if (last) { if (total < cap) out[total] = (unsigned)((long)b.x_1 * H); ++total; }
+        }
+        trans_cnt[d] = total;   // > cap: overflow, the caller must retry with a larger capacity
+    }
+}
+
+extern "C" int upsnet_im_post_rle(void *stream, const float *pred_boxes, const float *mask_prob, const int64_t *cls_inds, int num_det,
+                                  int num_mask_channels, int mask_size, int im_height, int im_width, int cap, unsigned *transitions,
+                                  int *transition_count)
+{
+    UPS_REQUIRE(pred_boxes && mask_prob && cls_inds && transitions && transition_count, "im_post_rle: null pointer");
+    UPS_REQUIRE(num_det >= 0 && num_mask_channels >= 1 && mask_size >= 2 && mask_size + 2 <= IMP_MAXMS, "im_post_rle: bad mask shape");
+    UPS_REQUIRE(im_height > 0 && im_width > 0 && (long)im_height * im_width < (1L << 32) && cap > 0, "im_post_rle: bad image size / capacity");
+    if (num_det == 0) return 0;
+    hipLaunchKernelGGL(im_post_rle_kernel, dim3(num_det), dim3(IMP_T), 0, (hipStream_t)stream, pred_boxes, mask_prob, cls_inds,
+                       num_mask_channels, mask_size, im_height, im_width, cap, transitions, transition_count);
+    UPS_CHECK_LAUNCH("im_post_rle_kernel");
     return 0;
 }
