@@ -74,6 +74,47 @@ int upsnet_mod_deform_im2col(void *stream, const float *data_im, const float *da
                              int stride_h, int stride_w, int dilation_h, int dilation_w, int deformable_group,
                              float *data_col);
 
+/* ---- backward natives of the same pybind modules (API parity for fine-tuning; not on the inference path).
+ * fp32 NCHW, argument order of the reference launchers. The scatter kernels accumulate INTO their output with
+ * fp32 atomics exactly like the reference (zero it first; summation order unspecified => parity 1e-5-level);
+ * the col2im_coord gathers have a fixed order and are bit-exact against the oracle. */
+
+/* Replaces roi_align_backward_gpu_kernel_launcher (upsnet/operators/src/roi_align_cuda.cpp:32-36, bound as
+ * roi_align_cuda.roi_align_backward :77-112; kernel roi_align_kernel.cu:238-349). top_diff [N,C,PH,PW],
+ * bottom_diff [B,C,H,W] accumulated. */
+int upsnet_roi_align_backward(void *stream, const float *top_diff, float spatial_scale, int batch_size, int num_rois,
+                              int height, int width, int channels, int pooled_height, int pooled_width,
+                              int sampling_ratio, const float *bottom_rois, float *bottom_diff);
+
+/* Replaces deformable_col2im_gpu_kernel_launcher (deform_conv_cuda.cpp:32-38, bound as deform_col2im :70-86;
+ * kernel deform_conv_kernel.cu:293-383). data_col [C*kh*kw, parallel_imgs, Ho, Wo] -> grad_im accumulated. */
+int upsnet_deform_col2im(void *stream, const float *data_col, const float *data_offset, int channels, int height,
+                         int width, int ksize_h, int ksize_w, int pad_h, int pad_w, int stride_h, int stride_w,
+                         int dilation_h, int dilation_w, int parallel_imgs, int deformable_group, float *grad_im);
+
+/* Replaces deformable_col2im_coord_gpu_kernel_launcher (deform_conv_cuda.cpp:40-46, bound as deform_col2im_coord
+ * :88-105; kernel deform_conv_kernel.cu:391-500). grad_offset is overwritten. */
+int upsnet_deform_col2im_coord(void *stream, const float *data_col, const float *data_im, const float *data_offset,
+                               int channels, int height, int width, int ksize_h, int ksize_w, int pad_h, int pad_w,
+                               int stride_h, int stride_w, int dilation_h, int dilation_w, int parallel_imgs,
+                               int deformable_group, float *grad_offset);
+
+/* Replaces modulated_deformable_col2im_gpu_kernel_launcher (mod_deform_conv_cuda.cpp:33-40, bound as
+ * mod_deform_col2im :76-92; kernel mod_deform_conv_kernel.cu:251-311, launcher :409-433). Like the reference
+ * launcher (:423) the kernel receives pad_h for BOTH paddings; pad_w is accepted and ignored. */
+int upsnet_mod_deform_col2im(void *stream, const float *data_col, const float *data_offset, const float *data_mask,
+                             int batch_size, int channels, int height_im, int width_im, int height_col, int width_col,
+                             int kernel_h, int kernel_w, int pad_h, int pad_w, int stride_h, int stride_w,
+                             int dilation_h, int dilation_w, int deformable_group, float *grad_im);
+
+/* Replaces modulated_deformable_col2im_coord_gpu_kernel_launcher (mod_deform_conv_cuda.cpp:42-50, bound as
+ * mod_deform_col2im_coord :94-114; kernel mod_deform_conv_kernel.cu:313-381). grad_offset / grad_mask overwritten. */
+int upsnet_mod_deform_col2im_coord(void *stream, const float *data_col, const float *data_im, const float *data_offset,
+                                   const float *data_mask, int batch_size, int channels, int height_im, int width_im,
+                                   int height_col, int width_col, int kernel_h, int kernel_w, int pad_h, int pad_w,
+                                   int stride_h, int stride_w, int dilation_h, int dilation_w, int deformable_group,
+                                   float *grad_offset, float *grad_mask);
+
 /* Fused deformable convolution forward (v1 when mask == NULL, v2 otherwise), the MI355X-native
  * replacement for DeformConvFunction.forward's im2col + torch.mm (functions/deform_conv.py:43-57)
  * with no column buffer: the dense implicit-GEMM kernel below with a bilinear-gather A operand

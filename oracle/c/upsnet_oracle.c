@@ -152,6 +152,159 @@ void orc_deform_im2col(const float *im, const float *offset, const float *mask /
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Backward natives. The scatter kernels use atomics in the reference, so their
+ * summation order is unspecified there; the restatement accumulates in kernel-index order and the tests
+ * compare within 1e-5-level tolerances. The gather kernels (col2im_coord) have a fixed order: bit-exact.
+ *   RoIAlignBackwardFeature + bilinear_interpolate_gradient   roi_align_kernel.cu:97-160, 238-349
+ *   deformable_col2im / get_gradient_weight                   deform_conv_kernel.cu:120-143, 293-358
+ *   deformable_col2im_coord / get_coordinate_weight           deform_conv_kernel.cu:146-184, 391-450
+ *   modulated versions                                        mod_deform_conv_kernel.cu:251-381
+ * ---------------------------------------------------------------------------------------- */
+void orc_roi_align_backward(const float *top_diff, const float *rois, int num_rois, int channels, int height, int width,
+                            int pooled_h, int pooled_w, int sampling_ratio, float spatial_scale, float *bottom_diff)
+{
+    for (int n = 0; n < num_rois; ++n) {
+        const float *r = rois + n * 5;
+        int b = (int)roundf(r[0]);
+        float roi_start_w = r[1] * spatial_scale, roi_start_h = r[2] * spatial_scale;
+        float roi_end_w = r[3] * spatial_scale, roi_end_h = r[4] * spatial_scale;
+        float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f), roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+        float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+        int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+        int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+        const float count = (float)(grid_h * grid_w);
+        for (int c = 0; c < channels; ++c) {
+            float *plane = bottom_diff + ((size_t)b * channels + c) * height * width;
+            for (int ph = 0; ph < pooled_h; ++ph)
+                for (int pw = 0; pw < pooled_w; ++pw) {
+                    const float top = top_diff[(((size_t)n * channels + c) * pooled_h + ph) * pooled_w + pw];
+                    for (int iy = 0; iy < grid_h; ++iy) {
+                        float y0 = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+                        for (int ix = 0; ix < grid_w; ++ix) {
+                            float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+                            float y = y0;
+                            if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) continue;   /* :112-117 */
+                            if (y <= 0) y = 0;
+                            if (x <= 0) x = 0;
+                            int y_low = (int)y, x_low = (int)x, y_high, x_high;
+                            if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else y_high = y_low + 1;
+                            if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else x_high = x_low + 1;
+                            float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+                            float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                            plane[y_low * width + x_low] += top * w1 / count;     /* :324-327 */
+                            plane[y_low * width + x_high] += top * w2 / count;
+                            plane[y_high * width + x_low] += top * w3 / count;
+                            plane[y_high * width + x_high] += top * w4 / count;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+static float orc_dcn_grad_weight(float ah, float aw, int h, int w, int height, int width)
+{
+    if (ah <= -1 || ah >= (float)height || aw <= -1 || aw >= (float)width) return 0.f;
+    int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
+    float weight = 0.f;
+    if (h == hl && w == wl) weight = ((float)(h + 1) - ah) * ((float)(w + 1) - aw);
+    if (h == hl && w == wh) weight = ((float)(h + 1) - ah) * (aw + 1.0f - (float)w);
+    if (h == hh && w == wl) weight = (ah + 1.0f - (float)h) * ((float)(w + 1) - aw);
+    if (h == hh && w == wh) weight = (ah + 1.0f - (float)h) * (aw + 1.0f - (float)w);
+    return weight;
+}
+
+/* col [C,kh,kw,B,Hc,Wc], offset [B,dg*2*kh*kw,Hc,Wc], mask [B,dg*kh*kw,Hc,Wc] or NULL (v1) -> grad_im [B,C,H,W] (accumulated) */
+void orc_deform_col2im(const float *col, const float *offset, const float *mask, int batch, int channels, int height, int width,
+                       int height_col, int width_col, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                       int dil_w, int deformable_group, float *grad_im)
+{
+    const int cpg = channels / deformable_group;
+    const size_t plane_col = (size_t)height_col * width_col;
+    size_t index = 0;
+    for (int c = 0; c < channels; ++c)
+        for (int i = 0; i < kh; ++i)
+            for (int j = 0; j < kw; ++j)
+                for (int b = 0; b < batch; ++b)
+                    for (int h_out = 0; h_out < height_col; ++h_out)
+                        for (int w_out = 0; w_out < width_col; ++w_out, ++index) {
+                            const int g = c / cpg;
+                            const size_t pix = (size_t)h_out * width_col + w_out;
+                            const float *off = offset + ((size_t)b * deformable_group + g) * 2 * kh * kw * plane_col;
+                            const float off_h = off[(size_t)(2 * (i * kw + j)) * plane_col + pix];
+                            const float off_w = off[(size_t)(2 * (i * kw + j) + 1) * plane_col + pix];
+                            const float ih = (float)(h_out * stride_h - pad_h + i * dil_h) + off_h;
+                            const float iw = (float)(w_out * stride_w - pad_w + j * dil_w) + off_w;
+                            float top = col[index];
+                            if (mask) top = top * mask[(((size_t)b * deformable_group + g) * kh * kw + (i * kw + j)) * plane_col + pix];
+                            const int cur_h = (int)ih, cur_w = (int)iw;        /* truncation, :339-340 */
+                            for (int dy = -2; dy <= 2; ++dy)
+                                for (int dx = -2; dx <= 2; ++dx) {
+                                    const int h = cur_h + dy, w = cur_w + dx;
+                                    if (h >= 0 && h < height && w >= 0 && w < width && fabsf(ih - (float)h) < 1 && fabsf(iw - (float)w) < 1)
+                                        grad_im[(((size_t)b * channels + c) * height + h) * width + w] +=
+                                            orc_dcn_grad_weight(ih, iw, h, w, height, width) * top;
+                                }
+                        }
+}
+
+static float orc_dcn_coord_weight(float ah, float aw, int height, int width, const float *im, int bp_dir)
+{
+    if (ah <= -1 || ah >= (float)height || aw <= -1 || aw >= (float)width) return 0.f;
+    int hl = (int)floorf(ah), wl = (int)floorf(aw), hh = hl + 1, wh = wl + 1;
+    float weight = 0.f;
+    if (bp_dir == 0) {
+        if (hl >= 0 && wl >= 0) weight += -1.0f * ((float)(wl + 1) - aw) * im[hl * width + wl];
+        if (hl >= 0 && wh <= width - 1) weight += -1.0f * (aw - (float)wl) * im[hl * width + wh];
+        if (hh <= height - 1 && wl >= 0) weight += ((float)(wl + 1) - aw) * im[hh * width + wl];
+        if (hh <= height - 1 && wh <= width - 1) weight += (aw - (float)wl) * im[hh * width + wh];
+    } else {
+        if (hl >= 0 && wl >= 0) weight += -1.0f * ((float)(hl + 1) - ah) * im[hl * width + wl];
+        if (hl >= 0 && wh <= width - 1) weight += ((float)(hl + 1) - ah) * im[hl * width + wh];
+        if (hh <= height - 1 && wl >= 0) weight += -1.0f * (ah - (float)hl) * im[hh * width + wl];
+        if (hh <= height - 1 && wh <= width - 1) weight += (ah - (float)hl) * im[hh * width + wh];
+    }
+    return weight;
+}
+
+/* + im [B,C,H,W] -> grad_offset [B,dg*2*kh*kw,Hc,Wc] and (mask != NULL) grad_mask [B,dg*kh*kw,Hc,Wc] */
+void orc_deform_col2im_coord(const float *col, const float *im, const float *offset, const float *mask, int batch, int channels,
+                             int height, int width, int height_col, int width_col, int kh, int kw, int pad_h, int pad_w,
+                             int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group, float *grad_offset,
+                             float *grad_mask)
+{
+    const int taps = kh * kw, cpg = channels / deformable_group;
+    const size_t plane_col = (size_t)height_col * width_col;
+    for (int b = 0; b < batch; ++b)
+        for (int g = 0; g < deformable_group; ++g)
+            for (int oc = 0; oc < 2 * taps; ++oc)
+                for (int h = 0; h < height_col; ++h)
+                    for (int w = 0; w < width_col; ++w) {
+                        const int tap = oc / 2, bp_dir = oc % 2, i = tap / kw, j = tap % kw;
+                        const size_t pix = (size_t)h * width_col + w;
+                        const float *off = offset + ((size_t)b * deformable_group + g) * 2 * taps * plane_col;
+                        const float off_h = off[(size_t)(2 * tap) * plane_col + pix], off_w = off[(size_t)(2 * tap + 1) * plane_col + pix];
+                        float ih = (float)(h * stride_h - pad_h + i * dil_h) + off_h;
+                        float iw = (float)(w * stride_w - pad_w + j * dil_w) + off_w;
+                        const int outside = ih <= -1 || iw <= -1 || ih >= (float)height || iw >= (float)width;
+                        if (outside) ih = iw = -2.f;
+                        const float m = mask ? mask[(((size_t)b * deformable_group + g) * taps + tap) * plane_col + pix] : 1.f;
+                        float val = 0.f, mval = 0.f;
+                        for (int cc = 0; cc < cpg; ++cc) {
+                            const int c_im = g * cpg + cc;
+                            const float cv = col[(((size_t)(c_im * taps + tap)) * batch + b) * plane_col + pix];
+                            const float *plane = im + ((size_t)b * channels + c_im) * height * width;
+                            if (mask && !outside) mval += cv * orc_dcn_bilinear(plane, height, width, ih, iw);
+                            const float weight = orc_dcn_coord_weight(ih, iw, height, width, plane, bp_dir);
+                            if (mask) val += weight * cv * m;
+                            else val += weight * cv;
+                        }
+                        grad_offset[(((size_t)b * deformable_group + g) * 2 * taps + oc) * plane_col + pix] = val;
+                        if (mask && bp_dir == 0) grad_mask[(((size_t)b * deformable_group + g) * taps + tap) * plane_col + pix] = mval;
+                    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Hard NMS on score-sorted boxes [N,5]: restates _nms + nms_kernel + devIoU,
  * upsnet/nms/nms_kernel.cu:30-38 (IoU, +1 convention), :73-80 (strict ">"), :130-146 (greedy scan).
  * Returns the number kept; keep_out[] = indices into the SORTED array in visiting order.

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -85,3 +86,32 @@ def gen_panoptic_maps(rng, H, W, k, num_stuff=11, num_things=8, void_frac=0.03, 
     void = rng.random((H, W)) < void_frac
     pan[void] = 255
     return seg, pan, cls_ind
+
+
+def torch_deform_im2col(im, off, mask, k, pad, stride, dil, dg):
+    """Differentiable float64 deformable im2col (zero outside the image, bilinear inside): [B,C,k*k,Ho,Wo]."""
+    B, C, H, W = im.shape
+    Ho, Wo = off.shape[2:]
+    ys = torch.arange(Ho, dtype=torch.float64).view(1, 1, 1, Ho, 1) * stride - pad
+    xs = torch.arange(Wo, dtype=torch.float64).view(1, 1, 1, 1, Wo) * stride - pad
+    ki = (torch.arange(k * k) // k).view(1, 1, k * k, 1, 1).double() * dil
+    kj = (torch.arange(k * k) % k).view(1, 1, k * k, 1, 1).double() * dil
+    o = off.view(B, dg, k * k, 2, Ho, Wo)
+    ph, pw = ys + ki + o[:, :, :, 0], xs + kj + o[:, :, :, 1]                     # [B,dg,k*k,Ho,Wo]
+    cpg = C // dg
+    ph, pw = ph.repeat_interleave(cpg, 1), pw.repeat_interleave(cpg, 1)          # [B,C,k*k,Ho,Wo]
+    h0, w0 = torch.floor(ph).detach(), torch.floor(pw).detach()
+    flat = im.reshape(B, C, H * W)
+    val = 0
+    for dy in (0, 1):
+        for dx in (0, 1):
+            hh, ww = h0 + dy, w0 + dx
+            ok = (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1)
+            idx = (hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1)).long().view(B, C, -1)
+            v = torch.gather(flat, 2, idx).view_as(ph) * ok
+            wy = (ph - h0) if dy else (1 - (ph - h0))
+            wx = (pw - w0) if dx else (1 - (pw - w0))
+            val = val + wy * wx * v
+    if mask is not None:
+        val = val * mask.view(B, dg, k * k, Ho, Wo).repeat_interleave(cpg, 1)
+    return val

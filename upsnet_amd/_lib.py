@@ -22,6 +22,11 @@ _SIGNATURES = {
     "upsnet_fpn_roi_align_forward": (c_int, [P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P]),
     "upsnet_deform_im2col": (c_int, [P, P, P] + [c_int] * 13 + [P]),
     "upsnet_mod_deform_im2col": (c_int, [P, P, P, P] + [c_int] * 15 + [P]),
+    "upsnet_roi_align_backward": (c_int, [P, P, c_float] + [c_int] * 8 + [P, P]),
+    "upsnet_deform_col2im": (c_int, [P, P, P] + [c_int] * 13 + [P]),
+    "upsnet_deform_col2im_coord": (c_int, [P, P, P, P] + [c_int] * 13 + [P]),
+    "upsnet_mod_deform_col2im": (c_int, [P, P, P, P] + [c_int] * 15 + [P]),
+    "upsnet_mod_deform_col2im_coord": (c_int, [P, P, P, P, P] + [c_int] * 15 + [P, P]),
     "upsnet_deform_conv_forward_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 11 + [P, c_int, P, c_int]),
     "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_tuning": (None, [c_int, c_int]),

@@ -21,8 +21,24 @@ class _RoIAlignCuda(object):
         output.copy_(ops.roi_align_nchw(features, rois, pooled_height, pooled_width, spatial_scale, sampling_ratio))
         return 1
 
+    roi_align_backward = staticmethod(ops.roi_align_backward)
+
 
 roi_align_cuda = _RoIAlignCuda()
+
+
+class _RoIAlignGrad(torch.autograd.Function):
+    """What makes the callable below differentiable under today's autograd (the reference relied on the legacy
+    instance-Function protocol): forward = the native forward, backward = roi_align_backward into a zeroed map."""
+
+    @staticmethod
+    def forward(ctx, features, rois, fn):
+        ctx.fn = fn
+        return fn._forward(features, rois)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return ctx.fn.backward(grad_output)[0], None, None
 
 
 class RoIAlignFunction(object):
@@ -34,6 +50,11 @@ class RoIAlignFunction(object):
         self.feature_size = None
 
     def forward(self, features, rois):
+        if features.requires_grad and torch.is_grad_enabled():
+            return _RoIAlignGrad.apply(features, rois, self)
+        return self._forward(features, rois)
+
+    def _forward(self, features, rois):
         if not features.is_cuda:
             raise Exception('not implemented')
         self.feature_size = features.size()
@@ -48,4 +69,11 @@ class RoIAlignFunction(object):
     __call__ = forward
 
     def backward(self, grad_output):
-        raise NotImplementedError("upsnet_amd implements the inference path only")
+        # functions/roialign.py:45-54
+        assert self.feature_size is not None and grad_output.is_cuda
+        batch_size, num_channels, data_height, data_width = self.feature_size
+        grad_input = grad_output.new_zeros((batch_size, num_channels, data_height, data_width), dtype=torch.float32)
+        roi_align_cuda.roi_align_backward(self.pooled_height, self.pooled_width, self.sampling_ratio, self.spatial_scale,
+                                          grad_output.detach().float().contiguous(), self.rois.detach().float().contiguous(),
+                                          grad_input)
+        return grad_input, None

@@ -103,6 +103,71 @@ def mod_deform_im2col(data_im, data_offset, data_mask, im_shape, col_shape, kern
     return 1
 
 
+def _shape_args(im_shape, kernel_shape, pad, stride, dilation):
+    return (int(im_shape[1]), int(im_shape[2]), int(im_shape[3]), int(kernel_shape[0]), int(kernel_shape[1]), int(pad[0]),
+            int(pad[1]), int(stride[0]), int(stride[1]), int(dilation[0]), int(dilation[1]))
+
+
+def deform_col2im(data_col, data_offset, im_shape, col_shape, kernel_shape, pad, stride, dilation, parallel_imgs,
+                  deformable_group, grad_im):
+    """Drop-in for deform_conv_cuda.deform_col2im (deform_conv_cuda.cpp:70-86); accumulates into grad_im."""
+    require_cuda(data_col, data_offset, grad_im)
+    assert data_col.is_contiguous() and data_offset.is_contiguous() and grad_im.is_contiguous()
+    check(lib().upsnet_deform_col2im(stream(), ptr(data_col), ptr(data_offset), *_shape_args(im_shape, kernel_shape, pad, stride,
+                                                                                            dilation),
+                                     int(parallel_imgs), int(deformable_group), ptr(grad_im)), "deform_col2im")
+    return 1
+
+
+def deform_col2im_coord(data_col, data_im, data_offset, im_shape, col_shape, kernel_shape, pad, stride, dilation,
+                        parallel_imgs, deformable_group, grad_offset):
+    """Drop-in for deform_conv_cuda.deform_col2im_coord (deform_conv_cuda.cpp:88-105); overwrites grad_offset."""
+    require_cuda(data_col, data_im, data_offset, grad_offset)
+    assert data_col.is_contiguous() and data_im.is_contiguous() and data_offset.is_contiguous() and grad_offset.is_contiguous()
+    check(lib().upsnet_deform_col2im_coord(stream(), ptr(data_col), ptr(data_im), ptr(data_offset),
+                                           *_shape_args(im_shape, kernel_shape, pad, stride, dilation), int(parallel_imgs),
+                                           int(deformable_group), ptr(grad_offset)), "deform_col2im_coord")
+    return 1
+
+
+def mod_deform_col2im(data_col, data_offset, data_mask, im_shape, col_shape, kernel_shape, pad, stride, dilation,
+                      deformable_group, grad_im):
+    """Drop-in for mod_deform_conv_cuda.mod_deform_col2im (mod_deform_conv_cuda.cpp:76-92), batch 1."""
+    require_cuda(data_col, data_offset, data_mask, grad_im)
+    assert data_col.is_contiguous() and data_offset.is_contiguous() and data_mask.is_contiguous() and grad_im.is_contiguous()
+    a = _shape_args(im_shape, kernel_shape, pad, stride, dilation)
+    check(lib().upsnet_mod_deform_col2im(stream(), ptr(data_col), ptr(data_offset), ptr(data_mask), 1, a[0], a[1], a[2],
+                                         int(col_shape[1]), int(col_shape[2]), *a[3:], int(deformable_group), ptr(grad_im)),
+          "mod_deform_col2im")
+    return 1
+
+
+def mod_deform_col2im_coord(data_col, data_im, data_offset, data_mask, im_shape, col_shape, kernel_shape, pad, stride,
+                            dilation, deformable_group, grad_offset, grad_mask):
+    """Drop-in for mod_deform_conv_cuda.mod_deform_col2im_coord (mod_deform_conv_cuda.cpp:94-114), batch 1."""
+    require_cuda(data_col, data_im, data_offset, data_mask, grad_offset, grad_mask)
+    assert data_col.is_contiguous() and data_im.is_contiguous() and data_offset.is_contiguous() and data_mask.is_contiguous()
+    assert grad_offset.is_contiguous() and grad_mask.is_contiguous()
+    a = _shape_args(im_shape, kernel_shape, pad, stride, dilation)
+    check(lib().upsnet_mod_deform_col2im_coord(stream(), ptr(data_col), ptr(data_im), ptr(data_offset), ptr(data_mask), 1, a[0],
+                                               a[1], a[2], int(col_shape[1]), int(col_shape[2]), *a[3:], int(deformable_group),
+                                               ptr(grad_offset), ptr(grad_mask)), "mod_deform_col2im_coord")
+    return 1
+
+
+def roi_align_backward(pooled_h, pooled_w, sampling_ratio, spatial_scale, top_grad, rois, bottom_grad):
+    """Drop-in for roi_align_cuda.roi_align_backward (roi_align_cuda.cpp:77-112); accumulates into bottom_grad [B,C,H,W]."""
+    require_cuda(top_grad, rois, bottom_grad)
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        return 0
+    assert top_grad.is_contiguous() and rois.is_contiguous() and bottom_grad.is_contiguous()
+    assert top_grad.dtype == torch.float32 and rois.dtype == torch.float32 and bottom_grad.dtype == torch.float32
+    B, C, H, W = bottom_grad.shape
+    check(lib().upsnet_roi_align_backward(stream(), ptr(top_grad), float(spatial_scale), B, rois.shape[0], H, W, C, int(pooled_h),
+                                          int(pooled_w), int(sampling_ratio), ptr(rois), ptr(bottom_grad)), "roi_align_backward")
+    return 1
+
+
 def pack_dcn_weight(weight):
     """[Cout,Cin,kh,kw] -> (wpack [kh*kw*Cin, ldw], ldw): same packing as the dense convolution."""
     return pack_conv_weight(weight)
