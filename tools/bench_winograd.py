@@ -26,8 +26,16 @@ for name, segs, cin, cout in shapes:
     wgt = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
     b = torch.randn(cout, device='cuda')
     wd, ldd = ops.pack_conv_weight(wgt)
-    ww, ldw = ops.pack_winograd_weight(wgt)
     td = timeit(lambda: ops.conv2d_nhwc_multi(xs, wd, ldd, b, cout, 3, 1, 1, True))
-    tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
+    ref = ops.conv2d_nhwc_multi(xs, wd, ldd, b, cout, 3, 1, 1, True)
     gf = 2.0 * cout * cin * 9 * sum(n * h * w for n, h, w in segs) / 1e9
-    print("%-28s %6.1f GFLOP | direct %7.1f us (%5.1f TF) | winograd %7.1f us (%5.1f TF-equiv) | x%.2f" % (name, gf, td, gf / td * 1e3, tw, gf / tw * 1e3, td / tw), flush=True)
+    line = "%-28s %6.1f GFLOP | direct %7.1f us (%5.1f TF)" % (name, gf, td, gf / td * 1e3)
+    for form in (1, 0):                      # 1: per-position walks, 0: 16 resident accumulators (conv_wino.hip)
+        lib().upsnet_conv_tuning(form, 0)
+        ww, ldw = ops.pack_winograd_weight(wgt)
+        tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
+        got = ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True)
+        err = max(float((g - r).abs().max()) for g, r in zip(got, ref))
+        line += " | form %d %7.1f us (%5.1f TF-equiv, x%.2f, err %.1e)" % (form, tw, gf / tw * 1e3, td / tw, err)
+    lib().upsnet_conv_tuning(0, 0)
+    print(line, flush=True)

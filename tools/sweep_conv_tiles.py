@@ -38,7 +38,7 @@ for key, cnt in sorted(shapes.items(), key=lambda kv: -kv[1]):
         if tile == 4 and ldw % 128: continue
         if tile in (2, 5, 6) and ldw % 64: continue
         if tile == 6 and cin % 64: continue
-        lib().upsnet_conv_tuning(-1, tile)
+        lib().upsnet_conv_tuning(0, tile)
         for _ in range(2): ops.conv2d_nhwc_multi(xs, wp, ldw, b, cout, k, st, k // 2, True, res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,5 +54,5 @@ for key, cnt in sorted(shapes.items(), key=lambda kv: -kv[1]):
     print("x%-2d M=%-7d %4d->%-4d k%d s%d res%d | %s | best t%d %.0f (auto %.0f, loss %.0f us x%d)" % (cnt, M, cin, cout, k, st, has_res, " ".join(line), best[0], best[1], auto, (auto - best[1]), cnt), flush=True)
     tot['best'] = tot.get('best', 0) + best[1] * cnt
     tot['auto'] = tot.get('auto', 0) + auto * cnt
-lib().upsnet_conv_tuning(-1, 0)
+lib().upsnet_conv_tuning(0, 0)
 print("total per image: auto %.2f ms, best-of-tiles %.2f ms" % (tot['auto'] / 1000, tot['best'] / 1000))

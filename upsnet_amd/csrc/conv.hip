@@ -686,7 +686,10 @@ static int conv_launch(hipStream_t st, ConvParams &p)
 // expensive gather, computed once per 128 output channels; 168 registers -> 3 waves per SIMD). Cout <= 32 heads use 128x32.
 // upsnet_conv_tuning(0, force_tile) overrides for A/B runs.
 static int g_force_tile = 0;
-extern "C" void upsnet_conv_tuning(int reserved, int force_tile) { (void)reserved; g_force_tile = force_tile; }
+static int g_wino_form = 0;   // 0: conv_wino.hip (16 resident accumulators), 1: the per-position walk instance of this file (A/B runs)
+extern "C" void upsnet_conv_tuning(int winograd_form, int force_tile) { g_wino_form = winograd_form; g_force_tile = force_tile; }
+int conv_wino16_launch(hipStream_t st, ConvParams &p);                                                      // conv_wino.hip
+int conv_wino16_pack(hipStream_t st, const float *weight, int cout, int cin, int ldw, float *wpack);
 
 template <int DEFORM>
 static int conv_dispatch(hipStream_t st, ConvParams &p)
@@ -835,6 +838,7 @@ extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const flo
         s.Ho = (s.OH + 1) / 2; s.Wo = (s.OW + 1) / 2;
         s.M = (long)s.N * s.Ho * s.Wo;
     }
+    if (g_wino_form == 0) return conv_wino16_launch((hipStream_t)stream, p);
     p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1;
     return conv_dispatch<4>((hipStream_t)stream, p);
 }
@@ -874,6 +878,7 @@ __global__ void conv_pack_weight_winograd_kernel(const float *__restrict__ w, in
 extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
 {
     UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout && ldw % 32 == 0, "conv_pack_weight_winograd: bad args");
+    if (g_wino_form == 0) return conv_wino16_pack((hipStream_t)stream, weight, cout, cin, ldw, wpack);
     const long total = (long)ldw * cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;

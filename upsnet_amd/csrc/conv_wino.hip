@@ -1,0 +1,326 @@
+// conv_wino.hip -- Winograd F(2x2, 3x3) convolution, fp32 MFMA, NHWC, all 16 transform-domain accumulators resident.
+//
+// Replaces the 3x3 / stride 1 / pad 1 nn.Conv2d (+ folded BN, bias, residual, ReLU) layers of the reference's ResNet-FPN
+// (upsnet/models/resnet.py:64-77, fpn.py:60-98, rpn.py:34-47) where the feature map is large enough to fill the chip.
+//
+// GEMM view: a row is one 2x2 OUTPUT TILE (its 4x4 input patch d), a column one output channel; for each of the 16 positions
+// xi = (i, j) of the transformed domain M_xi = V_xi x U_xi with V = B^T d B (input transform) and U = G g G^T (weights, packed
+// once). A workgroup (8 waves, two per SIMD) owns 64 tiles x 64 channels and keeps ALL 16 M_xi accumulators in registers:
+// wave (pair, xh) holds the 32x32 block `pair` of the eight M_xi with xi in [8 xh, 8 xh + 8) = 128 accumulator registers, so
+//   * the K walk over the input channels happens ONCE: every input pixel of the patch is loaded once per slab and transformed
+//     once (the earlier form walked K once per xi and gathered four signed pixels per A element: 4x the loads, 16x the walks),
+//   * the two waves of a SIMD cover each other: while one runs its chain of dependent MFMAs the other issues the loads, the
+//     transform and the LDS traffic (a single wave per SIMD left ~20 % of the MFMA pipe idle behind them),
+//   * the output transform Y = A^T M A needs one exchange between the two waves of a pair (M_1j <-> M_2j through LDS), after
+//     which wave xh computes and stores output row xh of every 2x2 tile.
+// Per slab of 16 input channels: thread (tile, channel pair c2) loads the tile's 16 patch pixels (float2; out-of-image pixels
+// read as 0 through the buffer bounds check), transforms them (32 float2 adds) and writes V_xi to LDS as 16-byte units
+// [xi][q = c2/2][tile ^ 2q] -- conflict-free for the ds_write_b64 and for the fragment ds_read_b128 (lane = (row, k-half)
+// reads unit [xi][2h + half][row ^ (4h + 2 half)]: 16 distinct slots per lane group). The MFMA is v_mfma_f32_32x32x2_f32:
+// lane l supplies A[row l%32][k l/32], so a float4 fragment feeds four MFMAs (lanes < 32 walk quarter 2h, lanes >= 32 quarter
+// 2h+1). The B operand (U) does not go through LDS: it is packed as [n-tile][slab][xi][q][64 channels][4] so that a lane's
+// fragment is one 16-byte load, contiguous across the wave (1 KiB), prefetched in a register ring.
+// LDS: 2 buffers x 64 KiB (double-buffered V). One workgroup per CU.
+#include "conv_params.h"
+#include "upsnet_hip.h"
+
+#define WG_STEPS 32          // (xi, h) steps per slab: 16 positions x 2 k-halves of 8 channels; 16 per wave
+#define WG_BUF 65536u        // bytes of one V buffer: 16 xi x 4 q x 64 tiles x 16 B
+#define WG_RING 4            // B fragments in flight per wave
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+
+__device__ static inline float2 f2sub(const float2 a, const float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ static inline float2 f2add(const float2 a, const float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
+__global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave & 3, xh = wave >> 2;
+    const int wm = pair & 1, wn = pair >> 1;
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles, and all n-tiles of an
+    // m-tile (they share the input patches) stay on that XCD. Same scheme as conv_igemm_f32_kernel.
+    int m_t, n_t;
+    {
+        const int nt = p.n_tiles;
+        const int per = (p.m_tiles + 7) >> 3;
+        const int q = (int)blockIdx.x >> 3;
+        n_t = q % nt;
+        const int local = q / nt;
+        m_t = ((int)blockIdx.x & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
+    }
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
+    const ConvSeg sg = p.seg[si];
+    const long p0 = (long)(m_t - sg.tile_start) * 64;
+    const int n0 = n_t * 64;
+    const int nslabs = p.Cin >> 4;
+    const long HoWo = (long)sg.Ho * sg.Wo;       // tiles per image (Ho, Wo count 2x2 output tiles here)
+
+    // ---- loader geometry: thread = (tile tid/8, channel pair tid%8)
+    const int ltile = tid >> 3, lc2 = tid & 7, lq = lc2 >> 1;
+    // byte offsets of the patch rows / columns for this thread's channel pair; a row or column outside the image carries a flag
+    // bit that pushes the sum beyond the feature map (< 1 GiB, checked at launch), where the buffer load returns 0
+    unsigned ro0, ro1, ro2, ro3, co0, co1, co2, co3;
+    {
+        const long pp = p0 + ltile;
+        const bool tile_ok = pp < sg.M;
+        const long ppc = tile_ok ? pp : sg.M - 1;
+        const int n = (int)(ppc / HoWo);
+        const int rem = (int)(ppc - (long)n * HoWo);
+        const int ty = rem / sg.Wo, tx = rem - ty * sg.Wo;
+        const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
+        const unsigned cin4 = 4u * (unsigned)p.Cin;
+        unsigned ro[4], co[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = h0 + r, w = w0 + r;
+            const unsigned rv = (unsigned)((n * sg.H + min(max(h, 0), sg.H - 1)) * sg.W) * cin4;
+            const unsigned cv = (unsigned)min(max(w, 0), sg.W - 1) * cin4 + 8u * (unsigned)lc2;
+            ro[r] = rv | ((tile_ok && h >= 0 && h < sg.H) ? 0u : 0x80000000u);
+            co[r] = cv | ((w >= 0 && w < sg.W) ? 0u : 0x40000000u);
+        }
+        ro0 = ro[0]; ro1 = ro[1]; ro2 = ro[2]; ro3 = ro[3];
+        co0 = co[0]; co1 = co[1]; co2 = co[2]; co3 = co[3];
+    }
+    // buffer descriptors from provably uniform scalars (readfirstlane), so that no load is waterfalled
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const char *xbase = reinterpret_cast<const char *>(((size_t)xhi << 32) | xlo);
+    // LDS addresses (bytes within a buffer): stash unit [xi][lq][ltile ^ 2 lq] (+ 4096 per xi), this thread's 8-byte half;
+    // fragment unit [2t + lhalf][row ^ (4h + 2 lhalf)] (+ 2048 per step t), row = 32 wm + l32
+    const unsigned st_base = (unsigned)((lq * 64 + (ltile ^ (2 * lq))) * 16 + (lc2 & 1) * 8);
+    const int frow = 32 * wm + l32;
+    const unsigned fr_base0 = (unsigned)(lhalf * 1024 + (frow ^ (2 * lhalf)) * 16 + xh * 16 * 2048);
+    const unsigned fr_base1 = (unsigned)(lhalf * 1024 + (frow ^ (4 + 2 * lhalf)) * 16 + xh * 16 * 2048);
+    // B: lane's float4 of step g = slab * 32 + t sits at wbase + g * 2048 + lhalf * 1024 + (32 wn + l32) * 16
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)n_t * (size_t)nslabs * (WG_STEPS * 2048u);
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0,
+                                                                            nslabs * (WG_STEPS * 2048), 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * 1024 + (32 * wn + l32) * 16);
+    const int gmax = nslabs * WG_STEPS - 1;
+    const int xh_u = __builtin_amdgcn_readfirstlane(xh);
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#define WG_PO(PX) (((PX) >> 2) == 0 ? ro0 : ((PX) >> 2) == 1 ? ro1 : ((PX) >> 2) == 2 ? ro2 : ro3) + (((PX) & 3) == 0 ? co0 : ((PX) & 3) == 1 ? co1 : ((PX) & 3) == 2 ? co2 : co3)
+    float2 ld[16];     // patch pixels of the slab being staged; after the row pass: (d B)[r][j]
+    float4 breg[WG_RING];
+
+#define WG_LOAD(PX, RS) { const uintx2 v_ = __builtin_amdgcn_raw_buffer_load_b64(RS, WG_PO(PX), 0, 0); ld[PX] = make_float2(__uint_as_float(v_.x), __uint_as_float(v_.y)); }
+    // row pass of the input transform on patch row R: (d B)[R][0..3]
+#define WG_ROWPASS(R)                                                                                                 \
+    {                                                                                                                 \
+        const float2 d0 = ld[4 * R + 0], d1 = ld[4 * R + 1], d2 = ld[4 * R + 2], d3 = ld[4 * R + 3];                 \
+        ld[4 * R + 0] = f2sub(d0, d2); ld[4 * R + 1] = f2add(d1, d2); ld[4 * R + 2] = f2sub(d2, d1); ld[4 * R + 3] = f2sub(d1, d3); \
+    }
+    // column pass + stash of V[i][J] for i = 0..3 into the buffer at byte address SB
+#define WG_COLSTASH(J, SB)                                                                                            \
+    {                                                                                                                 \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (0 * 4 + J) * 4096) = f2sub(ld[0 + J], ld[8 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (1 * 4 + J) * 4096) = f2add(ld[4 + J], ld[8 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (2 * 4 + J) * 4096) = f2sub(ld[8 + J], ld[4 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (3 * 4 + J) * 4096) = f2sub(ld[4 + J], ld[12 + J]);           \
+    }
+#define WG_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 2048u, 0); \
+        breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+
+    // ---- prologue: slab 0 into buffer 0, first ring of B fragments
+    {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase), 0, xbytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) WG_LOAD(i, xr)
+#pragma unroll
+        for (int u = 0; u < WG_RING; ++u) WG_BLOAD(u, 16 * xh_u + u)
+        WG_ROWPASS(0) WG_ROWPASS(1) WG_ROWPASS(2) WG_ROWPASS(3)
+        WG_COLSTASH(0, st_base) WG_COLSTASH(1, st_base) WG_COLSTASH(2, st_base) WG_COLSTASH(3, st_base)
+    }
+    __syncthreads();
+    float4 afr = *reinterpret_cast<const float4 *>(smem_raw + fr_base0);    // fragment of this wave's step 0
+
+    for (int s = 0; s < nslabs; ++s) {
+        const int sn = min(s + 1, nslabs - 1);                              // next slab (last slab: harmless re-stage of itself)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase) + (size_t)sn * 64, 0, xbytes - (unsigned)sn * 64u, 0x00020000);
+        const unsigned cur = (s & 1) ? WG_BUF : 0u, nxt = WG_BUF - cur;
+        const unsigned sb = nxt + st_base;
+        const int g0 = s * WG_STEPS + 16 * xh_u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            // (1) global loads of the next slab's patch: two pixels per step in steps 0..7
+            if (u < 8) { WG_LOAD(2 * u, xr) WG_LOAD(2 * u + 1, xr) }
+            // (2) A fragment of the next step (step 0 of the next slab comes from the other buffer, after the barrier)
+            float4 afn;
+            if (u < 15) afn = *reinterpret_cast<const float4 *>(smem_raw + cur + (((u + 1) & 1) ? fr_base1 : fr_base0) + (unsigned)(u + 1) * 2048u);
+            else afn = *reinterpret_cast<const float4 *>(smem_raw + nxt + fr_base0);
+            // (3) input transform of the next slab and its stash into the other buffer
+            if (u == 8) WG_ROWPASS(0)
+            if (u == 9) WG_ROWPASS(1)
+            if (u == 10) WG_ROWPASS(2)
+            if (u == 11) { WG_ROWPASS(3) WG_COLSTASH(0, sb) }
+            if (u == 12) WG_COLSTASH(1, sb)
+            if (u == 13) WG_COLSTASH(2, sb)
+            if (u == 14) WG_COLSTASH(3, sb)
+            // (4) the four MFMAs of step (xi = 8 xh + u/2, h = u%2): channels 4(2h + half) .. +3 of the slab
+            const float4 bf = breg[u % WG_RING];
+            acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.x, bf.x, acc[u >> 1], 0, 0, 0);
+            acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.y, bf.y, acc[u >> 1], 0, 0, 0);
+            acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.z, bf.z, acc[u >> 1], 0, 0, 0);
+            acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.w, bf.w, acc[u >> 1], 0, 0, 0);
+            // (5) refill the ring slot just consumed: this wave's step 8 ahead (wraps into the next slab)
+            WG_BLOAD(u % WG_RING, (u + WG_RING < 16 ? g0 : g0 + 16) + u + WG_RING)
+            if (u == 14) __syncthreads();   // every read of `cur` is issued, every stash into `nxt` is visible
+            afr = afn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef WG_LOAD
+#undef WG_PO
+#undef WG_ROWPASS
+#undef WG_COLSTASH
+#undef WG_BLOAD
+
+    // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]. acc[4 il + j] = M[2 xh + il][j]. Wave xh = 0 needs M_2j,
+    // wave xh = 1 needs M_1j: one float4 per accumulator element through LDS ([pair][direction][r][lane] 16-byte units).
+    __syncthreads();
+    {
+        float4 *mine = reinterpret_cast<float4 *>(smem_raw + pair * 32768 + xh_u * 16384) + lane;
+        const float4 *theirs = reinterpret_cast<const float4 *>(smem_raw + pair * 32768 + (1 - xh_u) * 16384) + lane;
+        if (xh_u == 0) {                    // xh = 0 gives M_1j = acc[4 + j], xh = 1 gives M_2j = acc[j]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+        __syncthreads();
+        const bool has_res = sg.res != nullptr;
+        const long pbase = p0 + wm * 32 + 4 * lhalf;
+        const long pb = pbase < sg.M ? pbase : sg.M - 1;
+        const int n_b = (int)(pb / HoWo);
+        const int rem_b = (int)(pb - (long)n_b * HoWo);
+        const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+        const bool fast = sg.Wo >= 32;
+        const int co = n0 + wn * 32 + l32;
+        const bool co_ok = co < p.Cout;
+        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = (r & 3) + 8 * (r >> 2);
+            const float4 o = theirs[r * 64];
+            if (!(co_ok && pbase + off < sg.M)) continue;
+            int n = n_b, h = h_b, w = w_b;
+            if (fast) {
+                w += off;
+                if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+            } else {
+                const long pp = pbase + off;
+                n = (int)(pp / HoWo);
+                const int rem = (int)(pp - (long)n * HoWo);
+                h = rem / sg.Wo; w = rem - h * sg.Wo;
+            }
+            // t[j] = sum_i A^T[xh][i] M[i][j]: row 0: (M0j + M1j) + M2j, row 1: (M1j - M2j) - M3j
+            float t0, t1, t2, t3;
+            if (xh_u == 0) {
+                t0 = (acc[0][r] + acc[4][r]) + o.x; t1 = (acc[1][r] + acc[5][r]) + o.y;
+                t2 = (acc[2][r] + acc[6][r]) + o.z; t3 = (acc[3][r] + acc[7][r]) + o.w;
+            } else {
+                t0 = (o.x - acc[0][r]) - acc[4][r]; t1 = (o.y - acc[1][r]) - acc[5][r];
+                t2 = (o.z - acc[2][r]) - acc[6][r]; t3 = (o.w - acc[3][r]) - acc[7][r];
+            }
+            float v0 = ((t0 + t1) + t2) + bv, v1 = ((t1 - t2) - t3) + bv;
+            const int oy = 2 * h + xh_u, ox = 2 * w;
+            if (oy >= sg.OH) continue;
+            const bool x1 = ox + 1 < sg.OW;
+            const long o0 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
+            const long o1 = o0 + p.Cout;
+            if (has_res) {
+                v0 = v0 + sg.res[o0];
+                if (x1) v1 = v1 + sg.res[o1];
+            }
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            sg.out[o0] = v0;
+            if (x1) sg.out[o1] = v1;
+        }
+    }
+}
+
+// Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
+int conv_wino16_launch(hipStream_t st, ConvParams &p)
+{
+    UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
+    int tiles = 0;
+    for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + 63) / 64); }
+    p.m_tiles = tiles;
+    p.n_tiles = p.ldw / 64;
+    for (int i = 0; i < p.nseg; ++i)
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
+    const size_t smem = 2 * WG_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    hipLaunchKernelGGL(conv_wino16_f32_kernel, dim3(grid), dim3(512), smem, st, p);
+    UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
+    return 0;
+}
+
+// weight [Cout, Cin, 3, 3] -> U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in fragment order
+// [n-tile = co/64][slab = c/16][xi = 4i+j][q = (c%16)/4][co%64][c%4] (16 * Cin * ldw floats, ldw = Cout rounded up to 64)
+__global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
+{
+    const long total = (long)ldw * cin;
+    const int nslabs = cin >> 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int co = idx % ldw, c = idx / ldw;
+        float g[3][3], t[4][3], u[4][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = co < cout ? w[(((long)co * cin + c) * 3 + a) * 3 + b] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u[a][0] = t[a][0];
+            u[a][1] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+            u[a][2] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+            u[a][3] = t[a][2];
+        }
+        const long blk = ((long)(co >> 6) * nslabs + (c >> 4)) * 16;
+        const int q = (c & 15) >> 2, ci = c & 3, cl = co & 63;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wp[(((blk + a * 4 + b) * 4 + q) * 64 + cl) * 4 + ci] = u[a][b];
+    }
+}
+
+int conv_wino16_pack(hipStream_t st, const float *weight, int cout, int cin, int ldw, float *wpack)
+{
+    UPS_REQUIRE(cin % 16 == 0 && ldw % 64 == 0, "conv_pack_weight_winograd: Cin %% 16 and ldw %% 64 must be 0");
+    const long total = (long)ldw * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(conv_pack_weight_wino16_kernel, dim3(blocks), dim3(256), 0, st, weight, cout, cin, ldw, wpack);
+    UPS_CHECK_LAUNCH("conv_pack_weight_wino16_kernel");
+    return 0;
+}

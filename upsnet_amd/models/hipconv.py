@@ -15,10 +15,11 @@ from .. import ops
 import os
 
 ENABLED = True
-# 3x3 / stride-1 layers with enough 2x2 output tiles to fill the chip go through the fused Winograd F(2x2,3x3) instance of the
-# kernel (1.3-1.7x faster there; same fp32 arithmetic class, ~1e-6 relative difference). Smaller layers stay on the direct form.
+# 3x3 / stride-1 layers with enough 2x2 output tiles to occupy half the chip go through the Winograd F(2x2,3x3) kernel
+# (csrc/conv_wino.hip; 1.2-2.2x faster there, tools/bench_winograd.py; same fp32 arithmetic class, ~1e-5 absolute difference).
+# Smaller layers stay on the direct form.
 WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
-WINOGRAD_MIN_WORKGROUPS = 256
+WINOGRAD_MIN_WORKGROUPS = int(os.environ.get('UPSNET_WINOGRAD_MIN_WG', '128'))
 SPLITK = os.environ.get('UPSNET_SPLITK', '1') != '0'
 # Arithmetic of the dense convolutions: 'fp32' (default; exact fp32 products on the fp32 MFMA, the configuration every headline
 # number is measured on), 'bf16x3' (bf16 matrix cores, 3-term split, fp32-equivalent to ~1e-5) or 'bf16' (BASELINE.json
@@ -75,10 +76,12 @@ def _winograd_plan(m):
     return ent[1], ent[2]
 
 
-def _use_winograd(m, xs):
+def _use_winograd(m, xs, always=False):
     if not (WINOGRAD and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (1, 1) and
-            m.out_channels >= 64):   # (narrow heads -- DCN offsets, Cout = 18 -- are faster on the direct 128x32 instance)
+            tuple(m.dilation) == (1, 1) and m.in_channels % 16 == 0):
         return False
+    if always:
+        return True
     tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // 64) for x in xs)
     return tiles * (-(-m.out_channels // 64)) >= WINOGRAD_MIN_WORKGROUPS
 
@@ -101,13 +104,14 @@ def _ksplit(m, x, ldw):
 
 def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
-    winograd=False pins the direct form (layers whose batch size varies at run time and whose results must not depend on it)."""
+    winograd=False / 'always' pins the direct / the Winograd form (layers whose batch size varies at run time: the choice,
+    hence the rounding, must not depend on it)."""
     if supported(m, x):
         if PRECISION != 'fp32' and not residual_up:
             hi, lo, ldw = _bf16_plan(m)
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual])[0]
-        if winograd and not residual_up and _use_winograd(m, [x]):
+        if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0]

@@ -39,9 +39,10 @@ class MaskBranch(nn.Module):
     def forward(self, feat, rois):
         x = self.roi_pooling(feat, rois)
         for blk in (self.mask_conv1, self.mask_conv2, self.mask_conv3, self.mask_conv4):
-            # direct form pinned: the ROI count varies per image and per pass, and the logits of a ROI must not depend on how
-            # many other ROIs share the launch (the fused pipeline's single pass == the reference's two passes, bit for bit)
-            x = hipconv.conv(blk[0], x, relu=True, winograd=False)
+            # Winograd form pinned whatever the ROI count: it varies per image and per pass, and the logits of a ROI must not
+            # depend on how many other ROIs share the launch (the fused pipeline's single pass == the reference's two passes,
+            # bit for bit) -- every 2x2 output tile is computed independently of the others, in a fixed K order
+            x = hipconv.conv(blk[0], x, relu=True, winograd='always')
         return hipconv.conv(self.mask_score, hipconv.deconv2x2(self.mask_deconv1[0], x, relu=True))
 
 
