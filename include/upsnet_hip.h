@@ -179,6 +179,13 @@ int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const float *res
 int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
                                     float *const out[], const int batch[], const int height[], const int width[], int Cin,
                                     const float *wpack, int ldw, const float *bias, int Cout, int relu);
+
+/* The same convolution of ONE map with the K walk split `ksplit` (2..8) ways -- maps with too few 2x2 tiles to fill 256 CUs
+ * (res4 / res5 3x3, FPN P4; replaces the same nn.Conv2d call sites). workspace: upsnet_conv2d_splitk_workspace_bytes(batch,
+ * height, width, Cout, 3, 3, 1, 1, ksplit) bytes. Fixed summation order: bit-repeatable. */
+int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,
+                                           int width, int Cin, const float *wpack, int ldw, const float *bias, int Cout, int relu,
+                                           int ksplit, void *workspace);
 int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
 
 /* Dense convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- BASELINE.json configs[2]

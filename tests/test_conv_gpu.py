@@ -131,6 +131,37 @@ def test_winograd_conv_vs_torch(shapes, Cin, Cout, relu, res, bias):
     assert all(torch.equal(a, o) for a, o in zip(again, outs))   # fixed summation order: bit-repeatable
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ksplit,relu,res", [
+    (1, 64, 128, 256, 256, 2, True, False),     # res4 3x3
+    (1, 32, 64, 512, 512, 4, True, False),      # res5 3x3
+    (1, 33, 47, 64, 96, 2, False, True),        # odd sizes, residual, Cout not a multiple of 64
+    (2, 14, 14, 256, 256, 8, True, True),       # 16 slabs split 8 ways
+    (1, 9, 7, 96, 32, 3, False, False),         # 6 slabs split 3 ways
+])
+def test_winograd_splitk_vs_torch(N, H, W, Cin, Cout, ksplit, relu, res):
+    """Winograd with the K walk split over `ksplit` workgroups per tile + the shared reduce kernel vs torch fp64 (1e-4) and
+    vs the unsplit Winograd launch."""
+    from upsnet_amd import ops
+    torch.manual_seed(H + W + Cin + ksplit)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    r = torch.randn(N, Cout, H, W, device='cuda') if res else None
+    wp, ldw = ops.pack_winograd_weight(w)
+    out = ops.conv2d_winograd_splitk(x, wp, ldw, b, Cout, ksplit, relu=relu, residual=r)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    one = ops.conv2d_winograd_multi([x], wp, ldw, b, Cout, relu=relu, residuals=None if r is None else [r])[0]
+    assert float((out - one).abs().max()) < 2e-5
+    assert torch.equal(out, ops.conv2d_winograd_splitk(x, wp, ldw, b, Cout, ksplit, relu=relu, residual=r))   # bit-repeatable
+    with pytest.raises(RuntimeError):
+        ops.conv2d_winograd_splitk(x, wp, ldw, b, Cout, 9, relu=relu, residual=r)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,pad,relu,res", [
     (1, 64, 64, 33, 47, 3, 1, 1, True, False),
     (1, 256, 64, 40, 56, 1, 1, 0, True, False),

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "upsnet_unified_pan_result": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_mask_roi_dedup": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P]),
     "upsnet_conv2d_winograd_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int]),
+    "upsnet_conv2d_winograd_nhwc_f32_splitk": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P]),
     "upsnet_conv_pack_weight_winograd": (c_int, [P, P, c_int, c_int, c_int, P]),
     "upsnet_conv2d_nhwc_bf16": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_pack_weight_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),

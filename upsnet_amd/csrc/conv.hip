@@ -843,6 +843,38 @@ extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const flo
     return conv_dispatch<4>((hipStream_t)stream, p);
 }
 
+// Winograd with the K walk split `ksplit` ways (maps with too few 2x2 tiles to fill the chip: res4 / res5 / FPN P4): partial
+// output tiles into the workspace (upsnet_conv2d_splitk_workspace_bytes with a 3x3 / 1 / 1 geometry), then the shared reduction.
+extern "C" int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,
+                                                      int width, int Cin, const float *wpack, int ldw, const float *bias, int Cout, int relu,
+                                                      int ksplit, void *workspace)
+{
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = conv_fill(p, "conv2d_winograd_nhwc_f32_splitk", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias, 3, 3,
+                       1, 1, 1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE(g_wino_form == 0, "conv2d_winograd_nhwc_f32_splitk: only the resident-accumulator form splits K");
+    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8, "conv2d_winograd_nhwc_f32_splitk: ksplit must be 2..8 and a workspace given");
+    UPS_REQUIRE(Cout % 4 == 0, "conv2d_winograd_nhwc_f32_splitk: Cout must be a multiple of 4");
+    ConvSeg &sg = p.seg[0];
+    sg.OH = sg.Ho; sg.OW = sg.Wo;
+    sg.Ho = (sg.OH + 1) / 2; sg.Wo = (sg.OW + 1) / 2;
+    sg.M = (long)sg.N * sg.Ho * sg.Wo;
+    p.ksplit = ksplit;
+    p.partial = (float *)workspace;
+    rc = conv_wino16_launch((hipStream_t)stream, p);
+    if (rc) return rc;
+    const long M = p.m_total;   // output pixels
+    const long n = M * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.partial, ksplit,
+                       p.m_total, M, Cout, bias, residual, relu, out);
+    UPS_CHECK_LAUNCH("conv_splitk_reduce_kernel");
+    return 0;
+}
+
 // weight [Cout, Cin, 3, 3] -> U [(i*4+j)*Cin + c, ldw] = (G g G^T)[i][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ void conv_pack_weight_winograd_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
 {

@@ -34,6 +34,9 @@ typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 __device__ static inline float2 f2sub(const float2 a, const float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ static inline float2 f2add(const float2 a, const float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
+// SPLITK: the K walk is divided over p.ksplit workgroups per tile; each writes its raw output-transformed partial sums to
+// p.partial [ksplit][N*OH*OW][Cout] (the transform is linear), reduced with bias / residual / ReLU by conv_splitk_reduce_kernel.
+template <bool SPLITK>
 __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -43,14 +46,17 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
     const int lhalf = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles, and all n-tiles of an
     // m-tile (they share the input patches) stay on that XCD. Same scheme as conv_igemm_f32_kernel.
-    int m_t, n_t;
+    int m_t, n_t, kz;
     {
         const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
-        const int q = (int)blockIdx.x >> 3;
+        const int base_grid = 8 * per * nt;
+        kz = SPLITK ? (int)blockIdx.x / base_grid : 0;
+        const int bid = (int)blockIdx.x - kz * base_grid;
+        const int q = bid >> 3;
         n_t = q % nt;
         const int local = q / nt;
-        m_t = ((int)blockIdx.x & 7) * per + local;
+        m_t = (bid & 7) * per + local;
         if (local >= per || m_t >= p.m_tiles) return;
     }
     int si = 0;
@@ -60,6 +66,8 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
     const long p0 = (long)(m_t - sg.tile_start) * 64;
     const int n0 = n_t * 64;
     const int nslabs = p.Cin >> 4;
+    const int s_per = SPLITK ? (nslabs + p.ksplit - 1) / p.ksplit : nslabs;
+    const int s_begin = kz * s_per, s_end = min(s_begin + s_per, nslabs);   // slabs walked by this workgroup (launcher: never empty)
     const long HoWo = (long)sg.Ho * sg.Wo;       // tiles per image (Ho, Wo count 2x2 output tiles here)
 
     // ---- loader geometry: thread = (tile tid/8, channel pair tid%8)
@@ -138,21 +146,21 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
 
     // ---- prologue: slab 0 into buffer 0, first ring of B fragments
     {
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase), 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase) + (size_t)s_begin * 64, 0, xbytes - (unsigned)s_begin * 64u, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 16; ++i) WG_LOAD(i, xr)
 #pragma unroll
-        for (int u = 0; u < WG_RING; ++u) WG_BLOAD(u, 16 * xh_u + u)
+        for (int u = 0; u < WG_RING; ++u) WG_BLOAD(u, s_begin * WG_STEPS + 16 * xh_u + u)
         WG_ROWPASS(0) WG_ROWPASS(1) WG_ROWPASS(2) WG_ROWPASS(3)
         WG_COLSTASH(0, st_base) WG_COLSTASH(1, st_base) WG_COLSTASH(2, st_base) WG_COLSTASH(3, st_base)
     }
     __syncthreads();
     float4 afr = *reinterpret_cast<const float4 *>(smem_raw + fr_base0);    // fragment of this wave's step 0
 
-    for (int s = 0; s < nslabs; ++s) {
-        const int sn = min(s + 1, nslabs - 1);                              // next slab (last slab: harmless re-stage of itself)
+    for (int s = s_begin; s < s_end; ++s) {
+        const int sn = min(s + 1, s_end - 1);                              // next slab (last slab: harmless re-stage of itself)
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase) + (size_t)sn * 64, 0, xbytes - (unsigned)sn * 64u, 0x00020000);
-        const unsigned cur = (s & 1) ? WG_BUF : 0u, nxt = WG_BUF - cur;
+        const unsigned cur = ((s - s_begin) & 1) ? WG_BUF : 0u, nxt = WG_BUF - cur;
         const unsigned sb = nxt + st_base;
         const int g0 = s * WG_STEPS + 16 * xh_u;
 #pragma unroll
@@ -239,12 +247,19 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
                 t0 = (o.x - acc[0][r]) - acc[4][r]; t1 = (o.y - acc[1][r]) - acc[5][r];
                 t2 = (o.z - acc[2][r]) - acc[6][r]; t3 = (o.w - acc[3][r]) - acc[7][r];
             }
-            float v0 = ((t0 + t1) + t2) + bv, v1 = ((t1 - t2) - t3) + bv;
+            float v0 = (t0 + t1) + t2, v1 = (t1 - t2) - t3;
             const int oy = 2 * h + xh_u, ox = 2 * w;
             if (oy >= sg.OH) continue;
             const bool x1 = ox + 1 < sg.OW;
             const long o0 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
             const long o1 = o0 + p.Cout;
+            if (SPLITK) {
+                float *part = p.partial + (long)kz * p.m_total * p.Cout;
+                part[o0] = v0;
+                if (x1) part[o1] = v1;
+                continue;
+            }
+            v0 = v0 + bv; v1 = v1 + bv;
             if (has_res) {
                 v0 = v0 + sg.res[o0];
                 if (x1) v1 = v1 + sg.res[o1];
@@ -257,6 +272,7 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
 }
 
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
+// p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
 int conv_wino16_launch(hipStream_t st, ConvParams &p)
 {
     UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
@@ -269,11 +285,20 @@ int conv_wino16_launch(hipStream_t st, ConvParams &p)
     const size_t smem = 2 * WG_BUF;
     static bool attr_set = false;
     if (!attr_set) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-    hipLaunchKernelGGL(conv_wino16_f32_kernel, dim3(grid), dim3(512), smem, st, p);
+    if (p.ksplit > 1) {
+        const int nslabs = p.Cin / 16;
+        UPS_REQUIRE(p.nseg == 1 && p.partial, "conv2d_winograd_nhwc_f32_splitk: one map and a workspace");
+        UPS_REQUIRE(((nslabs + p.ksplit - 1) / p.ksplit) * (p.ksplit - 1) < nslabs, "conv2d_winograd_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, p.ksplit);
+        p.m_total = (long)p.seg[0].N * p.seg[0].OH * p.seg[0].OW;
+        hipLaunchKernelGGL(conv_wino16_f32_kernel<true>, dim3(grid * p.ksplit), dim3(512), smem, st, p);
+    } else {
+        hipLaunchKernelGGL(conv_wino16_f32_kernel<false>, dim3(grid), dim3(512), smem, st, p);
+    }
     UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
     return 0;
 }

@@ -82,8 +82,26 @@ def _use_winograd(m, xs, always=False):
         return False
     if always:
         return True
+    return _wino_workgroups(m, xs) * (_wino_ksplit(m, xs) if len(xs) == 1 else 1) >= WINOGRAD_MIN_WORKGROUPS
+
+
+def _wino_workgroups(m, xs):
     tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // 64) for x in xs)
-    return tiles * (-(-m.out_channels // 64)) >= WINOGRAD_MIN_WORKGROUPS
+    return tiles * (-(-m.out_channels // 64))
+
+
+def _wino_ksplit(m, xs):
+    """Split-K factor of the Winograd kernel for one map with too few 64-tile x 64-channel workgroups for 256 CUs (res4 / res5
+    3x3, FPN P4 / P5): the largest split that keeps <= 256 workgroups (one round) and >= 4 slabs of 16 channels per workgroup."""
+    if not SPLITK or len(xs) != 1 or m.out_channels % 4:
+        return 1
+    wgs, slabs = _wino_workgroups(m, xs), m.in_channels // 16
+    if wgs > 160:
+        return 1
+    k = 1
+    while k < 8 and wgs * (k + 1) <= 256 and slabs // (k + 1) >= 4:
+        k += 1
+    return k
 
 
 def _ksplit(m, x, ldw):
@@ -113,6 +131,9 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
                                               relu=relu, residuals=None if residual is None else [residual])[0]
         if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
+            ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])
+            if ks > 1:
+                return ops.conv2d_winograd_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu, residual=residual)
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0]
         wp, ldw = _plan(m)

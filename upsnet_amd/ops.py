@@ -216,7 +216,8 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
         npix = sum(o.shape[2] * o.shape[3] for o in outs)
         taps = ksize[0] * ksize[1]
         PROFILE['events'].append(('dcn_fused', ev0, ev1, 2.0 * cout * cin * taps * npix,
-                                  4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps)))
+                                  4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps),
+                                  "dcn %d->%d %s" % (cin, cout, [tuple(x.shape[2:]) for x in xs])))
     return outs
 
 
@@ -456,7 +457,9 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
         npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
         nin = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
-                                  4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1) + cout * cin * ksize * ksize)))
+                                  4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1) + cout * cin * ksize * ksize),
+                                  "direct %dx%d/%d %d->%d %s%s" % (ksize, ksize, stride, cin, cout, [tuple(x.shape[0:1] + x.shape[2:]) for x in xs],
+                                                                    " +res" if ress is not None else "")))
     return outs
 
 
@@ -637,6 +640,33 @@ def pack_winograd_weight(weight):
     return wp, ldw
 
 
+def conv2d_winograd_splitk(x, wpack, ldw, bias, cout, ksplit, relu=False, residual=None):
+    """conv2d_winograd for one small map with the K walk split over `ksplit` workgroups per tile (+ the shared reduce kernel)."""
+    require_cuda(x, wpack)
+    x = nhwc(x.float())
+    N, C, H, W = x.shape
+    out = _nhwc_out(N, cout, H, W, x.device)
+    res = None
+    if residual is not None:
+        res = nhwc(residual.float())
+        if tuple(res.shape) != tuple(out.shape):
+            raise RuntimeError("conv2d_winograd_splitk: residual shape %s != %s" % (tuple(res.shape), tuple(out.shape)))
+    ws = _ws(lib().upsnet_conv2d_splitk_workspace_bytes(N, H, W, int(cout), 3, 3, 1, 1, int(ksplit)), x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_winograd_nhwc_f32_splitk(stream(), ptr(x), ptr(res), ptr(out), N, H, W, C, ptr(wpack), int(ldw),
+                                                       ptr(None if bias is None else f32c(bias)), int(cout), int(bool(relu)), int(ksplit),
+                                                       ptr(ws)), "conv2d_winograd_nhwc_f32_splitk")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * H * W
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * C * 9 * npix,
+                                  4.0 * (C * npix + cout * npix * (2 if res is not None else 1) + cout * C * 9),
+                                  "winograd split-K x%d 3x3/1 %d->%d %s" % (ksplit, C, cout, (N, H, W))))
+    return out
+
+
 def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None):
     """3x3 / stride 1 / pad 1 convolution of up to 5 maps (shared weights) by fused Winograd F(2x2,3x3); same contract as
     conv2d_nhwc_multi."""
@@ -668,7 +698,9 @@ def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None
         npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
         # algorithmic work of the convolution (direct-form flops), as for the direct kernel
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix,
-                                  4.0 * (cin * npix + cout * npix * (2 if ress is not None else 1) + cout * cin * 9)))
+                                  4.0 * (cin * npix + cout * npix * (2 if ress is not None else 1) + cout * cin * 9),
+                                  "winograd 3x3/1 %d->%d %s%s" % (cin, cout, [tuple(x.shape[0:1] + x.shape[2:]) for x in xs],
+                                                                  " +res" if ress is not None else "")))
     return outs
 
 
@@ -744,5 +776,6 @@ def conv2d_nhwc_splitk(x, wpack, ldw, bias, cout, ksize, stride, pad, ksplit, re
         ev1.record()
         npix = N * Ho * Wo
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * C * ksize * ksize * npix,
-                                  4.0 * (C * N * H * W + cout * npix * (2 if res is not None else 1) + cout * C * ksize * ksize)))
+                                  4.0 * (C * N * H * W + cout * npix * (2 if res is not None else 1) + cout * C * ksize * ksize),
+                                  "split-K x%d %dx%d/%d %d->%d %s" % (ksplit, ksize, ksize, stride, C, cout, (N, H, W))))
     return out
