@@ -170,12 +170,14 @@ int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const float *res
                                   int Cin, const float *wpack, int ldw, const float *bias, int Cout, int KH, int KW, int stride,
                                   int pad, int relu, int ksplit, void *workspace);
 
-/* 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2, 3x3) on the same MFMA kernel (16/36 of the multiplies of the
- * direct form; all arithmetic fp32; differs from the direct kernel by fp32 rounding only, ~1e-6 relative -- cuDNN, the
- * reference's convolution backend, uses the same algorithm). The input transform (a signed sum of four pixels per
- * position) is the A-operand loader, the 16 per-position GEMMs run back to back in one workgroup, the output transform is
- * folded into the accumulators. wpack [16*Cin, ldw] from upsnet_conv_pack_weight_winograd (weight [Cout,Cin,3,3]).
- * Same calling convention as upsnet_conv2d_nhwc_f32 (multi-map launch, bias / residual / ReLU epilogue). */
+/* 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) on the fp32 MFMA (csrc/conv_wino.hip; 16/36 of the multiplies
+ * of the direct form; all arithmetic fp32; differs from the direct kernel by fp32 rounding only, ~1e-5 absolute on unit-scale
+ * data -- cuDNN, the reference's convolution backend, uses the same algorithm). Replaces the 3x3 nn.Conv2d layers of
+ * upsnet/models/resnet.py:64-77, fpn.py:60-98, rpn.py:34-47 and the mask head rcnn.py:96-116 where the map has enough 2x2
+ * tiles. A workgroup keeps all 16 transform-domain accumulators of its 64 tiles x 64 channels in registers: one walk over the
+ * input channels, each patch pixel loaded and transformed once, lane-local output transform. Cin % 16 == 0 (conv_fill: % 32),
+ * ldw = Cout rounded up to 64; wpack (16 * Cin * ldw floats, fragment order) from upsnet_conv_pack_weight_winograd
+ * (weight [Cout,Cin,3,3]). Same calling convention as upsnet_conv2d_nhwc_f32 (multi-map launch, bias / residual / ReLU). */
 int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
                                     float *const out[], const int batch[], const int height[], const int width[], int Cin,
                                     const float *wpack, int ldw, const float *bias, int Cout, int relu);
@@ -221,10 +223,8 @@ int upsnet_deconv2x2_nhwc_f32(void *stream, const float *x, int batch, int heigh
 int upsnet_deconv2x2_pack_weight(void *stream, const float *weight, int cin, int cout, int ldw, float *wpack);
 
 /* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
- * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). winograd_form = 0: the Winograd entry points
- * below use the kernel with all 16 transform-domain accumulators resident (conv_wino.hip), 1: the earlier per-position walk;
- * the packed weight layout differs, so set it before packing. Not needed in production. */
-void upsnet_conv_tuning(int winograd_form, int force_tile);
+ * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). `reserved` is ignored. Not needed in production. */
+void upsnet_conv_tuning(int reserved, int force_tile);
 
 /* weight [Cout, Cin, kh, kw] (nn.Conv2d layout) -> wpack [kh*kw*Cin, ldw] (tap-major rows, zero-padded columns). */
 int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);

@@ -30,12 +30,9 @@ for name, segs, cin, cout in shapes:
     ref = ops.conv2d_nhwc_multi(xs, wd, ldd, b, cout, 3, 1, 1, True)
     gf = 2.0 * cout * cin * 9 * sum(n * h * w for n, h, w in segs) / 1e9
     line = "%-28s %6.1f GFLOP | direct %7.1f us (%5.1f TF)" % (name, gf, td, gf / td * 1e3)
-    for form in (1, 0):                      # 1: per-position walks, 0: 16 resident accumulators (conv_wino.hip)
-        lib().upsnet_conv_tuning(form, 0)
-        ww, ldw = ops.pack_winograd_weight(wgt)
-        tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
-        got = ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True)
-        err = max(float((g - r).abs().max()) for g, r in zip(got, ref))
-        line += " | form %d %7.1f us (%5.1f TF-equiv, x%.2f, err %.1e)" % (form, tw, gf / tw * 1e3, td / tw, err)
-    lib().upsnet_conv_tuning(0, 0)
+    ww, ldw = ops.pack_winograd_weight(wgt)
+    tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
+    got = ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True)
+    err = max(float((g - r).abs().max()) for g, r in zip(got, ref))
+    line += " | winograd %7.1f us (%5.1f TF-equiv, x%.2f, err %.1e)" % (tw, gf / tw * 1e3, td / tw, err)
     print(line, flush=True)

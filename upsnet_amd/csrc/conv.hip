@@ -81,59 +81,6 @@ __device__ static inline float dcn_blend1(const DcnDesc &d, float v1, float v2, 
     return val;
 }
 
-// Winograd F(2x2, 3x3) loader (DEFORM == 4). The GEMM "pixel" is a 2x2 OUTPUT TILE and the "tap" is one of the 16 positions
-// xi = (i, j) of the transformed domain: V_xi = (B^T d B)[i][j] of the tile's 4x4 input patch d. Every row of
-// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] has two non-zeros, so V_xi is a signed sum of FOUR input pixels: the
-// loader is the deformable one with integer offsets and weights +-1 (0 outside the image = zero padding). The 16 per-position
-// GEMMs against U_xi = (G g G^T)[i][j] run back to back in one workgroup; after the K walk of a position its accumulator
-// is folded into the four output accumulators Y = A^T M A (coefficients 0 / +-1) -- 16/36 of the multiplies of the direct form.
-struct WinoDesc {
-    unsigned o1, o2, o3, o4;
-    float w1, w2, w3, w4;
-};
-
-__device__ static inline void wino_sel(const int i, int &a1, int &a2, float &s1, float &s2)
-{
-    a1 = i == 0 ? 0 : 1;
-    a2 = i == 3 ? 3 : 2;
-    s1 = i == 2 ? -1.f : 1.f;
-    s2 = (i == 0 || i == 3) ? -1.f : 1.f;
-}
-
-// (h0, w0): input coordinates of the patch origin (2*ty - 1, 2*tx - 1); nb: element offset of (image, channel group)
-__device__ static inline WinoDesc wino_desc(const ConvSeg &sg, const int pix_n, const int nb, const int h0, const int w0, const int i,
-                                            const int j, const int cin)
-{
-    int a1, a2, b1, b2;
-    float sa1, sa2, sb1, sb2;
-    wino_sel(i, a1, a2, sa1, sa2);
-    wino_sel(j, b1, b2, sb1, sb2);
-    const int H = sg.H, W = sg.W;
-    const int ha = h0 + a1, hb = h0 + a2, wa = w0 + b1, wb = w0 + b2;
-    const bool ok = pix_n >= 0;
-    const bool vha = ok && ha >= 0 && ha < H, vhb = ok && hb >= 0 && hb < H, vwa = wa >= 0 && wa < W, vwb = wb >= 0 && wb < W;
-    const int hac = min(max(ha, 0), H - 1), hbc = min(max(hb, 0), H - 1), wac = min(max(wa, 0), W - 1), wbc = min(max(wb, 0), W - 1);
-    WinoDesc d;
-    d.o1 = 4u * (unsigned)(nb + (hac * W + wac) * cin);
-    d.o2 = 4u * (unsigned)(nb + (hac * W + wbc) * cin);
-    d.o3 = 4u * (unsigned)(nb + (hbc * W + wac) * cin);
-    d.o4 = 4u * (unsigned)(nb + (hbc * W + wbc) * cin);
-    d.w1 = (vha && vwa) ? sa1 * sb1 : 0.f;
-    d.w2 = (vha && vwb) ? sa1 * sb2 : 0.f;
-    d.w3 = (vhb && vwa) ? sa2 * sb1 : 0.f;
-    d.w4 = (vhb && vwb) ? sa2 * sb2 : 0.f;
-    return d;
-}
-
-__device__ static inline float wino_blend1(const WinoDesc &d, const float v1, const float v2, const float v3, const float v4)
-{
-    float val = d.w1 * v1;
-    val = val + d.w2 * v2;
-    val = val + d.w3 * v3;
-    val = val + d.w4 * v4;
-    return val;
-}
-
 // WM x WN = 32x32 tiles per wave, waves arranged WAVES_M x WAVES_N (4 waves): BM = 32*WM*WAVES_M (128 or 64) output
 // pixels x BN = 32*WN*WAVES_N (128 / 64 / 32) output channels per workgroup. BK = input channels per K slab (32 / 64).
 // DEFORM (A-operand loader): 0 dense, 1 deformable v1, 2 deformable v2 (modulated), 3 stem: the input is an NHWC image with
@@ -151,7 +98,7 @@ __device__ static inline float wino_blend1(const WinoDesc &d, const float v1, co
 //   step KS-2     barrier (all fragment reads of this buffer are complete, all stashes visible)
 //   step KS-1     fragment reads of step 0 of slab s+1 from the other buffer
 template <int WM, int WN, int WAVES_M, int WAVES_N, int DEFORM, int BK, int RESUP>
-__global__ void __launch_bounds__(256, DEFORM == 4 ? 2 : ((WM * WN <= 2 && BK == 32) ? 3 : 1))
+__global__ void __launch_bounds__(256, (WM * WN <= 2 && BK == 32) ? 3 : 1)
 conv_igemm_f32_kernel(const ConvParams p)
 {
     constexpr int BN = WAVES_N * WN * 32;
@@ -170,8 +117,6 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr bool MOD = DEFORM == 2;
     constexpr bool DEF = DEFORM == 1 || DEFORM == 2;
     constexpr bool STEM = DEFORM == 3;
-    constexpr bool WINO = DEFORM == 4;
-    static_assert(!WINO || WM == 1, "Winograd instances use one 32-row tile per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *As = reinterpret_cast<float *>(smem_raw);     // [2][BK][LDA]
     float *Bs = As + 2 * BK * LDA;                       // [2][BK][BN]
@@ -258,24 +203,6 @@ conv_igemm_f32_kernel(const ConvParams p)
     bool xv0 = false, xv1 = false, xv2 = false, xv3 = false, yv0 = false, yv1 = false, yv2 = false, yv3 = false;
     float4 c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33;  // deformable: [pixel][corner]
     DcnDesc d0, d1, d2, d3;
-    WinoDesc wd0, wd1, wd2, wd3;
-    float4 e00, e01, e02, e03, e10, e11, e12, e13;               // Winograd: second register set (2-slab prefetch), PXT == 2 only
-    float4 e20, e21, e22, e23, e30, e31, e32, e33;               // (never live: PXT == 2; named so that the shared slab macro compiles)
-    float cw21 = 0, cw22 = 0, cw23 = 0, cw24 = 0, cw31 = 0, cw32 = 0, cw33 = 0, cw34 = 0, ew21 = 0, ew22 = 0, ew23 = 0, ew24 = 0, ew31 = 0, ew32 = 0, ew33 = 0, ew34 = 0;
-    float cw01, cw02, cw03, cw04, cw11, cw12, cw13, cw14;        // blend weights captured with set c / set e at fetch time
-    float ew01, ew02, ew03, ew04, ew11, ew12, ew13, ew14;
-    static_assert(!WINO || PXT == 2, "Winograd instances stage two tiles per thread");
-    floatx16 yy[4][WINO ? WN : 1];                              // Winograd: output accumulators Y = A^T M A, [2p+q][n-tile]
-    if (WINO) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) yy[q][j][r] = 0.f;
-    }
-    int c_cs = 0, c_i = 0, c_j = 0;                             // Winograd: (channel slab, position) of the slab being contracted
-    const int cin_slabs = p.Cin / BK;
 
 #define CV_LDX(O) (*reinterpret_cast<const float4 *>(xbase + (O)))
 #define CV_TAP_DENSE(R)                                                                                               \
@@ -324,24 +251,9 @@ conv_igemm_f32_kernel(const ConvParams p)
         CV_FETCH_B(x)                                                                                                 \
         CV_ADVANCE                                                                                                    \
     }
-#define CV_TAP_WINO(R)                                                                                                \
-    wd##R = wino_desc(sg, pix_n[R], max(pix_n[R], 0) * sg.H * sg.W * p.Cin + 4 * ch4, pix_h[R], pix_w[R], f_ki, f_kj, p.Cin);
-#define CV_FETCH_WINO_PX(P, R)                                                                                        \
-    P##R##0 = CV_LDX(wd##R.o1); P##R##1 = CV_LDX(wd##R.o2); P##R##2 = CV_LDX(wd##R.o3); P##R##3 = CV_LDX(wd##R.o4);   \
-    P##w##R##1 = wd##R.w1; P##w##R##2 = wd##R.w2; P##w##R##3 = wd##R.w3; P##w##R##4 = wd##R.w4;                       \
-    wd##R.o1 += 4u * BK; wd##R.o2 += 4u * BK; wd##R.o3 += 4u * BK; wd##R.o4 += 4u * BK;
-#define CV_FETCH_WINO(P, PB)                                                                                          \
-    {                                                                                                                 \
-        if (f_newtap) { CV_TAP_WINO(0) CV_TAP_WINO(1) }                                                               \
-        CV_FETCH_WINO_PX(P, 0) CV_FETCH_WINO_PX(P, 1)                                                                 \
-        CV_FETCH_B(PB)                                                                                                \
-        CV_ADVANCE                                                                                                    \
-    }
 #define CV_FETCH_x CV_FETCH_DENSE(x)
 #define CV_FETCH_y CV_FETCH_DENSE(y)
 #define CV_FETCH_c CV_FETCH_DEFORM
-#define CV_FETCH_w CV_FETCH_WINO(c, x)
-#define CV_FETCH_v CV_FETCH_WINO(e, y)
 #define CV_FETCH(SET) CV_FETCH_##SET
 
 #define CV_STASH_PX(BUF, R, VX, VY, VZ, VW)                                                                           \
@@ -361,9 +273,6 @@ conv_igemm_f32_kernel(const ConvParams p)
                 dcn_blend1(d##R, (c##R##0).y, (c##R##1).y, (c##R##2).y, (c##R##3).y, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).z, (c##R##1).z, (c##R##2).z, (c##R##3).z, MOD),                                    \
                 dcn_blend1(d##R, (c##R##0).w, (c##R##1).w, (c##R##2).w, (c##R##3).w, MOD))
-#define CV_WBLEND(P, R, F) ((((P##w##R##1 * (P##R##0).F) + P##w##R##2 * (P##R##1).F) + P##w##R##3 * (P##R##2).F) + P##w##R##4 * (P##R##3).F)
-#define CV_STASH_A_w(BUF, R) CV_STASH_PX(BUF, R, CV_WBLEND(c, R, x), CV_WBLEND(c, R, y), CV_WBLEND(c, R, z), CV_WBLEND(c, R, w))
-#define CV_STASH_A_v(BUF, R) CV_STASH_PX(BUF, R, CV_WBLEND(e, R, x), CV_WBLEND(e, R, y), CV_WBLEND(e, R, z), CV_WBLEND(e, R, w))
 #define CV_STASH_A(SET, BUF, R) CV_STASH_A_##SET(BUF, R)
 #define CV_STASH_B_P(P, BUF)                                                                                          \
     {                                                                                                                 \
@@ -375,8 +284,6 @@ conv_igemm_f32_kernel(const ConvParams p)
 #define CV_STASH_B_x(BUF) CV_STASH_B_P(x, BUF)
 #define CV_STASH_B_y(BUF) CV_STASH_B_P(y, BUF)
 #define CV_STASH_B_c(BUF) CV_STASH_B_P(x, BUF)
-#define CV_STASH_B_w(BUF) CV_STASH_B_P(x, BUF)
-#define CV_STASH_B_v(BUF) CV_STASH_B_P(y, BUF)
 #define CV_STASH_B(SET, BUF) CV_STASH_B_##SET(BUF)
 
     float av[2][WM], bv[2][WN];  // MFMA fragments, double-buffered over k steps (carried across slabs)
@@ -410,37 +317,9 @@ conv_igemm_f32_kernel(const ConvParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);     \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
-        if (WINO && ++c_cs == cin_slabs) {  /* last slab of position (c_i, c_j): fold M into Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] */ \
-            const float ci0 = c_i < 3 ? 1.f : 0.f, ci1 = c_i == 0 ? 0.f : (c_i == 1 ? 1.f : -1.f);                    \
-            const float cj0 = c_j < 3 ? 1.f : 0.f, cj1 = c_j == 0 ? 0.f : (c_j == 1 ? 1.f : -1.f);                    \
-            const float k00 = ci0 * cj0, k01 = ci0 * cj1, k10 = ci1 * cj0, k11 = ci1 * cj1;                           \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                            \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-                    const float m_ = acc[0][j][r];                                                                    \
-                    yy[0][j][r] = yy[0][j][r] + k00 * m_; yy[1][j][r] = yy[1][j][r] + k01 * m_;                       \
-                    yy[2][j][r] = yy[2][j][r] + k10 * m_; yy[3][j][r] = yy[3][j][r] + k11 * m_;                       \
-                    acc[0][j][r] = 0.f;                                                                               \
-                }                                                                                                     \
-            c_cs = 0;                                                                                                 \
-            if (++c_j == 4) { c_j = 0; ++c_i; }                                                                       \
-        }                                                                                                             \
     }
 
-    if (WINO) {
-        if constexpr (PXT == 2) {   // (two register sets, loads two slabs ahead -- like the dense instances)
-            CV_FETCH(w)
-            CV_STASH_A(w, 0, 0) CV_STASH_A(w, 0, 1)
-            CV_STASH_B(w, 0)
-            if (nslabs > 1) CV_FETCH(v)
-            __syncthreads();
-            CV_FRAG(0, 0, 0)
-            for (int s = 0; s < nslabs; s += 2) {
-                CV_SLAB(0, w, v, s + 2 < nslabs, s + 1 < nslabs)
-                if (s + 1 >= nslabs) break;
-                CV_SLAB(1, v, w, s + 3 < nslabs, s + 2 < nslabs)
-            }
-        }
-    } else if (DEF) {
+    if (DEF) {
         CV_FETCH(c)
         CV_STASH_A(c, 0, 0) CV_STASH_A(c, 0, 1)
         if (PXT > 2) { CV_STASH_A(c, 0, 2) CV_STASH_A(c, 0, 3) }
@@ -477,16 +356,6 @@ conv_igemm_f32_kernel(const ConvParams p)
 #undef CV_FETCH_x
 #undef CV_FETCH_y
 #undef CV_FETCH_c
-#undef CV_FETCH_w
-#undef CV_FETCH_v
-#undef CV_STASH_A_v
-#undef CV_STASH_B_v
-#undef CV_WBLEND
-#undef CV_TAP_WINO
-#undef CV_FETCH_WINO_PX
-#undef CV_FETCH_WINO
-#undef CV_STASH_A_w
-#undef CV_STASH_B_w
 #undef CV_FETCH
 #undef CV_STASH_PX
 #undef CV_STASH_A_DENSE
@@ -502,55 +371,6 @@ conv_igemm_f32_kernel(const ConvParams p)
 #undef CV_FRAG
 #undef CV_SLAB
 
-    if (WINO) {
-        // ---- Winograd epilogue: row r of the tile is the 2x2 output tile (n, ty, tx); + bias, + residual, ReLU, 4 stores
-        const bool has_res_w = sg.res != nullptr;
-        const long pbase = p0 + wm * 32 + 4 * akr;
-        const long pb = pbase < sg.M ? pbase : sg.M - 1;
-        const int n_b = (int)(pb / HoWo);
-        const int rem_b = (int)(pb - (long)n_b * HoWo);
-        const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
-        const bool fast = sg.Wo >= 32;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int co = n0 + wn * (WN * 32) + 32 * j + aij;
-            const bool co_ok = co < p.Cout;
-            const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                if (!(co_ok && pbase + off < sg.M)) continue;
-                int n = n_b, h = h_b, w = w_b;
-                if (fast) {
-                    w += off;
-                    if (w >= sg.Wo) { w -= sg.Wo; ++h; }
-                    if (h >= sg.Ho) { h -= sg.Ho; ++n; }
-                } else {
-                    const long pp = pbase + off;
-                    n = (int)(pp / HoWo);
-                    const int rem = (int)(pp - (long)n * HoWo);
-                    h = rem / sg.Wo; w = rem - h * sg.Wo;
-                }
-                const int oy = 2 * h, ox = 2 * w;
-                const bool y1 = oy + 1 < sg.OH, x1 = ox + 1 < sg.OW;
-                const long o00 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
-                const long o01 = o00 + p.Cout, o10 = o00 + (long)sg.OW * p.Cout, o11 = o10 + p.Cout;
-                float v00 = yy[0][j][r] + bv, v01 = yy[1][j][r] + bv, v10 = yy[2][j][r] + bv, v11 = yy[3][j][r] + bv;
-                if (has_res_w) {
-                    v00 = v00 + sg.res[o00];
-                    if (x1) v01 = v01 + sg.res[o01];
-                    if (y1) v10 = v10 + sg.res[o10];
-                    if (x1 && y1) v11 = v11 + sg.res[o11];
-                }
-                if (p.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
-                sg.out[o00] = v00;
-                if (x1) sg.out[o01] = v01;
-                if (y1) sg.out[o10] = v10;
-                if (x1 && y1) sg.out[o11] = v11;
-            }
-        }
-        return;
-    }
     if (RESUP == 3) {
         // ---- split-K: raw partial sums to the workspace; bias / residual / ReLU are applied by conv_splitk_reduce_kernel
         if (nslabs <= 0) {
@@ -686,10 +506,7 @@ static int conv_launch(hipStream_t st, ConvParams &p)
 // expensive gather, computed once per 128 output channels; 168 registers -> 3 waves per SIMD). Cout <= 32 heads use 128x32.
 // upsnet_conv_tuning(0, force_tile) overrides for A/B runs.
 static int g_force_tile = 0;
-static int g_wino_form = 0;   // 0: conv_wino.hip (16 resident accumulators), 1: the per-position walk instance of this file (A/B runs)
-extern "C" void upsnet_conv_tuning(int winograd_form, int force_tile) { g_wino_form = winograd_form; g_force_tile = force_tile; }
-int conv_wino16_launch(hipStream_t st, ConvParams &p);                                                      // conv_wino.hip
-int conv_wino16_pack(hipStream_t st, const float *weight, int cout, int cin, int ldw, float *wpack);
+extern "C" void upsnet_conv_tuning(int reserved, int force_tile) { (void)reserved; g_force_tile = force_tile; }
 
 template <int DEFORM>
 static int conv_dispatch(hipStream_t st, ConvParams &p)
@@ -714,11 +531,7 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
         return conv_launch<1, 1, 2, 2, 0, CV_BK, 3>(st, p);
     }
     if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
-    if (DEFORM == 4) {   // (64 tiles x 128 channels was measured: slower, 256 registers + spills)
-        UPS_REQUIRE(n64, "conv2d_winograd_nhwc_f32: Cout must round up to a multiple of 64 (ldw %% 64 == 0); use the direct kernel");
-        return conv_launch<1, 1, 2, 2, 4>(st, p);
-    }
-    constexpr int D = DEFORM >= 3 ? 0 : DEFORM;  // (stem / Winograd returned above; keeps their instantiations to two tiles)
+    constexpr int D = DEFORM >= 3 ? 0 : DEFORM;  // (the stem returned above; keeps its instantiations to two tiles)
     switch (tile) {
     case 1: return conv_launch<2, 2, 2, 2, D>(st, p);      // 128 x 128
     case 2: return conv_launch<1, 2, 4, 1, D>(st, p);      // 128 x 64
@@ -785,6 +598,16 @@ conv_splitk_reduce_kernel(const float *__restrict__ partial, const int ksplit, c
     reinterpret_cast<float4 *>(out + pp * Cout)[c4] = a;
 }
 
+int conv_splitk_reduce(hipStream_t st, const float *partial, int ksplit, long m_total, long M, int Cout, const float *bias, const float *res,
+                       int relu, float *out)
+{
+    const long n = M * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, ksplit, m_total, M, Cout, bias,
+                       res, relu, out);
+    UPS_CHECK_LAUNCH("conv_splitk_reduce_kernel");
+    return 0;
+}
+
 extern "C" size_t upsnet_conv2d_splitk_workspace_bytes(int batch, int height, int width, int Cout, int KH, int KW, int stride, int pad,
                                                        int ksplit)
 {
@@ -813,111 +636,9 @@ extern "C" int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const
     p.partial = (float *)workspace;
     rc = conv_dispatch<0>((hipStream_t)stream, p);
     if (rc) return rc;
-    const long M = p.seg[0].M;
-    const long n = M * (Cout / 4);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.partial, ksplit,
-                       p.m_total, M, Cout, bias, residual, relu, out);
-    UPS_CHECK_LAUNCH("conv_splitk_reduce_kernel");
-    return 0;
+    return conv_splitk_reduce((hipStream_t)stream, p.partial, ksplit, p.m_total, p.seg[0].M, Cout, bias, residual, relu, out);
 }
 
-extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
-                                               float *const out[], const int batch[], const int height[], const int width[], int Cin,
-                                               const float *wpack, int ldw, const float *bias, int Cout, int relu)
-{
-    ConvParams p;
-    // geometry of the 3x3 / stride 1 / pad 1 convolution first ...
-    int rc = conv_fill(p, "conv2d_winograd_nhwc_f32", nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout, wpack, ldw,
-                       bias, 3, 3, 1, 1, 1, relu);
-    if (rc) return rc;
-    UPS_REQUIRE((long)16 * Cin * ldw < (1L << 30), "conv2d_winograd_nhwc_f32: packed weight exceeds 4 GiB");
-    // ... then the GEMM "pixels" become 2x2 output tiles and the 16 "taps" the positions of the transformed domain
-    for (int i = 0; i < nseg; ++i) {
-        ConvSeg &s = p.seg[i];
-        s.OH = s.Ho; s.OW = s.Wo;
-        s.Ho = (s.OH + 1) / 2; s.Wo = (s.OW + 1) / 2;
-        s.M = (long)s.N * s.Ho * s.Wo;
-    }
-    if (g_wino_form == 0) return conv_wino16_launch((hipStream_t)stream, p);
-    p.KH = 4; p.KW = 4; p.stride = 2; p.pad = 1;
-    return conv_dispatch<4>((hipStream_t)stream, p);
-}
-
-// Winograd with the K walk split `ksplit` ways (maps with too few 2x2 tiles to fill the chip: res4 / res5 / FPN P4): partial
-// output tiles into the workspace (upsnet_conv2d_splitk_workspace_bytes with a 3x3 / 1 / 1 geometry), then the shared reduction.
-extern "C" int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,
-                                                      int width, int Cin, const float *wpack, int ldw, const float *bias, int Cout, int relu,
-                                                      int ksplit, void *workspace)
-{
-    const float *xs[1] = {x};
-    float *os[1] = {out};
-    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
-    ConvParams p;
-    int rc = conv_fill(p, "conv2d_winograd_nhwc_f32_splitk", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias, 3, 3,
-                       1, 1, 1, relu);
-    if (rc) return rc;
-    UPS_REQUIRE(g_wino_form == 0, "conv2d_winograd_nhwc_f32_splitk: only the resident-accumulator form splits K");
-    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8, "conv2d_winograd_nhwc_f32_splitk: ksplit must be 2..8 and a workspace given");
-    UPS_REQUIRE(Cout % 4 == 0, "conv2d_winograd_nhwc_f32_splitk: Cout must be a multiple of 4");
-    ConvSeg &sg = p.seg[0];
-    sg.OH = sg.Ho; sg.OW = sg.Wo;
-    sg.Ho = (sg.OH + 1) / 2; sg.Wo = (sg.OW + 1) / 2;
-    sg.M = (long)sg.N * sg.Ho * sg.Wo;
-    p.ksplit = ksplit;
-    p.partial = (float *)workspace;
-    rc = conv_wino16_launch((hipStream_t)stream, p);
-    if (rc) return rc;
-    const long M = p.m_total;   // output pixels
-    const long n = M * (Cout / 4);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.partial, ksplit,
-                       p.m_total, M, Cout, bias, residual, relu, out);
-    UPS_CHECK_LAUNCH("conv_splitk_reduce_kernel");
-    return 0;
-}
-
-// weight [Cout, Cin, 3, 3] -> U [(i*4+j)*Cin + c, ldw] = (G g G^T)[i][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-__global__ void conv_pack_weight_winograd_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
-{
-    const long total = (long)ldw * cin;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
-        const int co = idx % ldw, c = idx / ldw;
-        float g[3][3], t[4][3], u[4][4];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = co < cout ? w[(((long)co * cin + c) * 3 + a) * 3 + b] : 0.f;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
-            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
-            t[3][b] = g[2][b];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            u[a][0] = t[a][0];
-            u[a][1] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
-            u[a][2] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
-            u[a][3] = t[a][2];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) wp[((long)(a * 4 + b) * cin + c) * ldw + co] = u[a][b];
-    }
-}
-
-extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
-{
-    UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout && ldw % 32 == 0, "conv_pack_weight_winograd: bad args");
-    if (g_wino_form == 0) return conv_wino16_pack((hipStream_t)stream, weight, cout, cin, ldw, wpack);
-    const long total = (long)ldw * cin;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(conv_pack_weight_winograd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, ldw, wpack);
-    UPS_CHECK_LAUNCH("conv_pack_weight_winograd_kernel");
-    return 0;
-}
 
 extern "C" int upsnet_conv2d_stem_nhwc4_f32(void *stream, const float *x, int batch, int height, int width, const float *wpack,
                                             int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad, int relu,

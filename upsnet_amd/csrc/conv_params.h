@@ -70,3 +70,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
     return 0;
 }
 
+
+// out = relu?(sum_z partial[z] + bias + residual): the reduction + epilogue shared by the split-K launches (conv.hip)
+int conv_splitk_reduce(hipStream_t st, const float *partial, int ksplit, long m_total, long M, int Cout, const float *bias, const float *res,
+                       int relu, float *out);

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
 
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
 // p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
-int conv_wino16_launch(hipStream_t st, ConvParams &p)
+static int conv_wino16_launch(hipStream_t st, ConvParams &p)
 {
     UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
     int tiles = 0;
@@ -339,13 +339,60 @@ __global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int 
     }
 }
 
-int conv_wino16_pack(hipStream_t st, const float *weight, int cout, int cin, int ldw, float *wpack)
+extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
 {
+    UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout, "conv_pack_weight_winograd: bad args");
     UPS_REQUIRE(cin % 16 == 0 && ldw % 64 == 0, "conv_pack_weight_winograd: Cin %% 16 and ldw %% 64 must be 0");
     const long total = (long)ldw * cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(conv_pack_weight_wino16_kernel, dim3(blocks), dim3(256), 0, st, weight, cout, cin, ldw, wpack);
+    hipLaunchKernelGGL(conv_pack_weight_wino16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, ldw, wpack);
     UPS_CHECK_LAUNCH("conv_pack_weight_wino16_kernel");
     return 0;
+}
+
+// geometry of the 3x3 / stride 1 / pad 1 convolution first (conv_fill), then the GEMM rows become 2x2 output tiles
+static int wino_fill(ConvParams &p, const char *who, int nseg, const float *const x[], const float *const residual[], float *const out[],
+                     const int batch[], const int height[], const int width[], int Cin, int Cout, const float *wpack, int ldw,
+                     const float *bias, int relu)
+{
+    int rc = conv_fill(p, who, nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout, wpack, ldw, bias, 3, 3, 1, 1, 1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)16 * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
+    for (int i = 0; i < nseg; ++i) {
+        ConvSeg &s = p.seg[i];
+        s.OH = s.Ho; s.OW = s.Wo;
+        s.Ho = (s.OH + 1) / 2; s.Wo = (s.OW + 1) / 2;
+        s.M = (long)s.N * s.Ho * s.Wo;
+    }
+    return 0;
+}
+
+extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                                               float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                                               const float *wpack, int ldw, const float *bias, int Cout, int relu)
+{
+    ConvParams p;
+    int rc = wino_fill(p, "conv2d_winograd_nhwc_f32", nseg, x, residual, out, batch, height, width, Cin, Cout, wpack, ldw, bias, relu);
+    if (rc) return rc;
+    return conv_wino16_launch((hipStream_t)stream, p);
+}
+
+extern "C" int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,
+                                                      int width, int Cin, const float *wpack, int ldw, const float *bias, int Cout, int relu,
+                                                      int ksplit, void *workspace)
+{
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = wino_fill(p, "conv2d_winograd_nhwc_f32_splitk", 1, xs, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias, relu);
+    if (rc) return rc;
+    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8, "conv2d_winograd_nhwc_f32_splitk: ksplit must be 2..8 and a workspace given");
+    UPS_REQUIRE(Cout % 4 == 0, "conv2d_winograd_nhwc_f32_splitk: Cout must be a multiple of 4");
+    p.ksplit = ksplit;
+    p.partial = (float *)workspace;
+    rc = conv_wino16_launch((hipStream_t)stream, p);
+    if (rc) return rc;
+    return conv_splitk_reduce((hipStream_t)stream, p.partial, ksplit, p.m_total, p.m_total, Cout, bias, residual, relu, out);
 }
