@@ -42,6 +42,9 @@ def main():
     ap.add_argument('--conv-precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                     help="fp32 (default, the headline configuration): exact fp32 products; bf16x3: bf16 matrix cores, 3-term split "
                          "(fp32-equivalent to ~1e-5); bf16: BASELINE.json configs[2] (bf16 products, fp32 accumulation)")
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help="images launched per rank before the oldest one is read back (2: the next graph launch overlaps the read-back; "
+                         "1: strictly one image after the other)")
     ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
@@ -65,23 +68,20 @@ def main():
         ops.PROFILE['enabled'] = on
         model.overlap_streams = overlap[0] and not on
 
-    def on_step(s, out, model):
-        sample(model, (s + 1) % PROFILE_EVERY == 0)
-        sampled[0] += int(ops.PROFILE['enabled'])
+    def before_step(s, model):   # (called before the launch of timed image s: with two images in flight that is before image
+        on = s % PROFILE_EVERY == 0  # s-1 has been read back, so the switch cannot live in a per-result callback)
+        sample(model, on)
+        sampled[0] += int(on)
 
     def on_warmup_done(model):
         ops.PROFILE['events'].clear()
         overlap[0] = model.overlap_streams
-        sample(model, True)   # image 0 of the timed region
 
     overlap = [True]
-    sampled[0] = 1
-    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, on_step=on_step, on_warmup_done=on_warmup_done,
-                      input_mode=args.input, post=args.post)
+    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, before_step=before_step, on_warmup_done=on_warmup_done,
+                      input_mode=args.input, post=args.post, in_flight=args.in_flight)
     ops.PROFILE['enabled'] = False
     res['model'].overlap_streams = overlap[0]
-    if (args.steps) % PROFILE_EVERY == 0:
-        sampled[0] -= 1   # the toggle after the last step enabled recording for an image that never ran
     rank, world = res['rank'], res['world']
     if rank != 0:
         if torch.distributed.is_initialized():
@@ -102,8 +102,8 @@ def main():
 
     n_sampled = max(sampled[0], 1)
 
-    def agg(kind):
-        ev = [e for e in ops.PROFILE['events'] if e[0] == kind]
+    def agg(kind, prefix=None):
+        ev = [e for e in ops.PROFILE['events'] if e[0] == kind and (prefix is None or (len(e) > 5 and e[5].startswith(prefix)))]
         ms = sum(e[1].elapsed_time(e[2]) for e in ev)
         return len(ev), ms / 1000.0, sum(e[3] for e in ev), sum(e[4] for e in ev)
     roofline = None
@@ -118,13 +118,25 @@ def main():
             except Exception:
                 traffic = None
         achieved = f_c / t_c / 1e12
-        roofline = {'kernel': 'conv_igemm_f32_kernel (dense instances, all tile variants)', 'bound': 'mfma',
+        # Winograd launches execute 16/36 of their algorithmic (direct-form) multiplies: `achieved` / `frac` follow the contract
+        # (algorithmic flops / time), `executed` is what the MFMA pipe really did, against the same peak
+        n_w, t_w, f_w, _ = agg('conv', 'winograd')
+        f_exec = f_c - f_w * (1.0 - 16.0 / 36.0)
+        roofline = {'kernel': 'dense convolution family: conv_igemm_f32_kernel (direct, csrc/conv.hip) + conv_wino16_f32_kernel '
+                              '(Winograd F(2x2,3x3), csrc/conv_wino.hip)', 'bound': 'mfma',
                     'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                     'launches_timed': n_c, 'images_sampled': n_sampled, 'launches_per_image': n_c // n_sampled,
                     'avg_launch_ms': round(1000.0 * t_c / n_c, 4), 'ms_per_image': round(1000.0 * t_c / n_sampled, 3),
                     'algorithmic_flops_per_launch': f_c / n_c, 'algorithmic_bytes_per_launch': b_c / n_c,
-                    'hbm_equiv_GBs': round(b_c / t_c / 1e9, 1)}
+                    'hbm_equiv_GBs': round(b_c / t_c / 1e9, 1),
+                    'executed': {'achieved': round(f_exec / t_c / 1e12, 3), 'frac': round(f_exec / t_c / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'note': 'MFMA flops actually issued (Winograd launches counted at 16/36 of their direct-form flops)'},
+                    'winograd': {'launches_timed': n_w, 'ms_per_image': round(1000.0 * t_w / n_sampled, 3),
+                                 'achieved_algorithmic': round(f_w / max(t_w, 1e-9) / 1e12, 3),
+                                 'achieved_executed': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12, 3)},
+                    'direct': {'launches_timed': n_c - n_w, 'ms_per_image': round(1000.0 * (t_c - t_w) / n_sampled, 3),
+                               'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3)}}
         if n_d and t_d > 0:
             roofline['deformable'] = {'kernel': 'conv_igemm_f32_kernel (deformable instances = fused DCN v1)', 'bound': 'mfma',
                                       'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -184,13 +196,16 @@ def main():
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
                    'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip) for every convolution incl. the 7x7 stem and the 2x2 '
-                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; large 3x3 layers (FPN P2/P3, RPN, res2/res3) as fused '
-                                  'Winograd F(2x2,3x3) instances of the same kernel (fp32); max-pool + FC GEMMs on PyTorch-ROCm',
+                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; 3x3 / stride-1 layers with >= 128 workgroups '
+                                  'of tiles (FPN, RPN, res2-res5 conv2, DCN offset convs, mask head) on the fp32 Winograd F(2x2,3x3) kernel '
+                                  '(csrc/conv_wino.hip, split-K below 160 workgroups); max-pool + FC GEMMs on PyTorch-ROCm',
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank, final RCCL all_gather',
-                   'streams': 'static-shape part of the forward (trunk, semantic head on a side stream concurrent with the proposal/detection '
-                              'chain) replayed as one HIP graph; the %d roofline-sampled images run eagerly and serially' % n_sampled,
+                   'streams': 'whole forward (trunk, semantic head + mask head on a side stream concurrent with the proposal/detection '
+                              'chain, panoptic tail) replayed as one HIP graph per image, %d image(s) in flight per rank (the next launch '
+                              'overlaps the read-back of the previous outputs); the %d roofline-sampled image(s) run eagerly and serially'
+                              % (args.in_flight, n_sampled),
                    'hip_graph': bool(g), 'verified_vs_eager_rerun': same,
                    'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
         'roofline': roofline, 'cpu_baseline': cpu_baseline,

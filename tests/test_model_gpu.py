@@ -202,14 +202,28 @@ def test_hip_graph_replay_equals_eager(setup):
         model.use_graph = False
         eager = [{k: v.clone() for k, v in model(im).items()} for im in imgs]
         model.use_graph = True
-        model._graphs.clear()
-        order = [0, 1, 2, 3, 0, 3, 1, 3, 2, 3, 0]     # shape A captured at its 3rd visit, shape B (index 3) at its 3rd
-        for step, j in enumerate(order):
-            out = model(imgs[j])
-            for k in keys:
-                assert torch.equal(out[k], eager[j][k]), (step, j, k)
-        assert sum(1 for e in model._graphs.values() if 'graph' in e) == 2
+        for slots in (1, 2):
+            model._graphs.clear()
+            model.graph_slots = slots
+            # every graph instance of a shape is captured at ITS 3rd visit: shape A, then shape B (index 3) interleaved
+            order = [0, 1, 2, 0, 1, 2, 3, 0, 3, 1, 3, 2, 3, 0, 3, 3, 3, 1]
+            for step, j in enumerate(order):
+                out = model(imgs[j])
+                for k in keys:
+                    assert torch.equal(out[k], eager[j][k]), (slots, step, j, k)
+            assert sum(1 for e in model._graphs.values() for sl in e['slots'] if 'graph' in sl) == 2 * slots
+        # two images in flight: launch i+1 before reading i; the outputs of i stay valid while i+1 runs
+        order = [0, 1, 2, 0, 3, 3, 1, 2, 3, 0]
+        pending = None
+        for step, j in enumerate(order + [None]):
+            nxt = (j, model.forward_async(imgs[j])) if j is not None else None
+            if pending is not None:
+                out = pending[1].result()
+                for k in keys:
+                    assert torch.equal(out[k], eager[pending[0]][k]), ('async', step, pending[0], k)
+            pending = nxt
     model._graphs.clear()
+    model.graph_slots = 2
 
 
 def test_hip_graph_fallback_when_assumptions_fail(setup):
@@ -233,7 +247,11 @@ def test_hip_graph_fallback_when_assumptions_fail(setup):
                 out = model(img)
                 for k in keys:
                     assert torch.equal(out[k], ref[k]), (step, k)
-            ent = next(iter(model._graphs.values()))
+            for step in range(3):
+                out = model.forward_async(img).result()
+                for k in keys:
+                    assert torch.equal(out[k], ref[k]), ('async', step, k)
+            ent = next(iter(model._graphs.values()))['slots'][0]
             n_det, n_pan, n_extra, _ = ent['out']['tail']['counters'].tolist()
             assert n_extra > 0 or n_pan > 256 or n_det > ent['out']['max_det'], (n_det, n_pan, n_extra)   # the fallback was exercised
     finally:

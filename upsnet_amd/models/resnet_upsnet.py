@@ -13,6 +13,7 @@ Two execution styles produce identical results:
     MaskRemoval -> SegTerm -> cat/argmax) through the drop-in modules, materialising what the
     reference materialises. Used by the parity tests.
 """
+import gc
 import os
 
 import numpy as np
@@ -36,6 +37,21 @@ from .rpn import RPN, rpn_forward_levels
 
 _SIDE = {}  # device index -> (side stream, fork event, join event)
 
+
+class _Pending(object):
+    """Handle of resnet_upsnet.forward_async()."""
+
+    def __init__(self, model, data, ent, out=None):
+        self.model, self.data, self.ent, self.out = model, data, ent, out
+
+    def result(self):
+        if self.out is None:
+            ent, self.ent = self.ent, None
+            ent['done'].synchronize()
+            self.out = self.model._forward_fused(self.data, st=ent['out'], counters=ent['host'].tolist())
+        return self.out
+
+
 class resnet_upsnet(resnet_rcnn):
 
     def __init__(self, backbone_depth, pipeline='fused'):
@@ -47,6 +63,10 @@ class resnet_upsnet(resnet_rcnn):
         # the static-shape part of the forward (everything before the first host read) replayed as one HIP graph
         self.use_graph = os.environ.get('UPSNET_GRAPH', '1') != '0'
         self._graphs = {}
+        # graph instances (each with its own static input / activation / output buffers) used in turn per input shape: with 2,
+        # forward_async() can launch image i+1 while the caller still reads the outputs of image i (they stay valid for
+        # graph_slots forwards of that shape)
+        self.graph_slots = max(1, int(os.environ.get('UPSNET_GRAPH_SLOTS', '2')))
         self.graph_outputs_alias = os.environ.get('UPSNET_GRAPH_ALIAS', '1') != '0'
         self.early_mask_head = os.environ.get('UPSNET_EARLY_MASK', '1') != '0'
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
@@ -159,6 +179,22 @@ class resnet_upsnet(resnet_rcnn):
             return self._forward_modules(data)
         return self._forward_fused(data)
 
+    def forward_async(self, data):
+        """Launch the forward of one image and return a handle; handle.result() waits for it and returns the output dict of
+        forward(). On the graph path the launch is one input copy + one hipGraphLaunch + one small asynchronous device-to-host
+        copy, so the caller can launch image i+1 before reading image i (graph_slots >= 2): the host work between two images
+        (result read-back, Python, the next launch) then overlaps with the device. Elsewhere it simply runs forward()."""
+        x = data['data']
+        if (self.pipeline == 'fused' and self.use_graph and self.graph_slots >= 2 and self.taps is None and not ops.PROFILE['enabled']
+                and x.is_cuda and not torch.is_grad_enabled()):
+            ent = self._phase1_graphed(x, data['im_info'])
+            if ent is not None and ent['host'] is not None:
+                ent['host'].copy_(ent['out']['tail']['counters'], non_blocking=True)
+                ent['done'].record()
+                return _Pending(self, data, ent)
+            return _Pending(self, data, None, self._forward_fused(data, st=None if ent is None else ent['out'], try_graph=False))
+        return _Pending(self, data, None, self.forward(data))
+
     # ------------------------------------------------------------------ MI355X pipeline
     def _phase1(self, x, im_info, tail=False):
         """Everything up to the first host read (static shapes: fixed-capacity ROI / detection buffers + device counters), on the
@@ -245,12 +281,15 @@ class resnet_upsnet(resnet_rcnn):
 
     def _phase1_graphed(self, x, im_info_host):
         """HIP-graph replay of _phase1 for this input shape / im_info: the ~150 launches of the trunk, the semantic head (side
-        stream) and the proposal / detection chain cost one hipGraphLaunch on the host. The first two images of a shape run
-        eagerly (weight packing, function attributes, library handles), the third is captured."""
+        stream) and the proposal / detection chain cost one hipGraphLaunch on the host. graph_slots instances per shape are used
+        in turn; for each, the first two images run eagerly (weight packing, function attributes, library handles), the third is
+        captured."""
         key = (tuple(x.shape), x.dtype, x.is_contiguous(), tuple(float(v) for v in np.asarray(im_info_host).reshape(-1)))
-        ent = self._graphs.get(key)
-        if ent is None:
-            ent = self._graphs[key] = {'seen': 0}
+        slots = self._graphs.get(key)
+        if slots is None:
+            slots = self._graphs[key] = {'next': 0, 'slots': [{'seen': 0} for _ in range(self.graph_slots)]}
+        ent = slots['slots'][slots['next']]
+        slots['next'] = (slots['next'] + 1) % len(slots['slots'])
         if 'graph' not in ent:
             ent['seen'] += 1
             if ent['seen'] <= 2:
@@ -259,6 +298,8 @@ class resnet_upsnet(resnet_rcnn):
             static_im = torch.from_numpy(np.asarray(im_info_host, dtype=np.float32).reshape(-1)[:3].copy()).to(x.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            gc_was_on = gc.isenabled()
+            gc.disable()   # a collection in the middle of the capture could release device objects (illegal while capturing)
             try:
                 # (thread_local: other threads of the process -- e.g. the RCCL watchdog of torch.distributed -- may call the runtime
                 # while this thread captures)
@@ -269,16 +310,23 @@ class resnet_upsnet(resnet_rcnn):
                 warnings.warn("upsnet_amd: HIP graph capture failed (%s); running eagerly" % (e,))
                 self.use_graph = False
                 return None
-            ent.update(graph=g, x=static_x, im_info=static_im, out=out)   # (the graph reads both static inputs by address)
+            finally:
+                if gc_was_on:
+                    gc.enable()
+            host = torch.empty((4,), dtype=out['tail']['counters'].dtype).pin_memory() if out.get('tail') is not None else None
+            # (the graph reads both static inputs by address)
+            ent.update(graph=g, x=static_x, im_info=static_im, out=out, host=host, done=torch.cuda.Event())
         ent['x'].copy_(x)
         ent['graph'].replay()
-        return ent['out']
+        return ent   # (ent['out']: the device tensors the graph writes; no reference from them back to ent -- a cycle would leave
+                     # the release of a dropped graph to the garbage collector, which may run in the middle of a later capture)
 
-    def _forward_fused(self, data):
+    def _forward_fused(self, data, st=None, counters=None, try_graph=True):
+        """st: the state of an already launched graph replay (forward_async); counters: its four counters, already on the host."""
         x, im_info = data['data'], data['im_info']
-        st = None
-        if self.use_graph and self.taps is None and not ops.PROFILE['enabled'] and x.is_cuda:
-            st = self._phase1_graphed(x, im_info)
+        if st is None and try_graph and self.use_graph and self.taps is None and not ops.PROFILE['enabled'] and x.is_cuda:
+            ent = self._phase1_graphed(x, im_info)
+            st = None if ent is None else ent['out']
         graphed = st is not None
         if st is None:
             st = self._phase1(x, im_info)
@@ -287,11 +335,11 @@ class resnet_upsnet(resnet_rcnn):
         H, W = (fcn_score.shape[2] * 4, fcn_score.shape[3] * 4) if fuse_up else fcn_output.shape[2:]
         t = st.get('tail')
         if t is not None:   # whole forward was in the graph: ONE host read
-            n_det, n_pan, n_extra, k = t['counters'].tolist()
+            n_det, n_pan, n_extra, k = counters if counters is not None else t['counters'].tolist()
             if n_extra == 0 and n_det <= st['max_det'] and n_pan <= min(256, st['pan_boxes'].shape[0]):
-                # every output is a view into the graph's buffers: no launch after the replay. They are valid until the next
-                # forward() of this model (the usual contract of graph-replayed inference); graph_outputs_alias = False
-                # (UPSNET_GRAPH_ALIAS=0) returns private copies instead.
+                # every output is a view into the graph's buffers: no launch after the replay. They are valid until this graph
+                # instance is replayed again, graph_slots forwards of this shape later (the usual contract of graph-replayed
+                # inference); graph_outputs_alias = False (UPSNET_GRAPH_ALIAS=0) returns private copies instead.
                 out = {
                     'cls_probs': st['det_scores'][:n_det], 'pred_boxes': st['det_boxes'][:n_det], 'mask_probs': t['mask_prob'][:n_det],
                     'fcn_outputs': t['sem'], 'cls_inds': st['det_cls'][:n_det], 'panoptic_cls_inds': t['kept_cls'][:k],
