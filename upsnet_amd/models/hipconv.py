@@ -208,3 +208,35 @@ def clear_cache(model=None):
     if model is not None:
         for m in model.modules():
             m.__dict__.pop('_hip_plans', None)
+
+
+def conv_multi_cat(ms, xs):
+    """Several sibling convolutions of the same geometry (the RPN's objectness and box-delta 1x1 heads) on the same maps as ONE
+    launch over the concatenated output channels: the input maps are read once instead of once per head. Returns one list of
+    per-map outputs per module (channel slices of the shared output). Every output channel is computed exactly as in a separate
+    launch (same kernel instance, same K order)."""
+    xs = list(xs)
+    m0 = ms[0]
+    same = all(isinstance(m, nn.Conv2d) and m.kernel_size == m0.kernel_size and m.stride == m0.stride and m.padding == m0.padding and
+               m.dilation == m0.dilation and m.in_channels == m0.in_channels and (m.bias is None) == (m0.bias is None) for m in ms)
+    couts = [m.out_channels for m in ms]
+    # (the instance is chosen by ldw: the concatenation must stay on the one the separate heads would use)
+    if (not same or PRECISION != 'fp32' or len(xs) > 5 or not all(supported(m0, x) for x in xs) or
+            (sum(couts) + 31) // 32 != 1 or _use_winograd(m0, xs)):
+        return [conv_multi(m, xs) for m in ms]
+    key = tuple((m.weight.data_ptr(), m.weight._version, tuple(m.weight.shape), None if m.bias is None else m.bias._version) for m in ms)
+    ent = _plans(m0).get('cat')
+    if ent is None or ent[0] != key:
+        w = torch.cat([m.weight.detach() for m in ms], 0)
+        b = None if m0.bias is None else torch.cat([m.bias.detach() for m in ms], 0)
+        wp, ldw = ops.pack_conv_weight(w)
+        ent = (key, wp, ldw, b)
+        _plans(m0)['cat'] = ent
+    _, wp, ldw, b = ent
+    outs = ops.conv2d_nhwc_multi(xs, wp, ldw, b, sum(couts), m0.kernel_size[0], m0.stride[0], m0.padding[0], relu=False)
+    res, c0 = [], 0
+    for c in couts:
+        res.append([o[:, c0:c0 + c] for o in outs])
+        c0 += c
+    return res
+

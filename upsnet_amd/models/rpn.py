@@ -30,8 +30,7 @@ class RPN(nn.Module):
 
 
 def rpn_forward_levels(rpn, feats):
-    """All pyramid levels through the shared RPN head: 3 launches instead of 3 per level."""
+    """All pyramid levels through the shared RPN head: 2 launches (3x3 conv; both 1x1 heads together) instead of 3 per level."""
     xs = hipconv.conv_multi(rpn.conv_proposal[0], feats, relu=True)
-    scores = hipconv.conv_multi(rpn.cls_score, xs)
-    boxes = hipconv.conv_multi(rpn.bbox_pred, xs)
+    scores, boxes = hipconv.conv_multi_cat([rpn.cls_score, rpn.bbox_pred], xs)
     return scores, boxes, [torch.sigmoid(s) for s in scores]
