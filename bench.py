@@ -111,7 +111,7 @@ def main():
     n_d, t_d, f_d, b_d = agg('dcn_fused')
     if n_c and t_c > 0:
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r03_conv_pmc.json')  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
+        pmc = os.path.join(ROOT, 'profiles', 'r05_conv_pmc.json')  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
