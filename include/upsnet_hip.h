@@ -223,8 +223,9 @@ int upsnet_deconv2x2_nhwc_f32(void *stream, const float *x, int batch, int heigh
 int upsnet_deconv2x2_pack_weight(void *stream, const float *weight, int cin, int cout, int ldw, float *wpack);
 
 /* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
- * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). `reserved` is ignored. Not needed in production. */
-void upsnet_conv_tuning(int reserved, int force_tile);
+ * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). winograd_tiles = 0 auto, 32 / 64: 2x2 tiles per
+ * workgroup of the Winograd kernel. Not needed in production. */
+void upsnet_conv_tuning(int winograd_tiles, int force_tile);
 
 /* weight [Cout, Cin, kh, kw] (nn.Conv2d layout) -> wpack [kh*kw*Cin, ldw] (tap-major rows, zero-padded columns). */
 int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);

@@ -134,8 +134,8 @@ def test_blob_geometry_host_mirror_equals_oracle():
 
 def test_conv_instance_selection_rules():
     """hipconv picks the kernel instance by shape only (never by data): Winograd for 3x3/s1 layers with >= 128 workgroups of
-    2x2-tile work (after its own K split, for single maps below 160 workgroups), split-K direct for <= 256 direct workgroups
-    with a long K walk, direct otherwise."""
+    2x2-tile work (64-tile workgroups above 768 of them, else 32-tile ones; its own K split for single maps below 256
+    workgroups), split-K direct for <= 256 direct workgroups with a long K walk, direct otherwise."""
     import torch
     import torch.nn as nn
     from upsnet_amd.models import hipconv
@@ -143,10 +143,11 @@ def test_conv_instance_selection_rules():
     c5 = nn.Conv2d(512, 512, 3, padding=1)
     x = lambda n, h, w, c=256: torch.empty(n, c, h, w, device='meta')
     assert hipconv._use_winograd(c3, [x(1, 256, 512)]) and hipconv._use_winograd(c3, [x(1, 128, 256)])      # FPN P2, P3
+    assert hipconv._wino_tm(c3, [x(1, 256, 512)]) == 64 and hipconv._wino_tm(c3, [x(1, 128, 256)]) == 32     # 2048 / 512 workgroups of 64 tiles
     assert hipconv._wino_ksplit(c3, [x(1, 256, 512)]) == 1 and hipconv._wino_ksplit(c3, [x(1, 128, 256)]) == 1
-    assert hipconv._use_winograd(c3, [x(1, 64, 128)]) and hipconv._wino_ksplit(c3, [x(1, 64, 128)]) == 2    # P4 / res4: 128 wgs x 2
-    assert hipconv._use_winograd(c5, [x(1, 32, 64, 512)]) and hipconv._wino_ksplit(c5, [x(1, 32, 64, 512)]) == 4   # res5: 64 x 4
-    assert hipconv._use_winograd(c3, [x(1, 32, 64)]) and hipconv._wino_ksplit(c3, [x(1, 32, 64)]) == 4      # P5: 32 x 4 (4 slabs each)
+    assert hipconv._use_winograd(c3, [x(1, 64, 128)]) and hipconv._wino_ksplit(c3, [x(1, 64, 128)]) == 1    # P4 / res4: 256 x 32-tile wgs
+    assert hipconv._use_winograd(c5, [x(1, 32, 64, 512)]) and hipconv._wino_ksplit(c5, [x(1, 32, 64, 512)]) == 4   # res5: 128 x 4
+    assert hipconv._use_winograd(c3, [x(1, 32, 64)]) and hipconv._wino_ksplit(c3, [x(1, 32, 64)]) == 4      # P5: 64 x 4 (4 slabs each)
     assert not hipconv._use_winograd(c3, [x(1, 16, 32)])                                                      # P6: too few tiles
     assert hipconv._use_winograd(c3, [x(1, 256 >> l, 512 >> l) for l in range(5)])                            # RPN over 5 levels
     assert hipconv._use_winograd(nn.Conv2d(256, 18, 3, padding=1), [x(1, 256 >> l, 512 >> l) for l in range(4)])   # DCN offsets

@@ -31,8 +31,11 @@ for name, segs, cin, cout in shapes:
     gf = 2.0 * cout * cin * 9 * sum(n * h * w for n, h, w in segs) / 1e9
     line = "%-28s %6.1f GFLOP | direct %7.1f us (%5.1f TF)" % (name, gf, td, gf / td * 1e3)
     ww, ldw = ops.pack_winograd_weight(wgt)
-    tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
-    got = ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True)
-    err = max(float((g - r).abs().max()) for g, r in zip(got, ref))
-    line += " | winograd %7.1f us (%5.1f TF-equiv, x%.2f, err %.1e)" % (tw, gf / tw * 1e3, td / tw, err)
+    for tm in (64, 32):                     # 2x2 tiles per workgroup: 64 = 8 waves, 1 workgroup / CU; 32 = 4 waves, 2 / CU
+        lib().upsnet_conv_tuning(tm, 0)
+        tw = timeit(lambda: ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True))
+        got = ops.conv2d_winograd_multi(xs, ww, ldw, b, cout, True)
+        err = max(float((g - r).abs().max()) for g, r in zip(got, ref))
+        line += " | winograd/%d %7.1f us (%5.1f TF-equiv, x%.2f, err %.1e)" % (tm, tw, gf / tw * 1e3, td / tw, err)
+    lib().upsnet_conv_tuning(0, 0)
     print(line, flush=True)

@@ -506,7 +506,8 @@ static int conv_launch(hipStream_t st, ConvParams &p)
 // expensive gather, computed once per 128 output channels; 168 registers -> 3 waves per SIMD). Cout <= 32 heads use 128x32.
 // upsnet_conv_tuning(0, force_tile) overrides for A/B runs.
 static int g_force_tile = 0;
-extern "C" void upsnet_conv_tuning(int reserved, int force_tile) { (void)reserved; g_force_tile = force_tile; }
+extern int g_wino_tm;
+extern "C" void upsnet_conv_tuning(int winograd_tiles, int force_tile) { g_wino_tm = winograd_tiles; g_force_tile = force_tile; }
 
 template <int DEFORM>
 static int conv_dispatch(hipStream_t st, ConvParams &p)

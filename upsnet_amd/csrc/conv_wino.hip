@@ -25,7 +25,6 @@
 #include "upsnet_hip.h"
 
 #define WG_STEPS 32          // (xi, h) steps per slab: 16 positions x 2 k-halves of 8 channels; 16 per wave
-#define WG_BUF 65536u        // bytes of one V buffer: 16 xi x 4 q x 64 tiles x 16 B
 #define WG_RING 4            // B fragments in flight per wave
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -36,13 +35,18 @@ __device__ static inline float2 f2add(const float2 a, const float2 b) { return m
 
 // SPLITK: the K walk is divided over p.ksplit workgroups per tile; each writes its raw output-transformed partial sums to
 // p.partial [ksplit][N*OH*OW][Cout] (the transform is linear), reduced with bias / residual / ReLU by conv_splitk_reduce_kernel.
-template <bool SPLITK>
-__global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p)
+// TM: 2x2 tiles per workgroup. 64: 8 waves (2 x 2 blocks x 2 position halves), one workgroup per CU. 32: 4 waves (1 x 2 blocks x
+// 2 halves), two workgroups per CU -- the prologue / epilogue of one overlaps the K walk of the other and mid-size maps get
+// twice the workgroups, for twice the B traffic per output.
+template <bool SPLITK, int TM>
+__global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr unsigned WG_BUF = 16u * 4u * TM * 16u;     // bytes of one V buffer: 16 xi x 4 q x TM tiles x 16 B
+    constexpr int NPAIR = TM / 16;                       // 32x32 blocks of the workgroup tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = wave & 3, xh = wave >> 2;
-    const int wm = pair & 1, wn = pair >> 1;
+    const int pair = wave % NPAIR, xh = wave / NPAIR;
+    const int wm = TM == 64 ? (pair & 1) : 0, wn = TM == 64 ? (pair >> 1) : pair;
     const int lhalf = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles, and all n-tiles of an
     // m-tile (they share the input patches) stay on that XCD. Same scheme as conv_igemm_f32_kernel.
@@ -63,7 +67,7 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
 #pragma unroll
     for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
     const ConvSeg sg = p.seg[si];
-    const long p0 = (long)(m_t - sg.tile_start) * 64;
+    const long p0 = (long)(m_t - sg.tile_start) * TM;
     const int n0 = n_t * 64;
     const int nslabs = p.Cin >> 4;
     const int s_per = SPLITK ? (nslabs + p.ksplit - 1) / p.ksplit : nslabs;
@@ -101,12 +105,13 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
     const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
     const char *xbase = reinterpret_cast<const char *>(((size_t)xhi << 32) | xlo);
-    // LDS addresses (bytes within a buffer): stash unit [xi][lq][ltile ^ 2 lq] (+ 4096 per xi), this thread's 8-byte half;
-    // fragment unit [2t + lhalf][row ^ (4h + 2 lhalf)] (+ 2048 per step t), row = 32 wm + l32
-    const unsigned st_base = (unsigned)((lq * 64 + (ltile ^ (2 * lq))) * 16 + (lc2 & 1) * 8);
+    // LDS addresses (bytes within a buffer): stash unit [xi][lq][ltile ^ 2 lq] (+ 4 planes per xi), this thread's 8-byte half;
+    // fragment unit [2t + lhalf][row ^ (4h + 2 lhalf)] (+ 2 planes per step t), row = 32 wm + l32
+    const unsigned st_base = (unsigned)((lq * TM + (ltile ^ (2 * lq))) * 16 + (lc2 & 1) * 8);
     const int frow = 32 * wm + l32;
-    const unsigned fr_base0 = (unsigned)(lhalf * 1024 + (frow ^ (2 * lhalf)) * 16 + xh * 16 * 2048);
-    const unsigned fr_base1 = (unsigned)(lhalf * 1024 + (frow ^ (4 + 2 * lhalf)) * 16 + xh * 16 * 2048);
+    constexpr unsigned PLANE = TM * 16u;                  // bytes of one (xi, q) plane; a step t = (xi, h) spans two planes
+    const unsigned fr_base0 = (unsigned)(lhalf * PLANE + (frow ^ (2 * lhalf)) * 16 + xh * 16 * 2 * PLANE);
+    const unsigned fr_base1 = (unsigned)(lhalf * PLANE + (frow ^ (4 + 2 * lhalf)) * 16 + xh * 16 * 2 * PLANE);
     // B: lane's float4 of step g = slab * 32 + t sits at wbase + g * 2048 + lhalf * 1024 + (32 wn + l32) * 16
     const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)n_t * (size_t)nslabs * (WG_STEPS * 2048u);
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
@@ -136,10 +141,10 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
     // column pass + stash of V[i][J] for i = 0..3 into the buffer at byte address SB
 #define WG_COLSTASH(J, SB)                                                                                            \
     {                                                                                                                 \
-        *reinterpret_cast<float2 *>(smem_raw + (SB) + (0 * 4 + J) * 4096) = f2sub(ld[0 + J], ld[8 + J]);            \
-        *reinterpret_cast<float2 *>(smem_raw + (SB) + (1 * 4 + J) * 4096) = f2add(ld[4 + J], ld[8 + J]);            \
-        *reinterpret_cast<float2 *>(smem_raw + (SB) + (2 * 4 + J) * 4096) = f2sub(ld[8 + J], ld[4 + J]);            \
-        *reinterpret_cast<float2 *>(smem_raw + (SB) + (3 * 4 + J) * 4096) = f2sub(ld[4 + J], ld[12 + J]);           \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (0 * 4 + J) * 4 * PLANE) = f2sub(ld[0 + J], ld[8 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (1 * 4 + J) * 4 * PLANE) = f2add(ld[4 + J], ld[8 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (2 * 4 + J) * 4 * PLANE) = f2sub(ld[8 + J], ld[4 + J]);            \
+        *reinterpret_cast<float2 *>(smem_raw + (SB) + (3 * 4 + J) * 4 * PLANE) = f2sub(ld[4 + J], ld[12 + J]);           \
     }
 #define WG_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 2048u, 0); \
         breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
             if (u < 8) { WG_LOAD(2 * u, xr) WG_LOAD(2 * u + 1, xr) }
             // (2) A fragment of the next step (step 0 of the next slab comes from the other buffer, after the barrier)
             float4 afn;
-            if (u < 15) afn = *reinterpret_cast<const float4 *>(smem_raw + cur + (((u + 1) & 1) ? fr_base1 : fr_base0) + (unsigned)(u + 1) * 2048u);
+            if (u < 15) afn = *reinterpret_cast<const float4 *>(smem_raw + cur + (((u + 1) & 1) ? fr_base1 : fr_base0) + (unsigned)(u + 1) * 2u * PLANE);
             else afn = *reinterpret_cast<const float4 *>(smem_raw + nxt + fr_base0);
             // (3) input transform of the next slab and its stash into the other buffer
             if (u == 8) WG_ROWPASS(0)
@@ -273,34 +278,49 @@ __global__ void __launch_bounds__(512) conv_wino16_f32_kernel(const ConvParams p
 
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
 // p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
-static int conv_wino16_launch(hipStream_t st, ConvParams &p)
+template <int TM>
+static int conv_wino16_launch_tm(hipStream_t st, ConvParams &p)
 {
-    UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
     int tiles = 0;
-    for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + 63) / 64); }
+    for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + TM - 1) / TM); }
     p.m_tiles = tiles;
     p.n_tiles = p.ldw / 64;
-    for (int i = 0; i < p.nseg; ++i)
-        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
-    const size_t smem = 2 * WG_BUF;
+    const size_t smem = 2 * 16 * 4 * TM * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    if (p.ksplit > 1) hipLaunchKernelGGL((conv_wino16_f32_kernel<true, TM>), dim3(grid * p.ksplit), dim3(8 * TM), smem, st, p);
+    else hipLaunchKernelGGL((conv_wino16_f32_kernel<false, TM>), dim3(grid), dim3(8 * TM), smem, st, p);
+    UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
+    return 0;
+}
+
+// Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
+// p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
+int g_wino_tm = 0;   // 0 auto; 32 / 64 forced (upsnet_conv_tuning, A/B runs)
+static int conv_wino16_launch(hipStream_t st, ConvParams &p)
+{
+    UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
+    for (int i = 0; i < p.nseg; ++i)
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
     if (p.ksplit > 1) {
         const int nslabs = p.Cin / 16;
         UPS_REQUIRE(p.nseg == 1 && p.partial, "conv2d_winograd_nhwc_f32_splitk: one map and a workspace");
         UPS_REQUIRE(((nslabs + p.ksplit - 1) / p.ksplit) * (p.ksplit - 1) < nslabs, "conv2d_winograd_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, p.ksplit);
         p.m_total = (long)p.seg[0].N * p.seg[0].OH * p.seg[0].OW;
-        hipLaunchKernelGGL(conv_wino16_f32_kernel<true>, dim3(grid * p.ksplit), dim3(512), smem, st, p);
-    } else {
-        hipLaunchKernelGGL(conv_wino16_f32_kernel<false>, dim3(grid), dim3(512), smem, st, p);
     }
-    UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
-    return 0;
+    // 64-tile workgroups (one per CU) for the big maps, where the doubled B traffic of the 32-tile form costs more than its
+    // overlapped prologue / epilogue gains (FPN P2: 638 vs 733 us); 32-tile workgroups (two per CU) below 768 of the former
+    // (FPN P4 78 -> 49 us, res4 conv2 73 -> 46, mask head 148 -> 116; equal at P3 / the RPN launch). hipconv._wino_tm mirrors this.
+    long wgs64 = 0;
+    for (int i = 0; i < p.nseg; ++i) wgs64 += (p.seg[i].M + 63) / 64;
+    wgs64 *= p.ldw / 64;
+    const int tm = g_wino_tm ? g_wino_tm : (wgs64 > 768 ? 64 : 32);
+    return tm == 32 ? conv_wino16_launch_tm<32>(st, p) : conv_wino16_launch_tm<64>(st, p);
 }
 
 // weight [Cout, Cin, 3, 3] -> U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in fragment order

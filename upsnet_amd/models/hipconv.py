@@ -82,24 +82,31 @@ def _use_winograd(m, xs, always=False):
         return False
     if always:
         return True
-    return _wino_workgroups(m, xs) * (_wino_ksplit(m, xs) if len(xs) == 1 else 1) >= WINOGRAD_MIN_WORKGROUPS
+    return _wino_workgroups(m, xs, _wino_tm(m, xs)) * _wino_ksplit(m, xs) >= WINOGRAD_MIN_WORKGROUPS
 
 
-def _wino_workgroups(m, xs):
-    tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // 64) for x in xs)
+def _wino_workgroups(m, xs, tm=64):
+    tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // tm) for x in xs)
     return tiles * (-(-m.out_channels // 64))
 
 
+def _wino_tm(m, xs):
+    """2x2 tiles per workgroup the launcher will pick (csrc/conv_wino.hip, conv_wino16_launch): 64 (one workgroup per CU) above
+    768 such workgroups, else 32 (two per CU)."""
+    return 64 if _wino_workgroups(m, xs, 64) > 768 else 32
+
+
 def _wino_ksplit(m, xs):
-    """Split-K factor of the Winograd kernel for one map with too few 64-tile x 64-channel workgroups for 256 CUs (res4 / res5
-    3x3, FPN P4 / P5): the largest split that keeps <= 256 workgroups (one round) and >= 4 slabs of 16 channels per workgroup."""
-    if not SPLITK or len(xs) != 1 or m.out_channels % 4:
+    """Split-K factor of the Winograd kernel for one map with fewer than 256 32-tile x 64-channel workgroups (res5 3x3, FPN
+    P5): the largest split that stays within the 512 workgroup slots of 256 CUs and keeps >= 4 slabs of 16 channels per
+    workgroup."""
+    if not SPLITK or len(xs) != 1 or m.out_channels % 4 or _wino_tm(m, xs) == 64:
         return 1
-    wgs, slabs = _wino_workgroups(m, xs), m.in_channels // 16
-    if wgs > 160:
+    wgs, slabs = _wino_workgroups(m, xs, 32), m.in_channels // 16
+    if wgs >= 256:   # (res4 conv2, 256 workgroups: 46 us unsplit, 53 us split in two + the reduce launch)
         return 1
     k = 1
-    while k < 8 and wgs * (k + 1) <= 256 and slabs // (k + 1) >= 4:
+    while k < 8 and wgs * (k + 1) <= 512 and slabs // (k + 1) >= 4:
         k += 1
     return k
 
