@@ -310,7 +310,6 @@ soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int
     __shared__ float s_val[SNMS_T / 64];
     __shared__ int s_pos[SNMS_T / 64];
     __shared__ int s_scan[SNMS_T / 64];
-    __shared__ int s_maxpos;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += SNMS_T) inds[i] = i;
     __syncthreads();
@@ -331,7 +330,6 @@ soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int
             for (int w = 1; w < SNMS_T / 64; ++w) if (s_val[w] > v || (s_val[w] == v && s_pos[w] < p)) { v = s_val[w]; p = s_pos[w]; }
             // reference starts from maxpos = i and moves only on a strictly larger score
             if (!(boxes[i * 5 + 4] < v)) p = i;
-            s_maxpos = p;
             if (p != i) {
                 for (int k = 0; k < 5; ++k) { float t = boxes[i * 5 + k]; boxes[i * 5 + k] = boxes[p * 5 + k]; boxes[p * 5 + k] = t; }
                 int64_t ti = inds[i]; inds[i] = inds[p]; inds[p] = ti;
