@@ -131,6 +131,36 @@ def test_winograd_conv_vs_torch(shapes, Cin, Cout, relu, res, bias):
     assert all(torch.equal(a, o) for a, o in zip(again, outs))   # fixed summation order: bit-repeatable
 
 
+@pytest.mark.parametrize("shapes,Cin,Cout", [
+    ([(1, 1, 1)], 32, 5),                       # a single partial tile, odd Cout
+    ([(1, 2, 3), (3, 5, 7)], 64, 70),           # ragged maps, batch 3, Cout just above one 64-channel tile
+    ([(2, 31, 17)], 96, 64),                    # Cin = 6 slabs of 16
+])
+def test_winograd_tile_forms_agree_bit_for_bit(shapes, Cin, Cout):
+    """The 64-tile (8 waves, one workgroup per CU) and the 32-tile (4 waves, two per CU) forms of the Winograd kernel compute
+    every output element with the same arithmetic in the same order: identical bits, whatever the launcher would pick; both
+    within 1e-4 of torch fp64 on edge shapes."""
+    from upsnet_amd import ops
+    from upsnet_amd._lib import lib
+    torch.manual_seed(Cin + Cout)
+    xs = [torch.randn(n, Cin, h, w, device='cuda') for n, h, w in shapes]
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    rs = [torch.randn(x.shape[0], Cout, x.shape[2], x.shape[3], device='cuda') for x in xs]
+    wp, ldw = ops.pack_winograd_weight(w)
+    outs = {}
+    try:
+        for tm in (64, 32):
+            lib().upsnet_conv_tuning(tm, 0)
+            outs[tm] = ops.conv2d_winograd_multi(xs, wp, ldw, b, Cout, relu=True, residuals=rs)
+    finally:
+        lib().upsnet_conv_tuning(0, 0)
+    for x, r, o64, o32 in zip(xs, rs, outs[64], outs[32]):
+        assert torch.equal(o64, o32)
+        ref = (F.conv2d(x.double(), w.double(), b.double(), padding=1) + r.double()).clamp_min(0)
+        np.testing.assert_allclose(o64.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ksplit,relu,res", [
     (1, 64, 128, 256, 256, 2, True, False),     # res4 3x3
     (1, 32, 64, 512, 512, 4, True, False),      # res5 3x3
