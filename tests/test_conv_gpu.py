@@ -103,7 +103,9 @@ def test_conv_residual_nearest_upsample_fused(N, Cin, Cout, H, W):
     ([(1, 32, 64)], 64, 64, True, False, True),
     ([(1, 33, 47)], 32, 96, False, False, True),          # odd sizes: partial 2x2 tiles on the right / bottom edge
     ([(2, 14, 14)], 256, 256, True, True, True),          # batch > 1, residual, tiles wrap rows every 7
-    ([(1, 17, 9)], 64, 18, False, False, False),          # Cout < 32 (128x32 tile instance)
+    ([(1, 17, 9)], 64, 18, False, False, False),          # Cout <= 32: the 32-tile x 32-channel form (4 waves, 4 positions each)
+    ([(1, 64, 128), (1, 32, 64), (1, 16, 32)], 256, 18, False, False, True),   # DCN offset conv over 3 levels
+    ([(2, 9, 11)], 32, 32, True, True, True),             # exactly 32 channels, residual, ReLU
     ([(1, 64, 128), (1, 32, 64), (1, 16, 32), (1, 8, 16), (1, 4, 8)], 256, 256, True, False, True),   # 5 maps, one launch (RPN head)
 ])
 def test_winograd_conv_vs_torch(shapes, Cin, Cout, relu, res, bias):
@@ -166,7 +168,8 @@ def test_winograd_tile_forms_agree_bit_for_bit(shapes, Cin, Cout):
     (1, 32, 64, 512, 512, 4, True, False),      # res5 3x3
     (1, 33, 47, 64, 96, 2, False, True),        # odd sizes, residual, Cout not a multiple of 64
     (2, 14, 14, 256, 256, 8, True, True),       # 16 slabs split 8 ways
-    (1, 9, 7, 96, 32, 3, False, False),         # 6 slabs split 3 ways
+    (1, 9, 7, 96, 32, 3, False, False),         # 6 slabs split 3 ways, 32-channel form
+    (1, 20, 12, 128, 20, 2, True, True),        # 32-channel form, Cout % 4 == 0 but < 32
 ])
 def test_winograd_splitk_vs_torch(N, H, W, Cin, Cout, ksplit, relu, res):
     """Winograd with the K walk split over `ksplit` workgroups per tile + the shared reduce kernel vs torch fp64 (1e-4) and

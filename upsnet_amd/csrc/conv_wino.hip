@@ -25,7 +25,6 @@
 #include "upsnet_hip.h"
 
 #define WG_STEPS 32          // (xi, h) steps per slab: 16 positions x 2 k-halves of 8 channels; 16 per wave
-#define WG_RING 4            // B fragments in flight per wave
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
@@ -38,12 +37,20 @@ __device__ static inline float2 f2add(const float2 a, const float2 b) { return m
 // TM: 2x2 tiles per workgroup. 64: 8 waves (2 x 2 blocks x 2 position halves), one workgroup per CU. 32: 4 waves (1 x 2 blocks x
 // 2 halves), two workgroups per CU -- the prologue / epilogue of one overlaps the K walk of the other and mid-size maps get
 // twice the workgroups, for twice the B traffic per output.
-template <bool SPLITK, int TM>
+// TN: output channels per workgroup. 64, or 32 (only with TM = 32) for the narrow heads (the DCN offset convolutions, Cout = 18,
+// would waste 46 of 64 columns): one 32x32 block, the 16 positions split over FOUR waves (4 accumulators each).
+template <bool SPLITK, int TM, int TN>
 __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kernel(const ConvParams p)
 {
+    static_assert(TN == 64 || (TN == 32 && TM == 32), "tile forms: 64x64, 32x64, 32x32");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr unsigned WG_BUF = 16u * 4u * TM * 16u;     // bytes of one V buffer: 16 xi x 4 q x TM tiles x 16 B
-    constexpr int NPAIR = TM / 16;                       // 32x32 blocks of the workgroup tile
+    constexpr int NPAIR = (TM / 32) * (TN / 32);         // 32x32 blocks of the workgroup tile
+    constexpr int NX = (TM / 8) / NPAIR;                 // groups the 16 positions are split into (waves per block): 2 or 4
+    constexpr int NA = 16 / NX;                          // accumulators (positions) per wave
+    constexpr int NS = 2 * NA;                           // (xi, h) steps per wave and slab
+    constexpr unsigned BSTEP = TN * 32u;                 // bytes of one step of the packed weights: 2 q x TN channels x 16 B
+    constexpr int WG_RING = 4;                           // B fragments in flight per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pair = wave % NPAIR, xh = wave / NPAIR;
     const int wm = TM == 64 ? (pair & 1) : 0, wn = TM == 64 ? (pair >> 1) : pair;
@@ -68,7 +75,7 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
     for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
     const ConvSeg sg = p.seg[si];
     const long p0 = (long)(m_t - sg.tile_start) * TM;
-    const int n0 = n_t * 64;
+    const int n0 = n_t * TN;
     const int nslabs = p.Cin >> 4;
     const int s_per = SPLITK ? (nslabs + p.ksplit - 1) / p.ksplit : nslabs;
     const int s_begin = kz * s_per, s_end = min(s_begin + s_per, nslabs);   // slabs walked by this workgroup (launcher: never empty)
@@ -110,20 +117,20 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
     const unsigned st_base = (unsigned)((lq * TM + (ltile ^ (2 * lq))) * 16 + (lc2 & 1) * 8);
     const int frow = 32 * wm + l32;
     constexpr unsigned PLANE = TM * 16u;                  // bytes of one (xi, q) plane; a step t = (xi, h) spans two planes
-    const unsigned fr_base0 = (unsigned)(lhalf * PLANE + (frow ^ (2 * lhalf)) * 16 + xh * 16 * 2 * PLANE);
-    const unsigned fr_base1 = (unsigned)(lhalf * PLANE + (frow ^ (4 + 2 * lhalf)) * 16 + xh * 16 * 2 * PLANE);
+    const unsigned fr_base0 = (unsigned)(lhalf * PLANE + (frow ^ (2 * lhalf)) * 16 + xh * NS * 2 * PLANE);
+    const unsigned fr_base1 = (unsigned)(lhalf * PLANE + (frow ^ (4 + 2 * lhalf)) * 16 + xh * NS * 2 * PLANE);
     // B: lane's float4 of step g = slab * 32 + t sits at wbase + g * 2048 + lhalf * 1024 + (32 wn + l32) * 16
-    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)n_t * (size_t)nslabs * (WG_STEPS * 2048u);
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)n_t * (size_t)nslabs * (WG_STEPS * BSTEP);
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0,
-                                                                            nslabs * (WG_STEPS * 2048), 0x00020000);
-    const unsigned b_lane = (unsigned)(lhalf * 1024 + (32 * wn + l32) * 16);
+                                                                            nslabs * (int)(WG_STEPS * BSTEP), 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * (TN * 16) + (32 * wn + l32) * 16);
     const int gmax = nslabs * WG_STEPS - 1;
     const int xh_u = __builtin_amdgcn_readfirstlane(xh);
 
-    floatx16 acc[8];
+    floatx16 acc[NA];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -146,7 +153,7 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
         *reinterpret_cast<float2 *>(smem_raw + (SB) + (2 * 4 + J) * 4 * PLANE) = f2sub(ld[8 + J], ld[4 + J]);            \
         *reinterpret_cast<float2 *>(smem_raw + (SB) + (3 * 4 + J) * 4 * PLANE) = f2sub(ld[4 + J], ld[12 + J]);           \
     }
-#define WG_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 2048u, 0); \
+#define WG_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * BSTEP, 0); \
         breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
 
     // ---- prologue: slab 0 into buffer 0, first ring of B fragments
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
 #pragma unroll
         for (int i = 0; i < 16; ++i) WG_LOAD(i, xr)
 #pragma unroll
-        for (int u = 0; u < WG_RING; ++u) WG_BLOAD(u, s_begin * WG_STEPS + 16 * xh_u + u)
+        for (int u = 0; u < WG_RING; ++u) WG_BLOAD(u, s_begin * WG_STEPS + NS * xh_u + u)
         WG_ROWPASS(0) WG_ROWPASS(1) WG_ROWPASS(2) WG_ROWPASS(3)
         WG_COLSTASH(0, st_base) WG_COLSTASH(1, st_base) WG_COLSTASH(2, st_base) WG_COLSTASH(3, st_base)
     }
@@ -167,32 +174,39 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xbase) + (size_t)sn * 64, 0, xbytes - (unsigned)sn * 64u, 0x00020000);
         const unsigned cur = ((s - s_begin) & 1) ? WG_BUF : 0u, nxt = WG_BUF - cur;
         const unsigned sb = nxt + st_base;
-        const int g0 = s * WG_STEPS + 16 * xh_u;
+        const int g0 = s * WG_STEPS + NS * xh_u;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            // (1) global loads of the next slab's patch: two pixels per step in steps 0..7
-            if (u < 8) { WG_LOAD(2 * u, xr) WG_LOAD(2 * u + 1, xr) }
+        for (int u = 0; u < NS; ++u) {
+            // (1) global loads of the next slab's patch, spread over the first half of the steps
+            if (NS == 16 && u < 8) { WG_LOAD(2 * u, xr) WG_LOAD(2 * u + 1, xr) }
+            if (NS == 8 && u < 4) { WG_LOAD(4 * u, xr) WG_LOAD(4 * u + 1, xr) WG_LOAD(4 * u + 2, xr) WG_LOAD(4 * u + 3, xr) }
             // (2) A fragment of the next step (step 0 of the next slab comes from the other buffer, after the barrier)
             float4 afn;
-            if (u < 15) afn = *reinterpret_cast<const float4 *>(smem_raw + cur + (((u + 1) & 1) ? fr_base1 : fr_base0) + (unsigned)(u + 1) * 2u * PLANE);
+            if (u < NS - 1) afn = *reinterpret_cast<const float4 *>(smem_raw + cur + (((u + 1) & 1) ? fr_base1 : fr_base0) + (unsigned)(u + 1) * 2u * PLANE);
             else afn = *reinterpret_cast<const float4 *>(smem_raw + nxt + fr_base0);
             // (3) input transform of the next slab and its stash into the other buffer
-            if (u == 8) WG_ROWPASS(0)
-            if (u == 9) WG_ROWPASS(1)
-            if (u == 10) WG_ROWPASS(2)
-            if (u == 11) { WG_ROWPASS(3) WG_COLSTASH(0, sb) }
-            if (u == 12) WG_COLSTASH(1, sb)
-            if (u == 13) WG_COLSTASH(2, sb)
-            if (u == 14) WG_COLSTASH(3, sb)
-            // (4) the four MFMAs of step (xi = 8 xh + u/2, h = u%2): channels 4(2h + half) .. +3 of the slab
+            if (NS == 16) {
+                if (u == 8) WG_ROWPASS(0)
+                if (u == 9) WG_ROWPASS(1)
+                if (u == 10) WG_ROWPASS(2)
+                if (u == 11) { WG_ROWPASS(3) WG_COLSTASH(0, sb) }
+                if (u == 12) WG_COLSTASH(1, sb)
+                if (u == 13) WG_COLSTASH(2, sb)
+                if (u == 14) WG_COLSTASH(3, sb)
+            } else {
+                if (u == 4) { WG_ROWPASS(0) WG_ROWPASS(1) }
+                if (u == 5) { WG_ROWPASS(2) WG_ROWPASS(3) WG_COLSTASH(0, sb) }
+                if (u == 6) { WG_COLSTASH(1, sb) WG_COLSTASH(2, sb) WG_COLSTASH(3, sb) }
+            }
+            // (4) the four MFMAs of step (xi = NA xh + u/2, h = u%2): channels 4(2h + half) .. +3 of the slab
             const float4 bf = breg[u % WG_RING];
             acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.x, bf.x, acc[u >> 1], 0, 0, 0);
             acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.y, bf.y, acc[u >> 1], 0, 0, 0);
             acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.z, bf.z, acc[u >> 1], 0, 0, 0);
             acc[u >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr.w, bf.w, acc[u >> 1], 0, 0, 0);
-            // (5) refill the ring slot just consumed: this wave's step 8 ahead (wraps into the next slab)
-            WG_BLOAD(u % WG_RING, (u + WG_RING < 16 ? g0 : g0 + 16) + u + WG_RING)
-            if (u == 14) __syncthreads();   // every read of `cur` is issued, every stash into `nxt` is visible
+            // (5) refill the ring slot just consumed: this wave's step WG_RING ahead (wraps into the next slab)
+            WG_BLOAD(u % WG_RING, (u + WG_RING < NS ? g0 : g0 + WG_STEPS - NS) + u + WG_RING)
+            if (u == NS - 2) __syncthreads();   // every read of `cur` is issued, every stash into `nxt` is visible
             afr = afn;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -206,7 +220,52 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
     // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]. acc[4 il + j] = M[2 xh + il][j]. Wave xh = 0 needs M_2j,
     // wave xh = 1 needs M_1j: one float4 per accumulator element through LDS ([pair][direction][r][lane] 16-byte units).
     __syncthreads();
-    {
+    const bool has_res = sg.res != nullptr;
+    const long pbase = p0 + wm * 32 + 4 * lhalf;
+    const long pb = pbase < sg.M ? pbase : sg.M - 1;
+    const int n_b = (int)(pb / HoWo);
+    const int rem_b = (int)(pb - (long)n_b * HoWo);
+    const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+    const bool fast = sg.Wo >= 32;
+    const int co = n0 + wn * 32 + l32;
+    const bool co_ok = co < p.Cout;
+    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+    // position of accumulator element with row offset `off` inside the block; false if it is beyond the map
+#define WG_WHERE(OFF, N_, H_, W_)                                                                                     \
+    int N_ = n_b, H_ = h_b, W_ = w_b;                                                                                 \
+    if (fast) {                                                                                                       \
+        W_ += (OFF);                                                                                                  \
+        if (W_ >= sg.Wo) { W_ -= sg.Wo; ++H_; }                                                                       \
+        if (H_ >= sg.Ho) { H_ -= sg.Ho; ++N_; }                                                                       \
+    } else {                                                                                                          \
+        const long pp_ = pbase + (OFF);                                                                               \
+        N_ = (int)(pp_ / HoWo);                                                                                       \
+        const int rem_ = (int)(pp_ - (long)N_ * HoWo);                                                                \
+        H_ = rem_ / sg.Wo; W_ = rem_ - H_ * sg.Wo;                                                                    \
+    }
+    // one output row (two pixels) of a tile: + bias, + residual, ReLU, store (split-K: raw partial sums)
+#define WG_STORE_ROW(N_, OY, OX, V0, V1)                                                                              \
+    if ((OY) < sg.OH) {                                                                                               \
+        float v0_ = (V0), v1_ = (V1);                                                                                 \
+        const bool x1_ = (OX) + 1 < sg.OW;                                                                            \
+        const long o0_ = (((long)(N_) * sg.OH + (OY)) * sg.OW + (OX)) * p.Cout + co;                                  \
+        const long o1_ = o0_ + p.Cout;                                                                                \
+        if (SPLITK) {                                                                                                 \
+            float *part_ = p.partial + (long)kz * p.m_total * p.Cout;                                                 \
+            part_[o0_] = v0_;                                                                                         \
+            if (x1_) part_[o1_] = v1_;                                                                                \
+        } else {                                                                                                      \
+            v0_ = v0_ + bv; v1_ = v1_ + bv;                                                                           \
+            if (has_res) {                                                                                            \
+                v0_ = v0_ + sg.res[o0_];                                                                              \
+                if (x1_) v1_ = v1_ + sg.res[o1_];                                                                     \
+            }                                                                                                         \
+            if (p.relu) { v0_ = fmaxf(v0_, 0.f); v1_ = fmaxf(v1_, 0.f); }                                             \
+            sg.out[o0_] = v0_;                                                                                        \
+            if (x1_) sg.out[o1_] = v1_;                                                                               \
+        }                                                                                                             \
+    }
+    if constexpr (NX == 2) {
         float4 *mine = reinterpret_cast<float4 *>(smem_raw + pair * 32768 + xh_u * 16384) + lane;
         const float4 *theirs = reinterpret_cast<const float4 *>(smem_raw + pair * 32768 + (1 - xh_u) * 16384) + lane;
         if (xh_u == 0) {                    // xh = 0 gives M_1j = acc[4 + j], xh = 1 gives M_2j = acc[j]
@@ -217,32 +276,12 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
             for (int r = 0; r < 16; ++r) mine[r * 64] = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
         }
         __syncthreads();
-        const bool has_res = sg.res != nullptr;
-        const long pbase = p0 + wm * 32 + 4 * lhalf;
-        const long pb = pbase < sg.M ? pbase : sg.M - 1;
-        const int n_b = (int)(pb / HoWo);
-        const int rem_b = (int)(pb - (long)n_b * HoWo);
-        const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
-        const bool fast = sg.Wo >= 32;
-        const int co = n0 + wn * 32 + l32;
-        const bool co_ok = co < p.Cout;
-        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int off = (r & 3) + 8 * (r >> 2);
             const float4 o = theirs[r * 64];
             if (!(co_ok && pbase + off < sg.M)) continue;
-            int n = n_b, h = h_b, w = w_b;
-            if (fast) {
-                w += off;
-                if (w >= sg.Wo) { w -= sg.Wo; ++h; }
-                if (h >= sg.Ho) { h -= sg.Ho; ++n; }
-            } else {
-                const long pp = pbase + off;
-                n = (int)(pp / HoWo);
-                const int rem = (int)(pp - (long)n * HoWo);
-                h = rem / sg.Wo; w = rem - h * sg.Wo;
-            }
+            WG_WHERE(off, n, h, w)
             // t[j] = sum_i A^T[xh][i] M[i][j]: row 0: (M0j + M1j) + M2j, row 1: (M1j - M2j) - M3j
             float t0, t1, t2, t3;
             if (xh_u == 0) {
@@ -252,59 +291,65 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
                 t0 = (o.x - acc[0][r]) - acc[4][r]; t1 = (o.y - acc[1][r]) - acc[5][r];
                 t2 = (o.z - acc[2][r]) - acc[6][r]; t3 = (o.w - acc[3][r]) - acc[7][r];
             }
-            float v0 = (t0 + t1) + t2, v1 = (t1 - t2) - t3;
-            const int oy = 2 * h + xh_u, ox = 2 * w;
-            if (oy >= sg.OH) continue;
-            const bool x1 = ox + 1 < sg.OW;
-            const long o0 = (((long)n * sg.OH + oy) * sg.OW + ox) * p.Cout + co;
-            const long o1 = o0 + p.Cout;
-            if (SPLITK) {
-                float *part = p.partial + (long)kz * p.m_total * p.Cout;
-                part[o0] = v0;
-                if (x1) part[o1] = v1;
-                continue;
-            }
-            v0 = v0 + bv; v1 = v1 + bv;
-            if (has_res) {
-                v0 = v0 + sg.res[o0];
-                if (x1) v1 = v1 + sg.res[o1];
-            }
-            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            sg.out[o0] = v0;
-            if (x1) sg.out[o1] = v1;
+            WG_STORE_ROW(n, 2 * h + xh_u, 2 * w, (t0 + t1) + t2, (t1 - t2) - t3)
+        }
+    } else {
+        // four waves per block: wave xh holds M[xh][0..3] (acc[j]); every wave publishes its row, then finishes the accumulator
+        // elements r in [4 xh, 4 xh + 4) -- both output rows of those tiles -- from the four published rows
+        float4 *mine = reinterpret_cast<float4 *>(smem_raw + xh_u * 16384) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64] = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * xh_u + rr;
+            const int off = rr + 8 * xh_u;      // (r & 3) + 8 (r >> 2)
+            const float4 m0 = reinterpret_cast<const float4 *>(smem_raw)[r * 64 + lane];
+            const float4 m1 = reinterpret_cast<const float4 *>(smem_raw + 16384)[r * 64 + lane];
+            const float4 m2 = reinterpret_cast<const float4 *>(smem_raw + 32768)[r * 64 + lane];
+            const float4 m3 = reinterpret_cast<const float4 *>(smem_raw + 49152)[r * 64 + lane];
+            if (!(co_ok && pbase + off < sg.M)) continue;
+            WG_WHERE(off, n, h, w)
+            const float a0 = (m0.x + m1.x) + m2.x, a1 = (m0.y + m1.y) + m2.y, a2 = (m0.z + m1.z) + m2.z, a3 = (m0.w + m1.w) + m2.w;
+            const float b0 = (m1.x - m2.x) - m3.x, b1 = (m1.y - m2.y) - m3.y, b2 = (m1.z - m2.z) - m3.z, b3 = (m1.w - m2.w) - m3.w;
+            WG_STORE_ROW(n, 2 * h, 2 * w, (a0 + a1) + a2, (a1 - a2) - a3)
+            WG_STORE_ROW(n, 2 * h + 1, 2 * w, (b0 + b1) + b2, (b1 - b2) - b3)
         }
     }
+#undef WG_WHERE
+#undef WG_STORE_ROW
 }
 
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
 // p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
-template <int TM>
+template <int TM, int TN>
 static int conv_wino16_launch_tm(hipStream_t st, ConvParams &p)
 {
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + TM - 1) / TM); }
     p.m_tiles = tiles;
-    p.n_tiles = p.ldw / 64;
+    p.n_tiles = p.ldw / TN;
     const size_t smem = 2 * 16 * 4 * TM * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-    if (p.ksplit > 1) hipLaunchKernelGGL((conv_wino16_f32_kernel<true, TM>), dim3(grid * p.ksplit), dim3(8 * TM), smem, st, p);
-    else hipLaunchKernelGGL((conv_wino16_f32_kernel<false, TM>), dim3(grid), dim3(8 * TM), smem, st, p);
+    if (p.ksplit > 1) hipLaunchKernelGGL((conv_wino16_f32_kernel<true, TM, TN>), dim3(grid * p.ksplit), dim3(8 * TM), smem, st, p);
+    else hipLaunchKernelGGL((conv_wino16_f32_kernel<false, TM, TN>), dim3(grid), dim3(8 * TM), smem, st, p);
     UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
     return 0;
 }
 
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
-// p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
+// p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction). The channel tile follows the packing:
+// ldw == 32 (Cout <= 32, packed in 32-channel fragment order) -> the 32x32 form; otherwise ldw % 64 == 0.
 int g_wino_tm = 0;   // 0 auto; 32 / 64 forced (upsnet_conv_tuning, A/B runs)
 static int conv_wino16_launch(hipStream_t st, ConvParams &p)
 {
-    UPS_REQUIRE(p.Cin % 16 == 0 && p.ldw % 64 == 0, "conv2d_winograd_nhwc_f32: Cin %% 16 and ldw %% 64 must be 0");
+    UPS_REQUIRE(p.Cin % 16 == 0 && (p.ldw == 32 || p.ldw % 64 == 0), "conv2d_winograd_nhwc_f32: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
     for (int i = 0; i < p.nseg; ++i)
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
     if (p.ksplit > 1) {
@@ -313,6 +358,7 @@ static int conv_wino16_launch(hipStream_t st, ConvParams &p)
         UPS_REQUIRE(((nslabs + p.ksplit - 1) / p.ksplit) * (p.ksplit - 1) < nslabs, "conv2d_winograd_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, p.ksplit);
         p.m_total = (long)p.seg[0].N * p.seg[0].OH * p.seg[0].OW;
     }
+    if (p.ldw == 32) return conv_wino16_launch_tm<32, 32>(st, p);
     // 64-tile workgroups (one per CU) for the big maps, where the doubled B traffic of the 32-tile form costs more than its
     // overlapped prologue / epilogue gains (FPN P2: 638 vs 733 us); 32-tile workgroups (two per CU) below 768 of the former
     // (FPN P4 78 -> 49 us, res4 conv2 73 -> 46, mask head 148 -> 116; equal at P3 / the RPN launch). hipconv._wino_tm mirrors this.
@@ -320,11 +366,12 @@ static int conv_wino16_launch(hipStream_t st, ConvParams &p)
     for (int i = 0; i < p.nseg; ++i) wgs64 += (p.seg[i].M + 63) / 64;
     wgs64 *= p.ldw / 64;
     const int tm = g_wino_tm ? g_wino_tm : (wgs64 > 768 ? 64 : 32);
-    return tm == 32 ? conv_wino16_launch_tm<32>(st, p) : conv_wino16_launch_tm<64>(st, p);
+    return tm == 32 ? conv_wino16_launch_tm<32, 64>(st, p) : conv_wino16_launch_tm<64, 64>(st, p);
 }
 
 // weight [Cout, Cin, 3, 3] -> U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in fragment order
-// [n-tile = co/64][slab = c/16][xi = 4i+j][q = (c%16)/4][co%64][c%4] (16 * Cin * ldw floats, ldw = Cout rounded up to 64)
+// [n-tile = co/TN][slab = c/16][xi = 4i+j][q = (c%16)/4][co%TN][c%4] (16 * Cin * ldw floats; TN = 64 and ldw = Cout rounded up to
+// 64, or TN = ldw = 32 for Cout <= 32)
 __global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
 {
     const long total = (long)ldw * cin;
@@ -350,19 +397,20 @@ __global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int 
             u[a][2] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
             u[a][3] = t[a][2];
         }
-        const long blk = ((long)(co >> 6) * nslabs + (c >> 4)) * 16;
-        const int q = (c & 15) >> 2, ci = c & 3, cl = co & 63;
+        const int tn = ldw == 32 ? 32 : 64;
+        const long blk = ((long)(co / tn) * nslabs + (c >> 4)) * 16;
+        const int q = (c & 15) >> 2, ci = c & 3, cl = co % tn;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) wp[(((blk + a * 4 + b) * 4 + q) * 64 + cl) * 4 + ci] = u[a][b];
+            for (int b = 0; b < 4; ++b) wp[(((blk + a * 4 + b) * 4 + q) * tn + cl) * 4 + ci] = u[a][b];
     }
 }
 
 extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
 {
     UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout, "conv_pack_weight_winograd: bad args");
-    UPS_REQUIRE(cin % 16 == 0 && ldw % 64 == 0, "conv_pack_weight_winograd: Cin %% 16 and ldw %% 64 must be 0");
+    UPS_REQUIRE(cin % 16 == 0 && (ldw == 32 || ldw % 64 == 0), "conv_pack_weight_winograd: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
     const long total = (long)ldw * cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;

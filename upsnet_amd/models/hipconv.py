@@ -87,13 +87,13 @@ def _use_winograd(m, xs, always=False):
 
 def _wino_workgroups(m, xs, tm=64):
     tiles = sum(-(-(x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)) // tm) for x in xs)
-    return tiles * (-(-m.out_channels // 64))
+    return tiles * (1 if m.out_channels <= 32 else -(-m.out_channels // 64))
 
 
 def _wino_tm(m, xs):
     """2x2 tiles per workgroup the launcher will pick (csrc/conv_wino.hip, conv_wino16_launch): 64 (one workgroup per CU) above
-    768 such workgroups, else 32 (two per CU)."""
-    return 64 if _wino_workgroups(m, xs, 64) > 768 else 32
+    768 such workgroups, else 32 (two per CU); always 32 for the 32-channel form (Cout <= 32)."""
+    return 64 if m.out_channels > 32 and _wino_workgroups(m, xs, 64) > 768 else 32
 
 
 def _wino_ksplit(m, xs):

@@ -628,13 +628,13 @@ def mask_roi_dedup(a_src, a_cls, a_num, b_src, b_cls, b_boxes, b_num):
 
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3)
 def pack_winograd_weight(weight):
-    """[Cout,Cin,3,3] -> ([16*Cin, ldw], ldw): U_xi = (G g G^T)[i][j] per transformed-domain position."""
+    """[Cout,Cin,3,3] -> (U = G g G^T in the kernel's fragment order, 16*Cin*ldw floats, ldw)."""
     require_cuda(weight)
     weight = f32c(weight)
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise RuntimeError("pack_winograd_weight: kernel must be 3x3")
-    ldw = (Cout + 63) // 64 * 64   # the Winograd instance tiles 64 output channels per workgroup
+    ldw = 32 if Cout <= 32 else (Cout + 63) // 64 * 64   # 64 output channels per workgroup; narrow heads: the 32-channel form
     wp = torch.empty((16 * Cin, ldw), dtype=torch.float32, device=weight.device)
     check(lib().upsnet_conv_pack_weight_winograd(stream(), ptr(weight), Cout, Cin, ldw, ptr(wp)), "conv_pack_weight_winograd")
     return wp, ldw
