@@ -7,8 +7,8 @@ from upsnet_amd import ops
 
 torch.manual_seed(0)
 from upsnet_amd._lib import lib
-lib().upsnet_conv_tuning(int(os.environ.get('WINO_FORM', '0')), int(os.environ.get('CONV_TILE', '0')))
-print('pipe', os.environ.get('CONV_PIPE', '-1'), 'tile', os.environ.get('CONV_TILE', '0'), flush=True)
+lib().upsnet_conv_tuning(int(os.environ.get('WINO_TILES', '0')), int(os.environ.get('CONV_TILE', '0')))
+print('winograd tiles', os.environ.get('WINO_TILES', '0'), 'tile', os.environ.get('CONV_TILE', '0'), flush=True)
 reps = int(os.environ.get('REPS', '10'))
 def bench(name, fn, flops, bytes_):
     for _ in range(3): fn()
