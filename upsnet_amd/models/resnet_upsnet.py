@@ -187,11 +187,14 @@ class resnet_upsnet(resnet_rcnn):
         x = data['data']
         if (self.pipeline == 'fused' and self.use_graph and self.graph_slots >= 2 and self.taps is None and not ops.PROFILE['enabled']
                 and x.is_cuda and not torch.is_grad_enabled()):
-            ent = self._phase1_graphed(x, data['im_info'])
+            ent = self._phase1_graphed(x, data['im_info'], wait=False)
             if ent is not None and ent['host'] is not None:
-                ent['host'].copy_(ent['out']['tail']['counters'], non_blocking=True)
-                ent['done'].record()
+                with torch.cuda.stream(ent['stream']):
+                    ent['host'].copy_(ent['out']['tail']['counters'], non_blocking=True)
+                    ent['done'].record()
                 return _Pending(self, data, ent)
+            if ent is not None:
+                torch.cuda.current_stream().wait_stream(ent['stream'])
             return _Pending(self, data, None, self._forward_fused(data, st=None if ent is None else ent['out'], try_graph=False))
         return _Pending(self, data, None, self.forward(data))
 
@@ -279,7 +282,7 @@ class resnet_upsnet(resnet_rcnn):
                     pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
                     mask_det=mask_det, max_det=max_det, _events=(ev_fork, ev_join))
 
-    def _phase1_graphed(self, x, im_info_host):
+    def _phase1_graphed(self, x, im_info_host, wait=True):
         """HIP-graph replay of _phase1 for this input shape / im_info: the ~150 launches of the trunk, the semantic head (side
         stream) and the proposal / detection chain cost one hipGraphLaunch on the host. graph_slots instances per shape are used
         in turn; for each, the first two images run eagerly (weight packing, function attributes, library handles), the third is
@@ -298,12 +301,13 @@ class resnet_upsnet(resnet_rcnn):
             static_im = torch.from_numpy(np.asarray(im_info_host, dtype=np.float32).reshape(-1)[:3].copy()).to(x.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            sk = torch.cuda.Stream(device=x.device) if self.graph_slots >= 2 else None
             gc_was_on = gc.isenabled()
             gc.disable()   # a collection in the middle of the capture could release device objects (illegal while capturing)
             try:
                 # (thread_local: other threads of the process -- e.g. the RCCL watchdog of torch.distributed -- may call the runtime
                 # while this thread captures)
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                with torch.cuda.graph(g, stream=sk, capture_error_mode='thread_local'):
                     out = self._phase1(static_x, static_im, tail=True)
             except Exception as e:   # capture not possible on this stack: stay eager, say so once
                 import warnings
@@ -315,9 +319,22 @@ class resnet_upsnet(resnet_rcnn):
                     gc.enable()
             host = torch.empty((4,), dtype=out['tail']['counters'].dtype).pin_memory() if out.get('tail') is not None else None
             # (the graph reads both static inputs by address)
-            ent.update(graph=g, x=static_x, im_info=static_im, out=out, host=host, done=torch.cuda.Event())
-        ent['x'].copy_(x)
-        ent['graph'].replay()
+            ent.update(graph=g, x=static_x, im_info=static_im, out=out, host=host, done=torch.cuda.Event(), stream=sk)
+        # Each instance lives on its own stream (captured and replayed there): two images in flight then really overlap on the
+        # device -- the kernels of one fill the tail rounds, the small layers and the latency-bound chain of the other (7.6 vs
+        # 8.2 ms per image, tools/two_stream_probe.py). Every buffer a graph writes comes from its own capture pool, so
+        # concurrent replays of different instances share read-only data only (weights, anchors, class map).
+        sk, cur = ent['stream'], torch.cuda.current_stream()
+        if sk is None:
+            ent['x'].copy_(x)
+            ent['graph'].replay()
+            return ent
+        sk.wait_stream(cur)   # x is ready, and whatever still reads this instance's previous outputs on `cur` is done
+        with torch.cuda.stream(sk):
+            ent['x'].copy_(x)
+            ent['graph'].replay()
+        if wait:   # the synchronous forward() continues on the caller's stream
+            cur.wait_stream(sk)
         return ent   # (ent['out']: the device tensors the graph writes; no reference from them back to ent -- a cycle would leave
                      # the release of a dropped graph to the garbage collector, which may run in the middle of a later capture)
 

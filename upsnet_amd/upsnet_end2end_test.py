@@ -140,10 +140,15 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
             dist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        # Two images in flight per rank: image i+1 is launched (one graph replay) before image i's outputs are read back, so the
-        # host work between two images -- read-back, Python, the next launch -- overlaps with the device. Every image is fully
-        # processed inside the timed region; net_time = interval between two completed images.
-        def finish(s, i, handle):
+        # `in_flight` images per rank: image i+1 is launched (one graph replay on that graph instance's own stream) before image
+        # i's outputs are read back, so (a) the host work between two images -- read-back, Python, the next launch -- is off the
+        # device's critical path and (b) the kernels of the two images overlap on the device (tail rounds, small layers and the
+        # latency-bound detection chain of one are filled by the other). Every image is fully processed inside the timed region.
+        # net_time = (completion of image i+d) - (completion of image i), divided by d = in_flight: the steady-state time per
+        # image; lat_time = launch -> outputs on the host side.
+        done_at, lat = [], []
+
+        def finish(s, i, handle, t_launch):
             out = handle.result() if hasattr(handle, 'result') else handle
             if post:
                 out['pan_2ch'] = post_fn([out['fcn_outputs']], [out['panoptic_outputs']], [out['panoptic_cls_inds']])[0]
@@ -154,25 +159,26 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
             outs.append((i, lab, int(out['panoptic_cls_inds'].numel())))
             if on_step is not None:
                 on_step(s, out, model)
-            net_timer.toc()
-            net_timer.tic()
+            if in_flight <= 1:
+                torch.cuda.synchronize(device)
+            now = time.perf_counter()
+            done_at.append(now)
+            lat.append(now - t_launch)
             return out
 
-        launch = model.forward_async if in_flight > 1 and hasattr(model, 'forward_async') else model
-        pending = None
-        net_timer.tic()
+        depth = max(1, min(int(in_flight), getattr(model, 'graph_slots', 1))) if hasattr(model, 'forward_async') else 1
+        launch = model.forward_async if depth > 1 else model
+        pending = []
+        done_at.append(time.perf_counter())
         for s, i in enumerate(my_ids):
             if before_step is not None:
                 before_step(s, model)
-            handle = launch(get(i))
-            if pending is not None:
-                out = finish(*pending)
-            pending = (s, i, handle)
-            if in_flight <= 1:
-                out = finish(*pending)
-                pending = None
-        if pending is not None:
-            out = finish(*pending)
+            pending.append((s, i, launch(get(i)), time.perf_counter()))
+            if len(pending) >= depth:
+                out = finish(*pending.pop(0))
+        while pending:
+            out = finish(*pending.pop(0))
+        net_timer.samples = [(done_at[k + depth] - done_at[k]) / depth for k in range(len(done_at) - depth)]
         results = gather_results(outs, world, device) if gather else None
         torch.cuda.synchronize(device)
         if world > 1:
@@ -182,5 +188,5 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return dict(rank=rank, world=world, elapsed=float(t.item()), net_times=list(net_timer.samples), results=results,
+    return dict(rank=rank, world=world, elapsed=float(t.item()), net_times=list(net_timer.samples), latencies=list(lat), results=results,
                 last_out=out, model=model, image=get(my_ids[-1]), H=H, W=W)
