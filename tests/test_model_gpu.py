@@ -222,6 +222,17 @@ def test_hip_graph_replay_equals_eager(setup):
                 for k in keys:
                     assert torch.equal(out[k], eager[pending[0]][k]), ('async', step, pending[0], k)
             pending = nxt
+        # a longer run of overlapping replays of both instances of one shape
+        pending = None
+        for step in range(25):
+            j = step % 3
+            nxt = (j, model.forward_async(imgs[j]))
+            if pending is not None:
+                out = pending[1].result()
+                assert torch.equal(out['panoptic_outputs'], eager[pending[0]]['panoptic_outputs']), ('stress', step)
+                assert torch.equal(out['mask_probs'], eager[pending[0]]['mask_probs']), ('stress', step)
+            pending = nxt
+        pending[1].result()
     model._graphs.clear()
     model.graph_slots = 2
 
