@@ -1,11 +1,13 @@
 // conv_wino.hip -- Winograd F(2x2, 3x3) convolution, fp32 MFMA, NHWC, all 16 transform-domain accumulators resident.
 //
 // Replaces the 3x3 / stride 1 / pad 1 nn.Conv2d (+ folded BN, bias, residual, ReLU) layers of the reference's ResNet-FPN
-// (upsnet/models/resnet.py:64-77, fpn.py:60-98, rpn.py:34-47) where the feature map is large enough to fill the chip.
+// (upsnet/models/resnet.py:64-77, fpn.py:60-98, rpn.py:34-47), of the mask head (rcnn.py:96-116) and the offset convolutions of
+// the deformable FCN head (fcn.py:33-60) where the feature map has enough 2x2 tiles (models/hipconv.py decides by shape).
 //
 // GEMM view: a row is one 2x2 OUTPUT TILE (its 4x4 input patch d), a column one output channel; for each of the 16 positions
 // xi = (i, j) of the transformed domain M_xi = V_xi x U_xi with V = B^T d B (input transform) and U = G g G^T (weights, packed
-// once). A workgroup (8 waves, two per SIMD) owns 64 tiles x 64 channels and keeps ALL 16 M_xi accumulators in registers:
+// once). In the base form a workgroup (8 waves, two per SIMD) owns 64 tiles x 64 channels and keeps ALL 16 M_xi accumulators in
+// registers (the 32-tile / 32-channel forms are described at the kernel template):
 // wave (pair, xh) holds the 32x32 block `pair` of the eight M_xi with xi in [8 xh, 8 xh + 8) = 128 accumulator registers, so
 //   * the K walk over the input channels happens ONCE: every input pixel of the patch is loaded once per slab and transformed
 //     once (the earlier form walked K once per xi and gathered four signed pixels per A element: 4x the loads, 16x the walks),
@@ -20,7 +22,7 @@
 // lane l supplies A[row l%32][k l/32], so a float4 fragment feeds four MFMAs (lanes < 32 walk quarter 2h, lanes >= 32 quarter
 // 2h+1). The B operand (U) does not go through LDS: it is packed as [n-tile][slab][xi][q][64 channels][4] so that a lane's
 // fragment is one 16-byte load, contiguous across the wave (1 KiB), prefetched in a register ring.
-// LDS: 2 buffers x 64 KiB (double-buffered V). One workgroup per CU.
+// LDS: 2 buffers x 64 KiB (double-buffered V), one workgroup per CU; the 32-tile forms: 2 x 32 KiB, two workgroups per CU.
 #include "conv_params.h"
 #include "upsnet_hip.h"
 
