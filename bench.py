@@ -33,7 +33,7 @@ PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='upsnet50_cityscapes_1024x2048')
     ap.add_argument('--no-cpu-baseline', action='store_true')
