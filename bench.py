@@ -30,6 +30,36 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the same guide)
 
 
+def ensure_ranks(args):
+    """`--gpus N` means N ranks, one per GPU. Started plainly (no WORLD_SIZE in the environment) with N > 1, re-exec this very
+    command line under torch.distributed.run; started by a launcher, require that its world size IS N. Never measure fewer
+    GPUs than the line will claim."""
+    n = args.gpus
+    if n < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    share = os.environ.get('UPSNET_SHARE_GPU', '0') == '1'   # ranks share a GPU: functional check of the N>1 path on a 1-GPU box
+    if 'WORLD_SIZE' in os.environ:
+        world = int(os.environ['WORLD_SIZE'])
+        if world != n:
+            sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (n, world))
+    if n > 1 or 'WORLD_SIZE' in os.environ:
+        have = torch.cuda.device_count()
+        if have < n and not share:
+            sys.exit('bench.py: --gpus %d but only %d GPU(s) visible (UPSNET_SHARE_GPU=1 runs the ranks on shared GPUs, for testing only)' % (n, have))
+    if n > 1 and 'WORLD_SIZE' not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '8')
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -47,8 +77,9 @@ def main():
                          "1: strictly one image after the other)")
     ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
-                    help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048)')
+                    help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048: 1 warm-up + 3 timed passes, ~35 s)')
     args = ap.parse_args()
+    ensure_ranks(args)
 
     from upsnet_amd import ops
     from upsnet_amd.models import hipconv
@@ -112,33 +143,46 @@ def main():
     n_c, t_c, f_c, b_c = agg('conv')
     n_d, t_d, f_d, b_d = agg('dcn_fused')
     if n_c and t_c > 0:
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r05_conv_pmc.json')  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
-        if os.path.exists(pmc):
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_round.sh -> tools/rocpd_pmc.py); it is
+        # reported here only when that profile was taken from THIS build (source hash recorded in the json), else null
+        traffic, traffic_src = None, None
+        from upsnet_amd import build as _b
+        cur = _b._source_hash()
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_conv_pmc.json')), reverse=True):
             try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                j = json.load(open(os.path.join(ROOT, 'profiles', name)))
             except Exception:
-                traffic = None
-        achieved = f_c / t_c / 1e12
-        # Winograd launches execute 16/36 of their algorithmic (direct-form) multiplies: `achieved` / `frac` follow the contract
-        # (algorithmic flops / time), `executed` is what the MFMA pipe really did, against the same peak
+                continue
+            if j.get('srchash') == cur:
+                traffic, traffic_src = j.get('hbm_bytes_per_launch'), 'profiles/' + name
+                break
+        alg = f_c / t_c / 1e12
+        # Winograd launches issue 16/36 of the multiplies of the direct form. `achieved` / `frac` = what the MFMA pipe really
+        # executed against its peak (the honest utilisation); `achieved_algorithmic` / `frac_algorithmic` = direct-form flops
+        #  / time, which exceeds the executed figure exactly by the Winograd saving.
         n_w, t_w, f_w, _ = agg('conv', 'winograd')
         f_exec = f_c - f_w * (1.0 - 16.0 / 36.0)
+        ex = f_exec / t_c / 1e12
         roofline = {'kernel': 'dense convolution family: conv_igemm_f32_kernel (direct, csrc/conv.hip) + conv_wino16_f32_kernel '
                               '(Winograd F(2x2,3x3), csrc/conv_wino.hip)', 'bound': 'mfma',
-                    'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'achieved': round(ex, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'achieved_algorithmic': round(alg, 3), 'frac_algorithmic': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'note': 'achieved/frac = MFMA flops actually issued (Winograd launches at 16/36 of their direct-form flops) / time; '
+                            '*_algorithmic = direct-form flops of SURVEY 8d / time',
+                    'traffic': traffic, 'traffic_source': traffic_src or 'none for this build (rocprofv3 --pmc passes: tools/profile_round.sh)',
                     'launches_timed': n_c, 'images_sampled': n_sampled, 'launches_per_image': n_c // n_sampled,
                     'avg_launch_ms': round(1000.0 * t_c / n_c, 4), 'ms_per_image': round(1000.0 * t_c / n_sampled, 3),
-                    'algorithmic_flops_per_launch': f_c / n_c, 'algorithmic_bytes_per_launch': b_c / n_c,
+                    'algorithmic_flops_per_launch': f_c / n_c, 'executed_flops_per_launch': f_exec / n_c,
+                    'algorithmic_bytes_per_launch': b_c / n_c,
                     'hbm_equiv_GBs': round(b_c / t_c / 1e9, 1),
-                    'executed': {'achieved': round(f_exec / t_c / 1e12, 3), 'frac': round(f_exec / t_c / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 'note': 'MFMA flops actually issued (Winograd launches counted at 16/36 of their direct-form flops)'},
                     'winograd': {'launches_timed': n_w, 'ms_per_image': round(1000.0 * t_w / n_sampled, 3),
                                  'achieved_algorithmic': round(f_w / max(t_w, 1e-9) / 1e12, 3),
-                                 'achieved_executed': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12, 3)},
+                                 'achieved': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12, 3),
+                                 'frac': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
                     'direct': {'launches_timed': n_c - n_w, 'ms_per_image': round(1000.0 * (t_c - t_w) / n_sampled, 3),
-                               'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3)}}
+                               'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3),
+                               'frac': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
         if n_d and t_d > 0:
             roofline['deformable'] = {'kernel': 'conv_igemm_f32_kernel (deformable instances = fused DCN v1)', 'bound': 'mfma',
                                       'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -160,15 +204,21 @@ def main():
         h, w = int(H * sc) // 32 * 32, int(W * sc) // 32 * 32
         m_cpu = cpu_copy(res['model'])
         img = make_image(h, w, seed=0, device='cpu')
-        stages = {}
-        t0 = time.perf_counter()
-        out_cpu = forward_cpu(m_cpu, img, stages)
-        dt = time.perf_counter() - t0
+        # 1 warm-up + 3 timed passes; the median is reported
+        forward_cpu(m_cpu, img, {})
+        times, stages = [], {}
+        for _ in range(3):
+            stages = {}
+            t0 = time.perf_counter()
+            out_cpu = forward_cpu(m_cpu, img, stages)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[1]
         # scale the sample's time to a full-size image by pixel count (all heavy stages are O(pixels))
         full = dt * (H * W) / float(h * w)
         cpu_baseline = {'value': round(1.0 / full, 5), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-                        'sample': '1 image %dx%d (%.2fx linear scale of the workload; scaled by pixel count if < 1) in %.1f s; '
-                                  'torch-CPU convs on %d threads (host has %d) + single-thread C oracle ops' % (h, w, sc, dt, cores, os.cpu_count()),
+                        'sample': '1 warm-up + 3 timed passes over 1 image %dx%d (%.2fx linear scale of the workload; scaled by pixel count '
+                                  'if < 1), median %.2f s (%s); torch-CPU convs on %d threads (host has %d) + single-thread C oracle ops'
+                                  % (h, w, sc, dt, ' / '.join('%.2f' % t for t in times), cores, os.cpu_count()),
                         'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
                         'n_inst': out_cpu['n_inst']}
 
@@ -182,6 +232,18 @@ def main():
         chk = model(res['image'])
     model.use_graph, model.overlap_streams = g, o
     same = bool(torch.equal(chk['panoptic_outputs'], last['panoptic_outputs']) and torch.equal(chk['pred_boxes'], last['pred_boxes']))
+    # the reference's strictly serial net_time window (forward + device sync per image, upsnet_end2end_test.py:244-252), measured
+    # after the timed region on the same model: p50 over 20 images
+    serial = []
+    with torch.no_grad():
+        for k in range(24):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model(res['image'])
+            torch.cuda.synchronize()
+            if k >= 4:
+                serial.append(time.perf_counter() - t0)
+    serial_ms = 1000.0 * sorted(serial)[len(serial) // 2]
     agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
     if agree < 0.99 or chk['pred_boxes'].shape != last['pred_boxes'].shape:   # (bit-identical in practice; the FC GEMMs are a library)
         raise RuntimeError("bench: the timed run's outputs differ from an eager re-run of the same image (label agreement %.4f)" % agree)
@@ -191,7 +253,7 @@ def main():
                                                    'upsnet101dcn_mixed_1024x2048_800x1333': 'UPSNet-101-DCN mixed 1024x2048 / 800x1333 stream'}.get(args.workload, args.workload),
         'value': round(value, 4), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
-        'ms_per_img_p50': round(p50_ms, 3), 'latency_ms_p50': round(lat_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_img_p50': round(p50_ms, 3), 'ms_per_img_serial': round(serial_ms, 3), 'latency_ms_p50': round(lat_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (3-term bf16 split of fp32 operands, fp32 accumulate; dense convs only)',
                   'bf16': 'bf16 (dense convs: bf16 products, fp32 accumulate; rest f32)'}[args.conv_precision], 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
@@ -203,7 +265,7 @@ def main():
                                   '(csrc/conv_wino.hip, split-K below 160 workgroups); max-pool + FC GEMMs on PyTorch-ROCm',
                    'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
-                   'parallelism': 'one image per rank, final RCCL all_gather',
+                   'parallelism': 'one image per rank (image i -> rank i mod N), one final RCCL gather of the label maps to rank 0', 'ranks': world,
                    'streams': 'whole forward (trunk, semantic head + mask head on a side stream concurrent with the proposal/detection '
                               'chain, panoptic tail) replayed as one HIP graph per image; %d image(s) in flight per rank, each graph instance '
                               'on its own stream (the images overlap on the device; ms_per_img_p50 = steady-state time per image, '

@@ -18,7 +18,12 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world) and dist.get_backend() == 'gloo'
     ids = shard_indices(7, rank, world)           # uneven: rank 0 gets 4 images, rank 1 gets 3
     local = [(i, torch.full((6, 10), i, dtype=torch.uint8), 10 + i) for i in ids]
-    out = gather_results(local, world, dev)
+    out = gather_results(local, world, dev, 6, 10)
+    if rank != 0:
+        assert out is None                       # gather to rank 0 ONLY (reference: outputs are collected on the first device)
+        out = {}
+    empty = gather_results([] if rank == 1 else local[:1], world, dev, 6, 10)   # a rank without images must not break the collective
+    assert rank != 0 or sorted(empty) == [0]
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)     # max-over-ranks timing reduction used by the bench
     q.put((rank, sorted(out.keys()), [int(out[i][0][0, 0]) for i in sorted(out)], [out[i][1] for i in sorted(out)], float(t)))
@@ -38,7 +43,10 @@ def test_two_rank_shard_and_gather():
         p.join(60)
         assert p.exitcode == 0
     for rank, keys, vals, ninst, tmax in res:
-        assert keys == list(range(7)) and vals == list(range(7)) and ninst == [10 + i for i in range(7)]
+        if rank == 0:
+            assert keys == list(range(7)) and vals == list(range(7)) and ninst == [10 + i for i in range(7)]
+        else:
+            assert keys == []
         assert tmax == 2.0
 
 
@@ -48,3 +56,16 @@ def test_shard_indices_cover_exactly_once():
         for n in (0, 1, 7, 64):
             got = sorted(sum([shard_indices(n, r, world) for r in range(world)], []))
             assert got == list(range(n))
+
+
+def test_bench_refuses_to_misreport_gpu_count():
+    """`bench.py --gpus N` must run N ranks or fail loudly (round-1 bug: the flag was parsed and ignored)."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and 'only' in r.stderr
+    env['WORLD_SIZE'] = '4'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr

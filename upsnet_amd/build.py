@@ -5,6 +5,7 @@
 hipcc cross-compiles for gfx950 without a GPU. The selection / sampling kernels must reproduce fp32
 decisions bit-for-bit, hence -ffp-contract=off (no FMA contraction).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,17 +14,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libupsnet_hip.so")
+STAMP = LIB + ".srchash"   # git-ignored, travels with the .so
 SOURCES = ["capi.cpp", "roi_align.hip", "nms.hip", "deform_conv.hip", "backward.hip", "conv.hip", "conv_wino.hip", "conv_bf16.hip", "proposal.hip", "detect.hip", "panoptic.hip", "fcn_head.hip", "preprocess.hip", "postprocess.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+def _source_hash():
+    """sha1 over the compile flags and every source / header the library is built from (mtimes are not trusted: a shipped
+    .so and a checked-out source can carry the same timestamp)."""
+    h = hashlib.sha1(" ".join(FLAGS + SOURCES).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
     deps.append(os.path.join(INCLUDE, "upsnet_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale():
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=True):
@@ -46,6 +59,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 

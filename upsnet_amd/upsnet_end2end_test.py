@@ -7,7 +7,7 @@ upsnet_end2end_test.py:244-252) and leaves the outputs on their GPUs.
 
 Here: one PROCESS per GPU (torchrun), weights built/loaded once per rank, image i goes to rank
 i mod world_size (independent units, no data-path collective), the same net_time window per image, and
-ONE RCCL all_gather of the small per-image results (uint8 label maps + counters) after the loop.
+ONE RCCL gather of the small per-image results (uint8 label maps + counters) to rank 0 after the loop.
 Datasets, cv2 post-processing and PQ evaluation are out of scope (SURVEY.md section 2, rows 11-12);
 inputs are the synthetic images of upsnet_amd.synthetic.
 """
@@ -38,7 +38,12 @@ def init_distributed():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
-        local = local % torch.cuda.device_count()  # (several ranks may share a GPU in single-GPU smoke runs)
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            # one rank per GPU is the contract; several ranks on one GPU only on request (single-GPU smoke runs of the N>1 path)
+            if os.environ.get('UPSNET_SHARE_GPU', '0') != '1':
+                raise RuntimeError('LOCAL_RANK %d but only %d GPU(s) visible (set UPSNET_SHARE_GPU=1 to let ranks share a GPU)' % (local, ndev))
+            local = local % ndev
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -53,33 +58,63 @@ def shard_indices(num_images, rank, world):
     return list(range(rank, num_images, world))
 
 
-def gather_results(local, world, device):
-    """One all_gather of fixed-size per-image records: local = list of (image_id, label_map uint8 [H,W], n_inst).
-    Returns on every rank a dict image_id -> (label_map, n_inst). Ranks may hold different counts: pad."""
+_REC_HDR = 16   # bytes in front of every label map: image id, instance count (2 x int64, little endian)
+
+
+def pack_records(local, H, W, device):
+    """[(image_id, label_map uint8 [h<=H, w<=W], n_inst)] -> one uint8 tensor [n, 16 + H*W] (header + row-major label map)."""
+    rec = torch.zeros((len(local), _REC_HDR + H * W), dtype=torch.uint8, device=device)
+    if local:
+        hdr = torch.tensor([[i, n] for i, _, n in local], dtype=torch.int64).view(torch.uint8).view(len(local), _REC_HDR)
+        rec[:, :_REC_HDR] = hdr.to(device)
+    for j, (_, lab, _) in enumerate(local):
+        assert lab.dtype == torch.uint8 and lab.shape[0] <= H and lab.shape[1] <= W
+        rec[j, _REC_HDR:].view(H, W)[:lab.shape[0], :lab.shape[1]] = lab.to(device)
+    return rec
+
+
+def unpack_records(rec, H, W):
+    out = {}
+    if rec.shape[0]:
+        hdr = rec[:, :_REC_HDR].cpu().reshape(-1).clone().view(torch.int64).view(-1, 2)
+        for j in range(rec.shape[0]):
+            out[int(hdr[j, 0])] = (rec[j, _REC_HDR:].view(H, W), int(hdr[j, 1]))
+    return out
+
+
+def gather_results(local, world, device, H=None, W=None, dst=0):
+    """The path's only collective (upsnet_end2end_test.py:224-247 leaves the outputs on their GPUs and the host collects them;
+    data_parallel.py:103-116 gathers to the first device): every rank sends its per-image records -- local = list of
+    (image_id, label_map uint8, n_inst) -- to rank `dst` ONLY. Returns a dict image_id -> (label_map [H,W], n_inst) on rank
+    `dst` and None elsewhere. H, W = record shape (the workload's padded size; defaults to the first local map).
+    One gather of the 8-byte record counts, then one gather of the payload (ranks with fewer records pad to the largest count:
+    with image i on rank i mod world the counts differ by at most one)."""
+    if H is None or W is None:
+        assert local, 'gather_results: give H, W when a rank may hold no image'
+        H, W = local[0][1].shape
     if world == 1:
-        return {i: (lab, n) for i, lab, n in local}
+        return unpack_records(pack_records(local, H, W, device), H, W)
     if dist.get_backend() == 'gloo':
         device = torch.device('cpu')
-    counts = torch.tensor([len(local)], dtype=torch.int64, device=device)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    mx = int(max(c.item() for c in all_counts))
-    H, W = local[0][1].shape if local else (1, 1)
-    labs = torch.zeros((mx, H, W), dtype=torch.uint8, device=device)
-    meta = torch.full((mx, 2), -1, dtype=torch.int64, device=device)
-    for j, (i, lab, n) in enumerate(local):
-        labs[j] = lab.to(device)
-        meta[j, 0], meta[j, 1] = i, n
-    g_labs = [torch.zeros_like(labs) for _ in range(world)]
-    g_meta = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(g_labs, labs)
-    dist.all_gather(g_meta, meta)
+    rank = dist.get_rank()
+    count = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(count) for _ in range(world)] if rank == dst else None
+    dist.gather(count, counts, dst=dst)
+    # every rank needs the padded row count; it follows from the sharding rule without another collective only if the caller
+    # sharded by i mod world -- do not assume it: broadcast the maximum (8 bytes)
+    mx = torch.tensor([max(int(c) for c in counts)] if rank == dst else [0], dtype=torch.int64, device=device)
+    dist.broadcast(mx, src=dst)
+    mx = int(mx)
+    rec = pack_records(local, H, W, device)
+    if rec.shape[0] < mx:
+        rec = torch.cat([rec, rec.new_zeros((mx - rec.shape[0], rec.shape[1]))], 0)
+    recv = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+    dist.gather(rec, recv, dst=dst)
+    if rank != dst:
+        return None
     out = {}
     for r in range(world):
-        for j in range(mx):
-            i = int(g_meta[r][j, 0])
-            if i >= 0:
-                out[i] = (g_labs[r][j], int(g_meta[r][j, 1]))
+        out.update(unpack_records(recv[r][:int(counts[r])], H, W))
     return out
 
 
@@ -96,6 +131,7 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
     sizes = list(zip(H, W)) if isinstance(H, (tuple, list)) else [(H, W)]
     H, W = max(h for h, _ in sizes), max(w for _, w in sizes)   # (label maps are padded to the largest size for the gather)
     update_config_dict(preset)
+    hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))   # record shape of the final gather (inputs are padded to 32)
     model = build_model(cls_gain=gain, device=device, pipeline=pipeline)
     # each rank owns its images: image id = step * world + rank, seeded by id
     my_ids = [s * world + rank for s in range(steps)]
@@ -129,9 +165,8 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         if world > 1 and gather:
             # warm the communicator with a gather of the final shape (RCCL sets up its channels / buffers on first use of a
             # collective at a given size; that one-off cost belongs to start-up, not to the timed loop)
-            hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))
             dummy = [(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0) for j in range(steps)]
-            gather_results(dummy, world, device)
+            gather_results(dummy, world, device, hp, wp)
             del dummy
             torch.cuda.synchronize(device)
         if on_warmup_done is not None:
@@ -154,7 +189,6 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
                 out['pan_2ch'] = post_fn([out['fcn_outputs']], [out['panoptic_outputs']], [out['panoptic_cls_inds']])[0]
             lab = out['panoptic_outputs'][0].to(torch.uint8)
             if len(sizes) > 1:  # mixed stream: common shape for the gather (255 = void outside the image)
-                hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))
                 lab = torch.nn.functional.pad(lab, (0, wp - lab.shape[1], 0, hp - lab.shape[0]), value=255)
             outs.append((i, lab, int(out['panoptic_cls_inds'].numel())))
             if on_step is not None:
@@ -179,7 +213,7 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         while pending:
             out = finish(*pending.pop(0))
         net_timer.samples = [(done_at[k + depth] - done_at[k]) / depth for k in range(len(done_at) - depth)]
-        results = gather_results(outs, world, device) if gather else None
+        results = gather_results(outs, world, device, hp, wp) if gather else None   # rank 0 only; None elsewhere
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
