@@ -249,10 +249,24 @@ int upsnet_nms_batched(void *stream, const float *boxes, const float *scores, co
                        const uint8_t *pre_removed, int num_problems, int nmax, float thresh, int *keep_idx,
                        int *keep_cnt, void *workspace);
 
-/* Device soft-NMS, bit-compatible with cpu_soft_nms (upsnet/nms/cpu_nms.pyx:91-196) on the returned
- * prefix: boxes [n,5] modified in place (rows >= *n_out unspecified), inds [n] int64 out (original
- * index of each surviving row), n_out device int32. workspace: upsnet_soft_nms_workspace_bytes(n).
- * method: 0 hard, 1 linear, 2 gaussian. */
+/* cpu_nms (upsnet/nms/cpu_nms.pyx:29-80, behind cpu_nms_wrapper, upsnet/nms/nms.py:37-40) on the device: same layout, visiting
+ * order and IoU expression as upsnet_nms_batched, but suppression at `overlap >= thresh` (:77) with `thresh` a double (a Python
+ * float in the reference's compiled module; the fp32 overlap is compared in double). */
+int upsnet_cpu_nms_batched(void *stream, const float *boxes, const float *scores, const int *counts, int num_problems,
+                           int nmax, double thresh, int *keep_idx, int *keep_cnt, void *workspace);
+
+/* Batched device soft-NMS = cpu_soft_nms (upsnet/nms/cpu_nms.pyx:91-196), P independent problems (RPN levels / classes) per
+ * launch, one workgroup each, state resident in LDS for nmax <= 4096. Bit-compatible with the compiled reference on the
+ * returned prefix (pinned: tests/test_ref_cpu_nms.py):
+ *   boxes [P,nmax,5] in/out (x1,y1,x2,y2,score; rows >= n_out[p] unspecified), inds [P,nmax] int64 out (original index of each
+ *   surviving row), counts [P] device int32 (valid rows per problem; NULL = nmax everywhere), n_out [P] device int32.
+ *   method: 0 hard, 1 linear, 2 gaussian. workspace: upsnet_soft_nms_batched_workspace_bytes(P, nmax) (may be NULL when
+ *   nmax <= 4096). */
+size_t upsnet_soft_nms_batched_workspace_bytes(int num_problems, int nmax);
+int upsnet_soft_nms_batched(void *stream, float *boxes, int64_t *inds, const int *counts, int num_problems, int nmax,
+                            float sigma, float Nt, float threshold, int method, int *n_out, void *workspace);
+
+/* Single problem: upsnet_soft_nms_batched with P = 1 and all n rows valid. */
 size_t upsnet_soft_nms_workspace_bytes(int n);
 int upsnet_soft_nms(void *stream, float *boxes, int64_t *inds, int n, float sigma, float Nt, float threshold,
                     int method, int *n_out, void *workspace);

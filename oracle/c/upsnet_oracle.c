@@ -335,6 +335,24 @@ int orc_nms_sorted(const float *boxes, int n, int box_dim, float thresh, int *ke
     return num;
 }
 
+/* cpu_nms (upsnet/nms/cpu_nms.pyx:29-80) on score-sorted boxes: same IoU expression (areas precomputed, :39; inter / (iarea +
+ * areas[j] - inter), :76), but suppression at ">=" and against the PYTHON float threshold, i.e. the fp32 overlap is compared
+ * in double (:77, `np.float thresh` is a Python object in the compiled module). */
+int orc_cpu_nms_sorted(const float *boxes, int n, int box_dim, double thresh, int *keep_out)
+{
+    uint8_t *removed = (uint8_t *)calloc(n > 0 ? n : 1, 1);
+    int num = 0;
+    for (int i = 0; i < n; ++i) {
+        if (removed[i]) continue;
+        keep_out[num++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (!removed[j] && (double)orc_iou(boxes + (size_t)i * box_dim, boxes + (size_t)j * box_dim) >= thresh)
+                removed[j] = 1;
+    }
+    free(removed);
+    return num;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Soft-NMS: upsnet/nms/cpu_nms.pyx:91-196 (cdef float arithmetic; gaussian weight through a
  * double exp, :170).  boxes [N,5] is modified in place, inds[N] must hold 0..N-1 on entry.
@@ -362,15 +380,19 @@ int orc_soft_nms(float *boxes, int64_t *inds, int n, float sigma, float Nt, floa
         while (pos < N) {
             float x1 = boxes[pos * 5 + 0], y1 = boxes[pos * 5 + 1], x2 = boxes[pos * 5 + 2],
                   y2 = boxes[pos * 5 + 3];
-            float area = (x2 - x1 + 1) * (y2 - y1 + 1);
-            float iw = (fminf(tx2, x2) - fmaxf(tx1, x1) + 1);
+            /* Cython coerces the integer literal in `x2 - x1 + 1` (cdef float operands, :155-163) to the C constant 1.0, a
+             * DOUBLE: the float difference is widened, the two-factor products and the union are evaluated in double and
+             * rounded to float once on assignment. Found by pinning against the compiled reference (tests/test_ref_cpu_nms.py);
+             * a pure-fp32 restatement is off by an ulp in `area` / `ua` and hence in the linear / gaussian scores. */
+            float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+            float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);
             if (iw > 0) {
-                float ih = (fminf(ty2, y2) - fmaxf(ty1, y1) + 1);
+                float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);
                 if (ih > 0) {
-                    float ua = (float)((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih);
+                    float ua = (float)(((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0)) + (double)area) - (double)(iw * ih));
                     float ov = iw * ih / ua;
                     float weight;
-                    if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+                    if (method == 1) weight = ov > Nt ? (float)(1.0 - (double)ov) : 1;
                     else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
                     else weight = ov > Nt ? 0 : 1;
                     boxes[pos * 5 + 4] = weight * boxes[pos * 5 + 4];

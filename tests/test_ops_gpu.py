@@ -191,6 +191,46 @@ def test_soft_nms_bitexact(U, method, n):
     assert np.array_equal(gb.cpu().numpy()[:len(ri)], rb[:len(ri)])
 
 
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("nmax,P", [(1000, 5), (64, 3), (1025, 2), (4096, 2), (4100, 2)])
+def test_soft_nms_batched_bitexact(U, method, nmax, P):
+    """P problems per launch (RPN levels / classes), ragged counts incl. empty: 1 wavefront (<= 1024 boxes), 4 wavefronts
+    (<= 4096, LDS) and the global-memory form (> 4096). The oracle is pinned to the compiled reference (test_ref_cpu_nms.py)."""
+    rng = np.random.default_rng(7 * nmax + method)
+    counts = [nmax] + [int(c) for c in rng.integers(0, nmax + 1, P - 1)]
+    counts[-1] = 0 if P > 2 else counts[-1]
+    boxes = np.zeros((P, nmax, 5), np.float32)
+    for p, c in enumerate(counts):
+        if c:
+            boxes[p, :c] = gen_dets(rng, c, ties=(p % 2 == 0))
+    thr = 0.001 if method else 0.05
+    gb, gi, gn = U.soft_nms_batched(cu(boxes), cu(np.array(counts, np.int32)), 0.5, 0.3, thr, method)
+    gb, gi, gn = gb.cpu().numpy(), gi.cpu().numpy(), gn.cpu().numpy()
+    for p, c in enumerate(counts):
+        rb, ri = oracle.soft_nms(boxes[p, :c], 0.5, 0.3, thr, method)
+        assert gn[p] == len(ri), (p, c)
+        assert np.array_equal(gi[p, :gn[p]], ri)
+        assert np.array_equal(gb[p, :gn[p]].view(np.uint32), rb[:len(ri)].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 3000])
+@pytest.mark.parametrize("thresh", [0.3, 0.7])
+def test_cpu_nms_ge_bitexact(U, n, thresh):
+    """cpu_nms_wrapper semantics (cpu_nms.pyx:77, `>=` against a double threshold) on the device vs the oracle restatement, which
+    is pinned to the compiled reference on CPU. Includes pairs whose overlap equals the threshold exactly."""
+    from upsnet_amd.nms.nms import cpu_nms_wrapper, py_nms_wrapper
+    rng = np.random.default_rng(n)
+    d = gen_dets(rng, n, ties=False)
+    d[:, 4] = (rng.permutation(n).astype(np.float32) + 1) / (n + 1)
+    order = np.argsort(d[:, 4], kind='stable')[::-1]
+    assert cpu_nms_wrapper(thresh)(d) == oracle.cpu_nms(d, thresh, order)
+    assert py_nms_wrapper(thresh)(d) == [int(order[k]) for k in oracle.nms_sorted(d[order], thresh)]
+    a = np.array([[0, 0, 9, 9, 0.9], [0, 5, 9, 14, 0.8]], np.float32)
+    t = float(np.float32(50.0) / np.float32(150.0))
+    assert cpu_nms_wrapper(t)(a) == [0] and py_nms_wrapper(t)(a) == [0, 1]
+    assert cpu_nms_wrapper(float(np.nextafter(t, 1.0)))(a) == [0, 1]
+
+
 # ------------------------------------------------------------------ proposals
 def _rpn_inputs(rng, H, W, strides=(4, 8, 16, 32, 64), A=3, sat=True):
     cls, box = [], []

@@ -12,7 +12,7 @@
 
 int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
                          const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
-                         int *keep_cnt, void *workspace);
+                         int *keep_cnt, void *workspace, int ge);
 
 #define DET_T 1024
 
@@ -230,7 +230,7 @@ extern "C" int upsnet_mask_roi(void *stream, const float *rois, const float *bbo
                        num_classes, im_info, class_agnostic, score_thresh, reg_weights[0], reg_weights[1], reg_weights[2],
                        reg_weights[3], nmax, cboxes, cscores, csrc, ccls, counts, status);
     UPS_CHECK_LAUNCH("mroi_candidates_kernel");
-    int rc = ups_nms_batched_impl(st, cboxes, cscores, counts, nullptr, P, nmax, nms_thresh, 0, keep, keepcnt, ws + m.nms);
+    int rc = ups_nms_batched_impl(st, cboxes, cscores, counts, nullptr, P, nmax, nms_thresh, 0, keep, keepcnt, ws + m.nms, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(mroi_finalize_kernel, dim3(1), dim3(DET_T), 0, st, P, nmax, max_det, cboxes, cscores, csrc, ccls, keep,
                        keepcnt, boxes_out, scores_out, cls_out, src_out, num_out);

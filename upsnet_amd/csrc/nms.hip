@@ -52,7 +52,7 @@ nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ score
 
 __global__ void __launch_bounds__(64)
 nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ counts, const int nmax, const int CB,
-                const float thresh, u64 *__restrict__ mask)
+                const float thresh, const int ge, u64 *__restrict__ mask)
 {
     const int p = blockIdx.z;
     const int n = min(counts[p], nmax);
@@ -70,7 +70,8 @@ nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ count
         const int start = (row_start == col_start) ? tid + 1 : 0;
         for (int i = start; i < col_size; ++i) {
             const float4 b = cb[i];
-            if (ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w) > thresh) t |= 1ULL << i;
+            const float ov = ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+            if (ge ? ov >= thresh : ov > thresh) t |= 1ULL << i;   // nms_kernel.cu:73-80 is ">", cpu_nms.pyx:77 ">="
         }
         mask[((long)p * nmax + cur) * CB + col_start] = t;
     }
@@ -189,7 +190,7 @@ extern "C" size_t upsnet_nms_workspace_bytes(int P, int nmax)
 // internal: tie_mode-selectable version used by the proposal / detection pipelines
 int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
                          const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
-                         int *keep_cnt, void *workspace)
+                         int *keep_cnt, void *workspace, int ge)
 {
     UPS_REQUIRE(boxes && scores && counts && keep_idx && keep_cnt && workspace, "nms_batched: null pointer");
     UPS_REQUIRE(P > 0 && nmax > 0, "nms_batched: bad sizes P=%d nmax=%d", P, nmax);
@@ -200,7 +201,7 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(M < 1024 ? M : 1024), (size_t)M * sizeof(u64), st, boxes, scores,
                        counts, nmax, M, tie_mode, w.sorted_boxes, w.order);
     UPS_CHECK_LAUNCH("nms_sort_kernel");
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, w.mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, ge, w.mask);
     UPS_CHECK_LAUNCH("nms_mask_kernel");
     const int use_lds = nmax <= NMS_LDS_ROWS;
     const size_t scan_smem = use_lds ? (size_t)nmax * CB * sizeof(u64) : 0;
@@ -223,7 +224,19 @@ extern "C" int upsnet_nms_batched(void *stream, const float *boxes, const float 
                                   int *keep_cnt, void *workspace)
 {
     return ups_nms_batched_impl((hipStream_t)stream, boxes, scores, counts, pre_removed, P, nmax, thresh, 0, keep_idx,
-                                keep_cnt, workspace);
+                                keep_cnt, workspace, 0);
+}
+
+// cpu_nms semantics (cpu_nms.pyx:29-80) on the device: same visiting order and IoU expression, suppression at
+// `ovr >= thresh` with the threshold a DOUBLE (a Python float in the reference's compiled module): the fp32 overlap is
+// >= the double threshold iff it is >= the smallest fp32 number that is >= the threshold.
+extern "C" int upsnet_cpu_nms_batched(void *stream, const float *boxes, const float *scores, const int *counts, int P, int nmax,
+                                      double thresh, int *keep_idx, int *keep_cnt, void *workspace)
+{
+    float tf = (float)thresh;
+    if ((double)tf < thresh) tf = nextafterf(tf, INFINITY);
+    return ups_nms_batched_impl((hipStream_t)stream, boxes, scores, counts, nullptr, P, nmax, tf, 0, keep_idx, keep_cnt,
+                                workspace, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,7 +272,7 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
         if (hipMemcpy(raw, boxes_host, (size_t)n * boxes_dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = ups_set_error("nms_host: H2D copy failed"); break; }
         hipLaunchKernelGGL(nms_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, raw, n, boxes_dim, packed);
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, mask);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, 0, mask);
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_T), 0, 0, mask, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
                            n, CB, 0, keep, kc);
         hipError_t e = hipGetLastError();
@@ -274,10 +287,177 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
 }
 
 // ---------------------------------------------------------------------------------------------
-// Soft-NMS (cpu_nms.pyx:91-196) as one workgroup: the outer loop is sequential by definition; each
-// trip does a parallel arg-max (first position of the maximum), the swap, a parallel re-score and the
-// reference's "swap with last" compaction restated as: k-th hole (ascending) <- k-th survivor from
-// the end (descending). Off the hot path in the reference (dead code); built for API parity.
+// Soft-NMS (cpu_nms.pyx:91-196), batched: ONE workgroup per problem (RPN level / class), P problems per launch.
+// The outer loop is sequential by definition; a trip is: arg-max over [i, N) (first position of the maximum, :113-118), swap
+// (:120-135), re-score of (i, N) (:147-180) and the reference's "swap with last" compaction (:184-193) restated as: k-th hole
+// (ascending) <- k-th survivor from the end (descending), with N' = N - #removed.
+//
+// The state of a problem -- x1/y1/x2/y2/score/index as structure-of-arrays -- lives in LDS (29 bytes per box: 1024 boxes =
+// 29 KiB, 4096 = 116 KiB of the CU's 160 KiB); problems up to 1024 boxes run on ONE wavefront (every "barrier" is free, ranks
+// come from ballots), up to 4096 on four. A trip costs a few hundred cycles instead of the ~10 global-memory round trips of the
+// r01 kernel (kept below for n > 4096).
+//
+// Arithmetic: Cython widens the literal in `x2 - x1 + 1` to the C double 1.0, so `area` and `ua` are evaluated in double from
+// fp32 differences and rounded once (see oracle/c/upsnet_oracle.c orc_soft_nms; pinned against the compiled reference).
+#define SNMS_KMAX 16     // chunks of T positions per trip: T * SNMS_KMAX >= nmax
+#define SNMS_LDS_MAX 4096
+
+__device__ static inline bool snms_rescore(const float tx1, const float ty1, const float tx2, const float ty2, const float bx1,
+                                           const float by1, const float bx2, const float by2, const float sigma, const float Nt,
+                                           const int method, float *score)
+{
+    const float area = (float)(((double)(bx2 - bx1) + 1.0) * ((double)(by2 - by1) + 1.0));
+    const float iw = (float)((double)(fminf(tx2, bx2) - fmaxf(tx1, bx1)) + 1.0);
+    if (!(iw > 0)) return false;
+    const float ih = (float)((double)(fminf(ty2, by2) - fmaxf(ty1, by1)) + 1.0);
+    if (!(ih > 0)) return false;
+    const float ua = (float)(((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0)) + (double)area) - (double)(iw * ih));
+    const float ov = iw * ih / ua;
+    float weight;
+    if (method == 1) weight = ov > Nt ? (float)(1.0 - (double)ov) : 1.0f;
+    else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
+    else weight = ov > Nt ? 0.0f : 1.0f;
+    *score = weight * *score;
+    return true;
+}
+
+template <int T>
+__global__ void __launch_bounds__(T)
+soft_nms_lds_kernel(float *__restrict__ boxes_g, int64_t *__restrict__ inds_g, const int *__restrict__ counts, const int nmax,
+                    const int cap, const float sigma, const float Nt, const float threshold, const int method,
+                    int *__restrict__ n_out)
+{
+    constexpr int W = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *x1 = reinterpret_cast<float *>(smem_raw), *y1 = x1 + cap, *x2 = y1 + cap, *y2 = x2 + cap, *sc = y2 + cap;
+    int *ind = reinterpret_cast<int *>(sc + cap);
+    unsigned short *hole = reinterpret_cast<unsigned short *>(ind + cap), *mover = hole + cap;
+    __shared__ int tab[3][SNMS_KMAX][W];
+    __shared__ float s_val[W];
+    __shared__ int s_pos[W];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *bg = boxes_g + (size_t)p * nmax * 5;
+    int64_t *ig = inds_g + (size_t)p * nmax;
+    const int n = counts ? min(counts[p], nmax) : nmax;
+    for (int q = tid; q < n; q += T) {
+        x1[q] = bg[q * 5 + 0]; y1[q] = bg[q * 5 + 1]; x2[q] = bg[q * 5 + 2]; y2[q] = bg[q * 5 + 3]; sc[q] = bg[q * 5 + 4];
+        ind[q] = q;
+    }
+    __syncthreads();
+    const u64 lt = (1ULL << lane) - 1ULL;
+    int N = n;
+    for (int i = 0; i < N; ++i) {
+        // ---- arg-max over [i, N): first position holding the maximum score (a thread walks ascending positions, `>` keeps the first)
+        float bv = -INFINITY; int bp = 0x7fffffff;
+        for (int q = i + tid; q < N; q += T) { const float v = sc[q]; if (v > bv) { bv = v; bp = q; } }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64); const int op = __shfl_xor(bp, d, 64);
+            if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+        }
+        if (W > 1) {
+            if (lane == 0) { s_val[wave] = bv; s_pos[wave] = bp; }
+            __syncthreads();
+            bv = s_val[0]; bp = s_pos[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) { const float ov = s_val[w]; const int op = s_pos[w]; if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; } }
+        }
+        if (!(sc[i] < bv)) bp = i;   // the reference starts from maxpos = i and moves only on a strictly larger score
+        __syncthreads();
+        if (tid == 0 && bp != i) {
+            float t;
+            t = x1[i]; x1[i] = x1[bp]; x1[bp] = t;  t = y1[i]; y1[i] = y1[bp]; y1[bp] = t;
+            t = x2[i]; x2[i] = x2[bp]; x2[bp] = t;  t = y2[i]; y2[i] = y2[bp]; y2[bp] = t;
+            t = sc[i]; sc[i] = sc[bp]; sc[bp] = t;
+            const int ti = ind[i]; ind[i] = ind[bp]; ind[bp] = ti;
+        }
+        __syncthreads();
+        const float tx1 = x1[i], ty1 = y1[i], tx2 = x2[i], ty2 = y2[i];
+        // ---- re-score (i, N); chunk k covers positions i+1+k*T .. +T-1, bit k of `rem` = "my position of chunk k falls below threshold"
+        const int len = N - (i + 1);
+        const int K = (len + T - 1) / T;
+        unsigned rem = 0;
+        int my_removed = 0;
+        for (int k = 0; k < K; ++k) {
+            const int q = i + 1 + k * T + tid;
+            bool r = false;
+            if (q < N) {
+                float ns = sc[q];
+                if (snms_rescore(tx1, ty1, tx2, ty2, x1[q], y1[q], x2[q], y2[q], sigma, Nt, method, &ns)) { sc[q] = ns; r = ns < threshold; }
+            }
+            const u64 m = __ballot(r);
+            if (r) rem |= 1u << k;
+            if (W > 1) { if (lane == 0) tab[0][k][wave] = __builtin_popcountll(m); }
+            else my_removed += __builtin_popcountll(m);
+        }
+        int R = my_removed;
+        if (W > 1) {
+            __syncthreads();
+            R = 0;
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int w = 0; w < W; ++w) R += tab[0][k][w];
+        }
+        if (R == 0) { if (W > 1) __syncthreads(); continue; }
+        const int Nn = N - R;
+        // ---- holes (removed, position < Nn) ranked ascending; movers (survivors at positions >= Nn) ranked ascending, used descending
+        int hole_base = 0, mover_base = 0;
+        if (W > 1) {
+            for (int k = 0; k < K; ++k) {
+                const int q = i + 1 + k * T + tid;
+                const bool r = (rem >> k) & 1u;
+                const u64 mh = __ballot(q < Nn && r), mm = __ballot(q >= Nn && q < N && !r);
+                if (lane == 0) { tab[1][k][wave] = __builtin_popcountll(mh); tab[2][k][wave] = __builtin_popcountll(mm); }
+            }
+            __syncthreads();
+        }
+        int n_holes = 0, n_movers = 0;
+        if (W > 1) {
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int w = 0; w < W; ++w) { n_holes += tab[1][k][w]; n_movers += tab[2][k][w]; }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const int q = i + 1 + k * T + tid;
+                const bool r = (rem >> k) & 1u;
+                n_holes += __builtin_popcountll(__ballot(q < Nn && r));
+                n_movers += __builtin_popcountll(__ballot(q >= Nn && q < N && !r));
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            const int q = i + 1 + k * T + tid;
+            const bool r = (rem >> k) & 1u;
+            const bool ish = q < Nn && r, ism = q >= Nn && q < N && !r;
+            const u64 mh = __ballot(ish), mm = __ballot(ism);
+            int hb = hole_base, mb = mover_base;
+            if (W > 1) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (w < wave) { hb += tab[1][k][w]; mb += tab[2][k][w]; }
+                    hole_base += tab[1][k][w]; mover_base += tab[2][k][w];
+                }
+            } else {
+                hole_base += __builtin_popcountll(mh); mover_base += __builtin_popcountll(mm);
+            }
+            if (ish) hole[hb + __builtin_popcountll(mh & lt)] = (unsigned short)q;
+            if (ism) mover[n_movers - 1 - (mb + __builtin_popcountll(mm & lt))] = (unsigned short)q;
+        }
+        __syncthreads();
+        for (int j = tid; j < n_holes; j += T) {   // n_holes == n_movers
+            const int dst = hole[j], src = mover[j];
+            x1[dst] = x1[src]; y1[dst] = y1[src]; x2[dst] = x2[src]; y2[dst] = y2[src]; sc[dst] = sc[src]; ind[dst] = ind[src];
+        }
+        __syncthreads();
+        N = Nn;
+    }
+    for (int q = tid; q < n; q += T) {
+        bg[q * 5 + 0] = x1[q]; bg[q * 5 + 1] = y1[q]; bg[q * 5 + 2] = x2[q]; bg[q * 5 + 3] = y2[q]; bg[q * 5 + 4] = sc[q];
+        ig[q] = ind[q];
+    }
+    if (tid == 0) n_out[p] = N;
+}
+
+// ---- global-memory form for problems beyond SNMS_LDS_MAX boxes (one workgroup of 1024 threads per problem)
 #define SNMS_T 1024
 
 __device__ static inline int block_excl_scan(int v, int *sh_wave, int *total)
@@ -303,10 +483,16 @@ __device__ static inline int block_excl_scan(int v, int *sh_wave, int *total)
 }
 
 __global__ void __launch_bounds__(SNMS_T)
-soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int n, const float sigma, const float Nt,
-                const float threshold, const int method, int *__restrict__ n_out, float *__restrict__ tmp_box,
-                int64_t *__restrict__ tmp_ind, uint8_t *__restrict__ flag)
+soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int *__restrict__ counts, const int nmax,
+                const float sigma, const float Nt, const float threshold, const int method, int *__restrict__ n_out,
+                float *__restrict__ tmp_box, int64_t *__restrict__ tmp_ind, uint8_t *__restrict__ flag)
 {
+    {   // problem blockIdx.x: its slice of every buffer
+        const size_t pb = blockIdx.x;
+        boxes += pb * nmax * 5; inds += pb * nmax; n_out += pb;
+        tmp_box += pb * nmax * 6; tmp_ind += pb * nmax * 2; flag += pb * nmax;
+    }
+    const int n = counts ? min(counts[blockIdx.x], nmax) : nmax;
     __shared__ float s_val[SNMS_T / 64];
     __shared__ int s_pos[SNMS_T / 64];
     __shared__ int s_scan[SNMS_T / 64];
@@ -341,22 +527,8 @@ soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int
         for (int p = i + 1 + tid; p < N; p += SNMS_T) {
             const float x1 = boxes[p * 5 + 0], y1 = boxes[p * 5 + 1], x2 = boxes[p * 5 + 2], y2 = boxes[p * 5 + 3];
             uint8_t rem = 0;
-            const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
-            const float iw = (fminf(tx2, x2) - fmaxf(tx1, x1) + 1);
-            if (iw > 0) {
-                const float ih = (fminf(ty2, y2) - fmaxf(ty1, y1) + 1);
-                if (ih > 0) {
-                    const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
-                    const float ov = iw * ih / ua;
-                    float weight;
-                    if (method == 1) weight = ov > Nt ? 1 - ov : 1;
-                    else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
-                    else weight = ov > Nt ? 0 : 1;
-                    const float ns = weight * boxes[p * 5 + 4];
-                    boxes[p * 5 + 4] = ns;
-                    rem = ns < threshold;
-                }
-            }
+            float ns = boxes[p * 5 + 4];
+            if (snms_rescore(tx1, ty1, tx2, ty2, x1, y1, x2, y2, sigma, Nt, method, &ns)) { boxes[p * 5 + 4] = ns; rem = ns < threshold; }
             flag[p] = rem;
         }
         __syncthreads();
@@ -409,22 +581,58 @@ soft_nms_kernel(float *__restrict__ boxes, int64_t *__restrict__ inds, const int
     if (tid == 0) *n_out = N;
 }
 
-extern "C" size_t upsnet_soft_nms_workspace_bytes(int n)
+extern "C" size_t upsnet_soft_nms_batched_workspace_bytes(int P, int nmax)
 {
-    return align256((size_t)n * 6 * sizeof(float)) + align256((size_t)n * 2 * sizeof(int64_t)) + align256((size_t)n) + 256;
+    if (P <= 0 || nmax <= SNMS_LDS_MAX) return 256;   // the LDS form needs no scratch
+    const size_t per = (size_t)nmax * 6 * sizeof(float) + (size_t)nmax * 2 * sizeof(int64_t) + (size_t)nmax;
+    return align256((size_t)P * per) + 3 * 256;
 }
 
-extern "C" int upsnet_soft_nms(void *stream, float *boxes, int64_t *inds, int n, float sigma, float Nt,
-                                  float threshold, int method, int *n_out, void *workspace)
+extern "C" int upsnet_soft_nms_batched(void *stream, float *boxes, int64_t *inds, const int *counts, int P, int nmax, float sigma,
+                                       float Nt, float threshold, int method, int *n_out, void *workspace)
 {
-    UPS_REQUIRE(boxes && inds && n_out && workspace, "soft_nms: null pointer");
-    UPS_REQUIRE(n >= 0 && n < (1 << 24), "soft_nms: bad n");
+    UPS_REQUIRE(boxes && inds && n_out, "soft_nms_batched: null pointer");
+    UPS_REQUIRE(P >= 0 && nmax >= 0 && nmax < (1 << 24), "soft_nms_batched: bad sizes P=%d nmax=%d", P, nmax);
+    UPS_REQUIRE(method >= 0 && method <= 2, "soft_nms_batched: method must be 0 (hard), 1 (linear) or 2 (gaussian)");
+    if (P == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (nmax == 0) { UPS_CHECK_HIP(hipMemsetAsync(n_out, 0, (size_t)P * sizeof(int), st)); return 0; }
+    if (nmax <= SNMS_LDS_MAX) {
+        const int T = nmax <= 64 * SNMS_KMAX ? 64 : 256;
+        const int cap = (nmax + 3) & ~3;
+        const size_t smem = (size_t)cap * (5 * sizeof(float) + sizeof(int) + 2 * sizeof(unsigned short));
+        if (T == 64) {
+            hipLaunchKernelGGL(soft_nms_lds_kernel<64>, dim3(P), dim3(64), smem, st, boxes, inds, counts, nmax, cap, sigma, Nt,
+                               threshold, method, n_out);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&soft_nms_lds_kernel<256>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SNMS_LDS_MAX * 28));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(soft_nms_lds_kernel<256>, dim3(P), dim3(256), smem, st, boxes, inds, counts, nmax, cap, sigma, Nt,
+                               threshold, method, n_out);
+        }
+        UPS_CHECK_LAUNCH("soft_nms_lds_kernel");
+        return 0;
+    }
+    UPS_REQUIRE(workspace, "soft_nms_batched: workspace required for nmax > %d", SNMS_LDS_MAX);
     unsigned char *b = (unsigned char *)workspace;
-    float *tmp_box = (float *)b; b += align256((size_t)n * 6 * sizeof(float));
-    int64_t *tmp_ind = (int64_t *)b; b += align256((size_t)n * 2 * sizeof(int64_t));
+    float *tmp_box = (float *)b; b += align256((size_t)P * nmax * 6 * sizeof(float));
+    int64_t *tmp_ind = (int64_t *)b; b += align256((size_t)P * nmax * 2 * sizeof(int64_t));
     uint8_t *flag = b;
-    hipLaunchKernelGGL(soft_nms_kernel, dim3(1), dim3(SNMS_T), 0, (hipStream_t)stream, boxes, inds, n, sigma, Nt, threshold,
-                       method, n_out, tmp_box, tmp_ind, flag);
+    hipLaunchKernelGGL(soft_nms_kernel, dim3(P), dim3(SNMS_T), 0, st, boxes, inds, counts, nmax, sigma, Nt, threshold, method,
+                       n_out, tmp_box, tmp_ind, flag);
     UPS_CHECK_LAUNCH("soft_nms_kernel");
     return 0;
+}
+
+// single problem (the r01 entry point): P = 1, all n rows valid
+extern "C" size_t upsnet_soft_nms_workspace_bytes(int n) { return upsnet_soft_nms_batched_workspace_bytes(1, n); }
+
+extern "C" int upsnet_soft_nms(void *stream, float *boxes, int64_t *inds, int n, float sigma, float Nt, float threshold, int method,
+                               int *n_out, void *workspace)
+{
+    return upsnet_soft_nms_batched(stream, boxes, inds, nullptr, 1, n, sigma, Nt, threshold, method, n_out, workspace);
 }

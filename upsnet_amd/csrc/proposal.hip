@@ -23,7 +23,7 @@
 
 int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
                          const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
-                         int *keep_cnt, void *workspace);
+                         int *keep_cnt, void *workspace, int ge);
 
 struct PropLevels {
     const float *cls[PROP_MAXLEV];
@@ -382,7 +382,7 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     hipLaunchKernelGGL(prop_decode_kernel, dim3((pre_n + 255) / 256, nlev), dim3(256), 0, st, lv, kbuf[cur], pre_n, im_info,
                        min_size, boxes, scores, pre_removed, counts);
     UPS_CHECK_LAUNCH("prop_decode_kernel");
-    int rc = ups_nms_batched_impl(st, boxes, scores, counts, pre_removed, nlev, pre_n, nms_thresh, 0, keep_idx, keep_cnt, nms_ws);
+    int rc = ups_nms_batched_impl(st, boxes, scores, counts, pre_removed, nlev, pre_n, nms_thresh, 0, keep_idx, keep_cnt, nms_ws, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(prop_merge_kernel, dim3(1), dim3(1024), (size_t)PROP_CH * 8, st, nlev, pre_n, post_n, boxes, scores,
                        keep_idx, keep_cnt, rois_out, scores_out, num_out);

@@ -26,14 +26,39 @@ def gpu_nms_wrapper(thresh, device_id):
     return _nms
 
 
-# The reference's cpu_nms / py_nms have no CUDA path; here every wrapper is served by the device kernel
-# (cpu_nms.pyx:77 suppresses at ">=", the GPU kernel at ">": the GPU semantics are the ones on the path).
+def _need_gpu(what):
+    if not torch.cuda.is_available():
+        raise RuntimeError("%s: upsnet_amd serves every NMS flavour with its HIP kernels and has no host path; no GPU is visible" % what)
+    return torch.cuda.current_device()
+
+
+def cpu_nms(dets, thresh):
+    """cpu_nms (cpu_nms.pyx:29-80) on the device: suppression at ``overlap >= thresh`` (:77), thresh compared as a double."""
+    dev = _need_gpu('cpu_nms')
+    if isinstance(dets, torch.Tensor):
+        return ops.cpu_nms(dets, thresh).tolist()
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    if dets.shape[0] == 0:
+        return []
+    return ops.cpu_nms(torch.from_numpy(dets).to('cuda:%d' % dev), thresh).tolist()
+
+
 def cpu_nms_wrapper(thresh):
-    return gpu_nms_wrapper(thresh, torch.cuda.current_device())
+    def _nms(dets):
+        return cpu_nms(dets, thresh)
+    return _nms
+
+
+def py_nms(dets, thresh):
+    """py_nms (nms.py:48-85) keeps ``ovr <= thresh``, i.e. suppresses at ``>`` like the GPU kernel; its areas and overlaps are the
+    same fp32 expressions -> served by the gpu_nms kernels."""
+    return gpu_nms(dets, thresh, _need_gpu('py_nms'))
 
 
 def py_nms_wrapper(thresh):
-    return gpu_nms_wrapper(thresh, torch.cuda.current_device())
+    def _nms(dets):
+        return py_nms(dets, thresh)
+    return _nms
 
 
 def cpu_soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):

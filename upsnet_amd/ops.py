@@ -263,18 +263,45 @@ def gpu_nms(dets, thresh):
     return keep[0, :int(cnt.item())].long()
 
 
+def cpu_nms(dets, thresh):
+    """cpu_nms (cpu_nms.pyx:29-80) on a device tensor [N,5]: like gpu_nms but suppression at `overlap >= thresh` (double compare)."""
+    require_cuda(dets)
+    dets = f32c(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=dets.device)
+    counts = torch.full((1,), n, dtype=torch.int32, device=dets.device)
+    boxes, scores = f32c(dets[None, :, :4]), f32c(dets[None, :, 4])
+    keep = torch.empty((1, n), dtype=torch.int32, device=dets.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    ws = _ws(lib().upsnet_nms_workspace_bytes(1, n), dets.device)
+    check(lib().upsnet_cpu_nms_batched(stream(), ptr(boxes), ptr(scores), ptr(counts), 1, n, float(thresh), ptr(keep), ptr(cnt),
+                                       ptr(ws)), "cpu_nms_batched")
+    return keep[0, :int(cnt.item())].long()
+
+
+def soft_nms_batched(boxes, counts=None, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """P soft-NMS problems in one launch (one workgroup each): boxes [P,nmax,5] (x1,y1,x2,y2,score), counts [P] int32 device or
+    None. Returns (boxes' [P,nmax,5], inds [P,nmax] int64, n_out [P] int32), all on the device: rows [0, n_out[p]) of problem p are
+    cpu_soft_nms's result (cpu_nms.pyx:91-196), the rest is unspecified."""
+    require_cuda(boxes)
+    b = f32c(boxes).clone()
+    Pn, nmax = b.shape[0], b.shape[1]
+    inds = torch.empty((Pn, max(nmax, 1)), dtype=torch.int64, device=b.device)
+    n_out = torch.zeros((max(Pn, 1),), dtype=torch.int32, device=b.device)
+    if Pn and nmax:
+        cnt = None if counts is None else counts.to(device=b.device, dtype=torch.int32).contiguous()
+        ws = _ws(lib().upsnet_soft_nms_batched_workspace_bytes(Pn, nmax), b.device)
+        check(lib().upsnet_soft_nms_batched(stream(), ptr(b), ptr(inds), ptr(cnt), Pn, nmax, float(sigma), float(Nt), float(threshold),
+                                            int(method), ptr(n_out), ptr(ws)), "soft_nms_batched")
+    return b, inds[:, :nmax], n_out[:Pn]
+
+
 def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
     """cpu_soft_nms semantics on device: returns (boxes', inds[:N'])."""
     require_cuda(boxes)
-    b = f32c(boxes).clone()
-    n = b.shape[0]
-    inds = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
-    n_out = torch.zeros((1,), dtype=torch.int32, device=b.device)
-    if n:
-        ws = _ws(lib().upsnet_soft_nms_workspace_bytes(n), b.device)
-        check(lib().upsnet_soft_nms(stream(), ptr(b), ptr(inds), n, float(sigma), float(Nt), float(threshold), int(method),
-                                    ptr(n_out), ptr(ws)), "soft_nms")
-    return b, inds[:int(n_out.item())]
+    b, inds, n_out = soft_nms_batched(f32c(boxes)[None], None, sigma, Nt, threshold, method)
+    return b[0], inds[0, :int(n_out[0].item())] if boxes.shape[0] else inds[0, :0]
 
 
 # ----------------------------------------------------------------------------- proposals
