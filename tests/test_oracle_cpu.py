@@ -200,3 +200,39 @@ def test_rle_counts_and_string_round_trip():
         assert sum(c) == mask.size and _rle_from_string(oops.rle_to_string(c)) == c
     big = [0, 5000, 123456, 7, 2000000, 1]
     assert _rle_from_string(oops.rle_to_string(big)) == big
+
+
+def test_dense_fp64_reference_agrees_with_the_modules_on_cpu():
+    """oracle/dense_ref.py (independent float64 restatement of the reference's dense graph, used by tests/test_trunk_gpu.py)
+    against the product's nn.Modules executed by torch on the CPU (library convolutions), UPSNet-50 on a 64x128 image."""
+    import torch
+    from oracle import dense_ref as dr
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50, config
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.synthetic import build_model, make_image
+    from conftest import gen_rois
+    torch.set_num_threads(8)
+    m = build_model(cls_gain=0.3, device='cpu', channels_last=False)
+    data = make_image(64, 128, seed=0)
+    with torch.no_grad():
+        res = m.resnet_backbone(data['data'])
+        pyr = m.fpn(*res)
+        rp = [m.rpn(f) for f in pyr]
+    rois = torch.from_numpy(gen_rois(np.random.default_rng(0), 40, 64, 128, 8, 64))
+    ref = dr.dense_reference(m, data, rois, rois[:5], rois[5:9], config.network.mask_size)
+    for a, b in list(zip(res, ref['res'])) + list(zip(pyr, ref['pyramid'])) + [(r[2], q) for r, q in zip(rp, ref['rpn_cls_prob'])] + \
+            [(r[1], q) for r, q in zip(rp, ref['rpn_bbox_pred'])]:
+        assert torch.allclose(a.double(), b, rtol=1e-4, atol=1e-4)
+    # ROI pooling and deformable convolution of the float64 reference vs the C oracle (itself bit-equal to the reference kernels)
+    f32 = [t.float().numpy() for t in ref['pyramid'][:4]]
+    pool = oops.fpn_roi_align(f32, rois.numpy(), 7, 7)
+    assert torch.allclose(torch.from_numpy(pool).double(), dr.fpn_roi_pool([torch.from_numpy(x).double() for x in f32], rois, 7), rtol=1e-4, atol=1e-4)
+    layer = m.fcn_head.fcn_subnet.conv[0][0]
+    x = ref['pyramid'][1]
+    off = dr.conv_bn(x, layer.conv_offset) * 30
+    col = oracle.deform_im2col(x[0].float().numpy(), off[0].float().numpy(), (3, 3), (1, 1), (1, 1), (1, 1), 1)
+    w = layer.conv.weight.detach().double().reshape(layer.conv.out_channels, -1)
+    y = (w @ torch.from_numpy(col).double().reshape(col.shape[0], -1)).reshape(1, -1, col.shape[1], col.shape[2]) + \
+        layer.conv.bias.detach().double().view(1, -1, 1, 1)
+    assert torch.allclose(y, dr.deform_conv(x, off, layer.conv), rtol=1e-4, atol=1e-4)
+    assert ref['fcn_score'].shape == (1, 19, 16, 32) and ref['cls_prob'].shape == (40, 9) and ref['mask_logit_det'].shape == (5, 9, 28, 28)
