@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import ops as oops
 
-D = torch.float64
+D = torch.float64   # evaluation dtype; dense_reference(..., dtype=torch.float32) re-runs the same graph as a plain fp32 library execution
 
 
 def _w(t):
@@ -145,14 +145,25 @@ def rpn(feat, m):
 
 
 # ----------------------------------------------------------------------------- semantic head
-def fcn_score(feats, head):
-    """fcn.py:88-108 up to the class scores at 1/4 resolution (the product's `fcn_score`; fcn_output = its bilinear x4)."""
+def fcn_score(feats, head, given_offsets=None, own_offsets=None):
+    """fcn.py:88-108 up to the class scores at 1/4 resolution (the product's `fcn_score`; fcn_output = its bilinear x4).
+    given_offsets[layer][level]: sample at THESE offsets instead of the ones predicted here (a deformable layer amplifies an
+    offset difference d by the local feature gradient: |d| ~ 1e-5 px on features of magnitude ~100 moves a sample by ~1e-3, so
+    the strict 1e-4 check of the sampling + GEMM stages is made at identical sampling positions and the offset predictions are
+    checked on their own); own_offsets (a list) receives the offsets predicted here, [layer][level]."""
     lv = []
-    for f in feats[:4]:
+    for l, f in enumerate(feats[:4]):
         y = f
         for i in range(head.fcn_subnet.num_layers):     # fcn.py:51-58: DeformConvWithOffset + ReLU
             layer = head.fcn_subnet.conv[i][0]
-            y = deform_conv(y, conv_bn(y, layer.conv_offset), layer.conv, relu=True)
+            off = conv_bn(y, layer.conv_offset)
+            if own_offsets is not None:
+                while len(own_offsets) <= i:
+                    own_offsets.append([None] * 4)
+                own_offsets[i][l] = off
+            if given_offsets is not None:
+                off = given_offsets[i][l].to(device=y.device, dtype=y.dtype)
+            y = deform_conv(y, off, layer.conv, relu=True)
         lv.append(y)
     for l, s in ((1, 2), (2, 4), (3, 8)):
         lv[l] = F.interpolate(lv[l], None, s, mode='bilinear', align_corners=False)
@@ -230,10 +241,21 @@ def mask_head(feats, boxes, m, size):
 
 
 # ----------------------------------------------------------------------------- driver
-def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size):
+def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, dtype=torch.float64, fcn_offsets=None):
     """The dense stages of resnet_upsnet.forward (resnet_upsnet.py:88-248, test branch) in float64, with the SELECTION results
     (rois, detections) taken from the caller (the product's recorded ones: selection is integer work with its own bit-exact
-    tests, and tiny logit differences must not be allowed to change which boxes the two executions look at)."""
+    tests, and tiny logit differences must not be allowed to change which boxes the two executions look at).
+    fcn_offsets: see fcn_score(given_offsets); the result then also holds 'fcn_score_given' and 'fcn_offsets' (own predictions
+    along the given-offset chain)."""
+    global D
+    saved, D = D, dtype
+    try:
+        return _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets)
+    finally:
+        D = saved
+
+
+def _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets):
     with torch.no_grad():
         dev = next(model.parameters()).device
         x = data['data'].to(dev).to(D)
@@ -244,6 +266,10 @@ def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size):
         r = [rpn(f, model.rpn) for f in pyr]
         out = dict(res=res, pyramid=pyr, rpn_cls_prob=[t[2] for t in r], rpn_bbox_pred=[t[1] for t in r])
         out['fcn_score'] = fcn_score(pyr, model.fcn_head)
+        if fcn_offsets is not None:
+            own = []
+            out['fcn_score_given'] = fcn_score(pyr, model.fcn_head, given_offsets=fcn_offsets, own_offsets=own)
+            out['fcn_offsets'] = own
         out['cls_prob'], out['bbox_pred'] = box_head(pyr, rois.to(dev), model.rcnn)
         out['mask_logit_det'] = mask_head(pyr, det_boxes.to(dev), model.mask_branch, mask_size // 2)
         out['mask_logit_pan'] = mask_head(pyr, pan_boxes.to(dev), model.mask_branch, mask_size // 2)

@@ -103,6 +103,28 @@ def test_coco_r101_dcn_config_stagewise_parity():
         update_config_dict(CITYSCAPES_R50)
 
 
+def test_coco_r101_dcn_full_size_stagewise_parity():
+    """BASELINE.json configs[3] at its real size: UPSNet-101-DCN, COCO-shaped 800x1333 (padded to 800x1344), 300 proposals,
+    81 / 133 classes -- every custom-op stage recomputed by the oracle from the recorded inputs, label map bit-identical."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN, CITYSCAPES_R50
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model(cls_gain=0.3)
+        data = make_image(800, 1333, seed=5, device='cuda')
+        model.taps = {}
+        with torch.no_grad():
+            out = model(data)
+        res = check_taps(model.taps, enable_void=True)
+        counts = res.pop('counts')
+        assert all(res.values()), (res, counts)
+        assert counts['label_mismatch'] == 0 and counts['n_rois'] <= 300 and counts['n_det'] >= 1, counts
+        assert out['panoptic_outputs'].shape == (1, 800, 1344)
+    finally:
+        update_config_dict(CITYSCAPES_R50)
+
+
 def test_mask_head_dedup_is_bit_identical_to_two_passes(setup):
     """The fused pipeline runs the mask head once over [per-class detections ; panoptic detections not among them] and reuses
     rows for the duplicates; the reference-shaped pipeline runs it twice (resnet_upsnet.py:190,215). Same bits."""

@@ -34,6 +34,7 @@ class FCNSubNet(nn.Module):
             conv.append(nn.ReLU(inplace=True))
             self.conv.append(nn.Sequential(*conv))
         self._packed = {}
+        self.taps = None   # parity tests: set to a dict to record every layer's predicted offsets (tests/test_trunk_gpu.py)
         self.initialize()
 
     def initialize(self):
@@ -67,6 +68,8 @@ class FCNSubNet(nn.Module):
                 xs = [self.conv[i](x) for x in xs]
                 continue
             offsets = hipconv.conv_multi(layer.conv_offset, xs)
+            if self.taps is not None:
+                self.taps.setdefault('offsets', []).append([o.detach().clone() for o in offsets])
             xs = ops.deform_conv_fused(xs, offsets, self._wpack(i, dc), dc.bias, dc.in_channels, dc.out_channels,
                                        dc.kernel_size, dc.stride, dc.padding, dc.dilation, relu=True)
         return xs

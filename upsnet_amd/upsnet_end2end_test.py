@@ -44,6 +44,8 @@ def init_distributed():
             if os.environ.get('UPSNET_SHARE_GPU', '0') != '1':
                 raise RuntimeError('LOCAL_RANK %d but only %d GPU(s) visible (set UPSNET_SHARE_GPU=1 to let ranks share a GPU)' % (local, ndev))
             local = local % ndev
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the shared-GPU functional run stages through gloo
+            os.environ.setdefault('UPSNET_DIST_BACKEND', 'gloo')
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
