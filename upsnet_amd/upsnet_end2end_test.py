@@ -39,12 +39,13 @@ def init_distributed():
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         ndev = torch.cuda.device_count()
-        if local >= ndev:
-            # one rank per GPU is the contract; several ranks on one GPU only on request (single-GPU smoke runs of the N>1 path)
+        per_node = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        if per_node > ndev:
+            # one rank per GPU is the contract; several ranks on one GPU only on request (single-GPU functional runs of the N>1 path)
             if os.environ.get('UPSNET_SHARE_GPU', '0') != '1':
-                raise RuntimeError('LOCAL_RANK %d but only %d GPU(s) visible (set UPSNET_SHARE_GPU=1 to let ranks share a GPU)' % (local, ndev))
+                raise RuntimeError('%d ranks on this node but only %d GPU(s) visible (set UPSNET_SHARE_GPU=1 to let ranks share a GPU)' % (per_node, ndev))
             local = local % ndev
-            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the shared-GPU functional run stages through gloo
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): EVERY rank of a shared-GPU run stages through gloo
             os.environ.setdefault('UPSNET_DIST_BACKEND', 'gloo')
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
