@@ -90,6 +90,40 @@ def _dcn_cpu(layer, x, relu=True):
     return F.relu(y) if relu else y
 
 
+def _conv_bn_cpu(conv, bn, x):
+    y = conv(x)
+    return y if isinstance(bn, torch.nn.Identity) else bn(y)
+
+
+def _backbone_cpu(bb, x):
+    """ResNetBackbone on the host (resnet.py:347-356). Plain stages run through the modules (torch-CPU convolutions); a
+    DCNBottleneck (resnet.py:102-153, configs[3]/[4]) has no CPU implementation in the reference or in the product, so its
+    3x3 is evaluated here as oracle im2col + GEMM (the reference's own structure, functions/deform_conv.py:43-57)."""
+    if not any(hasattr(b, 'conv2_offset') for b in bb.modules()):
+        return bb(x)
+    y = bb.conv1(x)
+    feats = []
+    for name in ('res2', 'res3', 'res4', 'res5'):
+        for blk in getattr(bb, name).layers:
+            if not hasattr(blk, 'conv2_offset'):
+                y = blk(y)
+                continue
+            t = F.relu(_conv_bn_cpu(blk.conv1, blk.bn1, y))
+            off = blk.conv2_offset(t)
+            dc = blk.conv2
+            col = deform_im2col(_np(t[0]), _np(off[0]), dc.kernel_size, dc.padding, dc.stride, dc.dilation, dc.deformable_groups)
+            w = dc.weight.detach().float().reshape(dc.out_channels, -1)
+            o = torch.mm(w, torch.from_numpy(col).reshape(col.shape[0], -1)).reshape(1, dc.out_channels, col.shape[1], col.shape[2])
+            if dc.bias is not None:
+                o = o + dc.bias.detach().view(1, -1, 1, 1)
+            t = F.relu(o if isinstance(blk.bn2, torch.nn.Identity) else blk.bn2(o))
+            t = _conv_bn_cpu(blk.conv3, blk.bn3, t)
+            sc = y if blk.downsample is None else _conv_bn_cpu(blk.downsample[0], blk.downsample[1], y)
+            y = F.relu(t + sc)
+        feats.append(y)
+    return tuple(feats)
+
+
 def _fpn_pool_cpu(feats, rois, size):
     return torch.from_numpy(oops.fpn_roi_align([_np(f) for f in feats], rois, size, size))
 
@@ -111,9 +145,7 @@ def forward_cpu(model_cpu, data, stage_times=None):
 
     with torch.no_grad():
         x = data['data'].float().cpu()
-        res = m.resnet_backbone(x) if not any(hasattr(b, 'conv2_offset') for b in m.resnet_backbone.modules()) else None
-        if res is None:
-            raise NotImplementedError("forward_cpu: DCN backbones are not needed for the CPU baseline config")
+        res = _backbone_cpu(m.resnet_backbone, x)
         pyramid = m.fpn(*res)
         rpn_prob, rpn_box = [], []
         for f in pyramid:

@@ -236,3 +236,20 @@ def test_dense_fp64_reference_agrees_with_the_modules_on_cpu():
         layer.conv.bias.detach().double().view(1, -1, 1, 1)
     assert torch.allclose(y, dr.deform_conv(x, off, layer.conv), rtol=1e-4, atol=1e-4)
     assert ref['fcn_score'].shape == (1, 19, 16, 32) and ref['cls_prob'].shape == (40, 9) and ref['mask_logit_det'].shape == (5, 9, 28, 28)
+
+
+def test_forward_cpu_covers_the_dcn_backbone():
+    """cpu_baseline for BASELINE configs[3]/[4]: the CPU composite forward handles UPSNet-101-DCN (30 deformable bottlenecks,
+    GAP, 3 FCN layers) -- r01 raised NotImplementedError there."""
+    import torch
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50, COCO_R101_DCN
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        from oracle.forward import forward_cpu
+        torch.set_num_threads(8)
+        m = build_model(cls_gain=0.3, device='cpu', channels_last=False)
+        out = forward_cpu(m, make_image(64, 96, seed=0))
+        assert out['panoptic_outputs'].shape == (64, 96) and out['n_rois'] <= 300 and out['mask_probs'].shape[1:] == (81, 28, 28)
+    finally:
+        update_config_dict(CITYSCAPES_R50)
