@@ -132,6 +132,22 @@ int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const float *const x
                                     int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
                                     const float *wpack, int ldw, const float *bias, int relu);
 
+/* Second-generation fused deformable convolution (csrc/deform_fused.hip): same operator and tensor layouts as
+ * upsnet_deform_conv_forward_nhwc (replaces DeformConvFunction.forward, functions/deform_conv.py:43-57, and the modulated
+ * v2 form, mod_deform_conv_kernel.cu:187-249), but the K walk is channel-slab outermost / tap innermost (neighbouring taps
+ * re-use their corner lines out of L1 / L2), the per-(pixel, tap) sampling descriptors live in an LDS table built once per
+ * workgroup, and the weights are read in MFMA fragment order straight from L2:
+ *   wpack: upsnet_dcn_packed_weight_floats(cout, cin, kh, kw) floats, filled by upsnet_dcn_pack_weight from the
+ *          nn.Conv2d-layout weight [Cout, Cin, kh, kw]; square pad / stride / dilation; at most 25 taps; Cin % 32 == 0.
+ * upsnet_dcn_tuning: development knob (register-set / occupancy variants for A/B runs). */
+size_t upsnet_dcn_packed_weight_floats(int cout, int cin, int kh, int kw);
+int upsnet_dcn_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, float *wpack);
+int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                  const float *const mask[], float *const out[], const int height[], const int width[],
+                                  int cin, int cout, int kh, int kw, int pad, int stride, int dil, const float *wpack,
+                                  const float *bias, int relu);
+void upsnet_dcn_tuning(int variant);
+
 /* ============================== Input blob (the step before the path) ============================== */
 
 /* BaseDataset.prep_im_for_blob + im_list_to_blob (upsnet/dataset/base_dataset.py:143-173,898-923) in one kernel:

@@ -94,19 +94,26 @@ def _dcn_ref(x, off, w, b, k, pad, stride, dil, mask=None, relu=False):
     return np.maximum(out, 0) if relu else out
 
 
+@pytest.mark.parametrize("kind", ["frag", "igemm"])
 @pytest.mark.parametrize("cin,cout,sizes,mod,relu", [(32, 32, [(9, 13)], False, False), (64, 128, [(16, 24), (8, 12), (4, 6), (2, 3)], False, True),
                                                      (32, 64, [(10, 10)], True, False), (32, 256, [(7, 19), (3, 5)], False, False),
-                                                     (256, 128, [(40, 64), (20, 32)], False, True), (64, 19, [(11, 13)], True, False)])
-def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu):
+                                                     (256, 128, [(40, 64), (20, 32)], False, True), (64, 19, [(11, 13)], True, False),
+                                                     (128, 160, [(33, 17)], False, False)])
+def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu, kind):
+    """Both generations of the fused kernel: 'frag' = csrc/deform_fused.hip (default), 'igemm' = the loader mode of csrc/conv.hip."""
     rng = np.random.default_rng(4)
     w = (rng.normal(size=(cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
     b = rng.normal(size=(cout,)).astype(np.float32)
     xs = [rng.normal(size=(1, cin, h, ww)).astype(np.float32) for h, ww in sizes]
     offs = [(rng.normal(size=(1, 18, h, ww)) * 2).astype(np.float32) for h, ww in sizes]
+    offs[0][0, :, 0, 0] = [-1.0, -1.0, -1.5, 0.0, 0.0, -2.0, 0.25, float(sizes[0][1]), 1.0, 1.0, 0.5, -0.5, 0.0, 0.0, 2.0, 2.0, float(sizes[0][0]), 0.0]
     masks = [rng.uniform(0, 2, size=(1, 9, h, ww)).astype(np.float32) for h, ww in sizes] if mod else None
-    wp = U.pack_dcn_weight(cu(w))
-    assert wp[1] == (cout + 31) // 32 * 32
-    assert np.array_equal(wp[0].cpu().numpy()[:, :cout], w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    wp = U.pack_dcn_weight(cu(w), kind)
+    if kind == 'igemm':
+        assert wp[1] == (cout + 31) // 32 * 32
+        assert np.array_equal(wp[0].cpu().numpy()[:, :cout], w.transpose(2, 3, 1, 0).reshape(9 * cin, cout))
+    else:
+        assert wp[0] == 'frag' and wp[1].numel() == (cout + 127) // 128 * 128 * cin * 9
     outs = U.deform_conv_fused([cu(x) for x in xs], [cu(o) for o in offs], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1),
                                masks=[cu(m) for m in masks] if mod else None, relu=relu)
     for i, o in enumerate(outs):
@@ -114,6 +121,31 @@ def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu):
         got = o.cpu().numpy()[0]
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)  # fp32 logits within 1e-4 (BASELINE.json)
+
+
+@pytest.mark.parametrize("k,pad,stride,dil", [(3, 2, 1, 2), (3, 1, 2, 1), (1, 0, 1, 1), (5, 2, 1, 1)])
+def test_deform_conv_fused_geometries(U, k, pad, stride, dil):
+    """Dilated (the reference's dilated res5 option), strided, 1x1 and 5x5 deformable kernels through csrc/deform_fused.hip; every
+    variant of its register-set / occupancy knob computes the same bits."""
+    rng = np.random.default_rng(k * 10 + dil)
+    cin, cout, H, W = 64, 96, 21, 30
+    w = (rng.normal(size=(cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    x = rng.normal(size=(1, cin, H, W)).astype(np.float32)
+    Ho, Wo = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1, (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    off = (rng.normal(size=(1, 2 * k * k, Ho, Wo)) * 1.5).astype(np.float32)
+    wp = U.pack_dcn_weight(cu(w), 'frag')
+    ref = _dcn_ref(x[0], off[0], w, None, k, pad, stride, dil)
+    from upsnet_amd._lib import lib
+    outs = []
+    try:
+        for variant in (1, 2, 3, 0):
+            lib().upsnet_dcn_tuning(variant)
+            outs.append(U.deform_conv_fused([cu(x)], [cu(off)], wp, None, cin, cout, (k, k), (stride, stride), (pad, pad), (dil, dil))[0].cpu().numpy()[0])
+    finally:
+        lib().upsnet_dcn_tuning(1)
+    np.testing.assert_allclose(outs[0], ref, rtol=1e-4, atol=1e-4)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
 
 
 def test_deform_conv_function_and_module(U):

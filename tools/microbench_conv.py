@@ -52,8 +52,15 @@ if not only or 'dcn' in only:
         xs = [torch.randn(1, cin, h, w, device='cuda').contiguous(memory_format=torch.channels_last) for h, w in sizes]
         offs = [(torch.randn(1, 18, h, w, device='cuda') * 2).contiguous(memory_format=torch.channels_last) for h, w in sizes]
         wgt = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
-        wp = ops.pack_dcn_weight(wgt)
         hw = sum(h * w for h, w in sizes)
-        bench("dcn fused %d->%d 4 levels" % (cin, cout),
-              lambda: ops.deform_conv_fused(xs, offs, wp, None, cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True),
-              2.0 * cout * cin * 9 * hw, 4.0 * hw * (cin + 18 + cout))
+        for std in (2.0, 0.3):   # offset spread in pixels (the synthetic benchmark weights give ~0.3-3 px)
+            offs = [(torch.randn(1, 18, h, w, device='cuda') * std).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+            for kind, variants in (('igemm', (None,)), ('frag', (1, 2, 3, 0))):
+                wp = ops.pack_dcn_weight(wgt, kind)
+                for v in variants:
+                    if v is not None:
+                        lib().upsnet_dcn_tuning(v)
+                    bench("dcn %s%s %d->%d 4 levels, offsets N(0,%.1f)" % (kind, '' if v is None else ' v%d' % v, cin, cout, std),
+                          lambda: ops.deform_conv_fused(xs, offs, wp, None, cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True),
+                          2.0 * cout * cin * 9 * hw, 4.0 * hw * (cin + 18 + cout))
+            lib().upsnet_dcn_tuning(1)

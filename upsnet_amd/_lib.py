@@ -28,6 +28,10 @@ _SIGNATURES = {
     "upsnet_mod_deform_col2im": (c_int, [P, P, P, P] + [c_int] * 15 + [P]),
     "upsnet_mod_deform_col2im_coord": (c_int, [P, P, P, P, P] + [c_int] * 15 + [P, P]),
     "upsnet_deform_conv_forward_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 11 + [P, c_int, P, c_int]),
+    "upsnet_dcn_packed_weight_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "upsnet_dcn_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "upsnet_deform_conv_fused_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 7 + [P, P, c_int]),
+    "upsnet_dcn_tuning": (None, [c_int]),
     "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_tuning": (None, [c_int, c_int]),
     "upsnet_conv_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

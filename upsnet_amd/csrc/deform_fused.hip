@@ -1,0 +1,337 @@
+// deform_fused.hip -- deformable convolution v1 / v2 (sampling + GEMM fused, no column buffer), second generation.
+//
+// Reference: DeformConvFunction.forward = deformable_im2col into a column buffer in HBM + torch.mm + bias
+// (upsnet/operators/functions/deform_conv.py:43-57, deform_conv_kernel.cu:88-118,194-242; v2: mod_deform_conv_kernel.cu:187-249).
+//
+// The first generation (conv.hip, DEFORM = 1 / 2) was the dense implicit-GEMM kernel with a bilinear-gather loader. Profiled on
+// MI355X (profiles/r05_*): 58 % of the fp32 MFMA peak, 18-178 registers spilled to scratch, and 2.63 GB of fabric traffic per
+// launch for 236 MB of algorithmic bytes -- the K walk went tap by tap over ALL input channels, so the 1 KiB pixel vectors a tap
+// touched had left the XCD's 4 MiB L2 (24 MB pass through it per tap) before the neighbouring tap came back to them.
+//
+// This kernel changes the three things behind those numbers:
+//   * K is walked CHANNEL SLAB outermost, tap innermost: for 32 channels (one 128-byte line per pixel) all kh*kw taps follow
+//     each other. The corners of neighbouring taps coincide or are adjacent, so a line is re-used out of L1 / L2 eight slabs
+//     later at most (working set per workgroup and slab: ~3 rows x 66 pixels x 128 B = 25 KiB).
+//   * The per-(pixel, tap) sampling descriptors -- corner address, validity bits, the two bilinear fractions (and the v2
+//     modulation) computed with the reference's exact fp32 arithmetic -- are built ONCE per workgroup into an LDS table
+//     (16 B x 64 pixels x taps) instead of living in registers / being recomputed per tap: no spills, and the slab-outer walk
+//     costs one ds_read_b128 per pixel and slab.
+//   * The B operand (weights) never touches LDS: packed in MFMA fragment order it is one 16-byte buffer load per lane and step,
+//     prefetched four steps ahead in a register ring (as conv_wino.hip). LDS holds only the blended A tile (2 x 8 KiB) and the
+//     table, so occupancy is set by registers alone (3 workgroups / CU) and two register sets of corners are in flight: the
+//     gather of slab s+2 is issued while slab s+1 is blended and slab s is contracted.
+// Tile: 64 output pixels x 128 output channels per workgroup (4 waves; wave w owns column block w and both 32-row blocks), fp32
+// products and accumulation on v_mfma_f32_32x32x2_f32 in a fixed order (bit-repeatable). Epilogue: + bias, ReLU, NHWC store.
+#include "conv_params.h"
+#include "upsnet_hip.h"
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define DF_BM 64
+#define DF_BN 128
+#define DF_ABUF (8 * DF_BM)        // float4 units of one A buffer: 8 channel quarters x 64 pixels
+#define DF_RING 4
+
+// Weights [Cout, Cin, kh, kw] -> fragment order [cb = co/32][cs = c/32][tap][h = (c%32)/8][half = (c%8)/4][co%32][c%4]; the column
+// blocks are padded to a multiple of 4 (zero weights) so that every wave of the last 128-channel tile reads valid memory.
+__global__ void dcn_pack_weight_frag_kernel(const float *__restrict__ w, int cout, int cin, int taps, int nblk, float *__restrict__ wp)
+{
+    const long total = (long)nblk * 32 * cin * taps;
+    const int cslabs = cin >> 5;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int c4 = idx & 3, col = (idx >> 2) & 31, half = (idx >> 7) & 1, h = (idx >> 8) & 3;
+        long r = idx >> 10;
+        const int tap = r % taps; r /= taps;
+        const int cs = r % cslabs; const int cb = r / cslabs;
+        const int co = 32 * cb + col, c = 32 * cs + 8 * h + 4 * half + c4;
+        wp[idx] = co < cout ? w[((long)co * cin + c) * taps + tap] : 0.f;
+    }
+}
+
+extern "C" size_t upsnet_dcn_packed_weight_floats(int cout, int cin, int kh, int kw)
+{
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)((cout + DF_BN - 1) / DF_BN) * DF_BN * (size_t)cin * kh * kw;
+}
+
+extern "C" int upsnet_dcn_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, float *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && cin % 32 == 0 && kh > 0 && kw > 0, "dcn_pack_weight: bad args (Cin %% 32 must be 0)");
+    const int nblk = (cout + DF_BN - 1) / DF_BN * 4;
+    const long total = (long)nblk * 32 * cin * kh * kw;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(dcn_pack_weight_frag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, kh * kw, nblk, wpack);
+    UPS_CHECK_LAUNCH("dcn_pack_weight_frag_kernel");
+    return 0;
+}
+
+// one bilinear blend with the reference's expression order (deform_conv_kernel.cu:88-118): w1*v1 + w2*v2 + w3*v3 + w4*v4 left to
+// right, corners outside the image contribute 0; v2: times the modulation (mod_deform_conv_kernel.cu:245).
+__device__ static inline float df_blend(const unsigned vb, const float w1, const float w2, const float w3, const float w4, float v1,
+                                        float v2, float v3, float v4)
+{
+    v1 = (vb & 1u) ? v1 : 0.f;
+    v2 = (vb & 2u) ? v2 : 0.f;
+    v3 = (vb & 4u) ? v3 : 0.f;
+    v4 = (vb & 8u) ? v4 : 0.f;
+    float val = w1 * v1;
+    val = val + w2 * v2;
+    val = val + w3 * v3;
+    val = val + w4 * v4;
+    return val;
+}
+
+// SETS: corner register sets in flight (2: the gather of step s+2 overlaps the blend of step s+1; 1: one step of lookahead);
+// WPE: waves per SIMD the register budget is set for.
+template <bool MOD, int SETS, int WPE>
+__global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *As = reinterpret_cast<float4 *>(smem_raw);                       // [2][8 q][64 px ^ 2q]
+    uintx4 *dsc = reinterpret_cast<uintx4 *>(smem_raw + 2 * DF_ABUF * 16);   // [tap][64 px]: (corner byte offset | vb, lh, lw, m)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles (vertically adjacent
+    // tiles share their sampling halos in that XCD's L2) and all n-tiles of an m-tile. Same scheme as conv_igemm_f32_kernel.
+    int m_t, n_t;
+    {
+        const int nt = p.n_tiles;
+        const int per = (p.m_tiles + 7) >> 3;
+        const int bid = (int)blockIdx.x;
+        const int q = bid >> 3;
+        n_t = q % nt;
+        const int local = q / nt;
+        m_t = (bid & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
+    }
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
+    const ConvSeg sg = p.seg[si];
+    const long p0 = (long)(m_t - sg.tile_start) * DF_BM;
+    const int ntap = p.KH * p.KW;
+    const int cslabs = p.Cin >> 5;
+    const int nsl = cslabs * ntap;                 // (channel slab, tap) steps of the K walk, tap innermost
+    const long HoWo = (long)sg.Ho * sg.Wo;
+
+    // ---- sampling descriptors of this tile, once: deform_conv_kernel.cu:227-240 (positions), :88-118 (corners, fractions)
+    for (int idx = tid; idx < ntap * DF_BM; idx += 256) {
+        const int tap = idx >> 6, px = idx & 63;
+        const long pp = p0 + px;
+        uintx4 d;
+        d.x = 0u; d.y = 0u; d.z = 0u; d.w = __float_as_uint(1.0f);
+        if (pp < sg.M) {
+            const int n = (int)(pp / HoWo);
+            const int rem = (int)(pp - (long)n * HoWo);
+            const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+            const int ki = tap / p.KW, kj = tap - ki * p.KW;
+            const int h_base = ho * p.stride - p.pad + ki * p.dil, w_base = wo * p.stride - p.pad + kj * p.dil;
+            const float off_h = sg.off[pp * (2 * ntap) + 2 * tap];
+            const float off_w = sg.off[pp * (2 * ntap) + 2 * tap + 1];
+            const float h_im = (float)h_base + off_h;   // integer part converted to float before the add (:227-228)
+            const float w_im = (float)w_base + off_w;
+            const int H = sg.H, W = sg.W;
+            unsigned pix = (unsigned)(n * H * W);
+            if (h_im > -1 && w_im > -1 && h_im < (float)H && w_im < (float)W) {
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                d.y = __float_as_uint(h_im - (float)h_low);
+                d.z = __float_as_uint(w_im - (float)w_low);
+                const bool a = h_low >= 0, b = h_high <= H - 1, c = w_low >= 0, e = w_high <= W - 1;
+                pix += (unsigned)((a ? h_low : 0) * W + (c ? w_low : 0));
+                // bits 0-3: corner inside the image; bit 4 / 5: the right / lower neighbour is a distinct in-range pixel (otherwise
+                // the clamped pair coincides and the invalid one is masked)
+                d.x = (a && c ? 1u : 0u) | (a && e ? 2u : 0u) | (b && c ? 4u : 0u) | (b && e ? 8u : 0u) | (c && e ? 16u : 0u) | (a && b ? 32u : 0u);
+            }
+            d.x |= pix * 4u * (unsigned)p.Cin;           // byte offset of the top-left corner's channel vector: a multiple of 128
+            if (MOD) d.w = __float_as_uint(sg.mask[pp * ntap + tap]);
+        }
+        dsc[idx] = d;
+    }
+
+    // ---- loader geometry: thread = (pixel prow [+32], channel quarter q of the slab)
+    const int q = tid & 7, prow = tid >> 3;
+    const unsigned cin4 = 4u * (unsigned)p.Cin, wcin4 = cin4 * (unsigned)sg.W;   // byte steps to the right / lower pixel
+    // corners are fetched with buffer loads: uniform resource (base, size) + one 32-bit byte offset per lane -- no 64-bit address
+    // VALU, and (unlike flat loads) nothing that the LDS wait counter has to wait for
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    const unsigned st0 = (unsigned)(q * DF_BM + (prow ^ (2 * q))), st1 = (unsigned)(q * DF_BM + ((prow + 32) ^ (2 * q)));
+    // fragment units of step h: quarter 2h + lhalf, rows l32 (block 0) and 32 + l32 (block 1)
+    // B: lane's float4 of global step g = 4 s + h sits at wbase + g * 1024 + lhalf * 512 + l32 * 16
+    const int cb = 4 * n_t + wave;
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)cb * (size_t)nsl * 4096u;
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 4096, 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
+    const int gmax = nsl * 4 - 1;
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    float4 xc00, xc01, xc02, xc03, xc10, xc11, xc12, xc13;   // register set X: [pixel][corner]
+    float4 yc00, yc01, yc02, yc03, yc10, yc11, yc12, yc13;   // register set Y
+    float4 breg[DF_RING];
+    int f_cs = 0, f_tap = 0;                                   // (channel slab, tap) of the NEXT step to fetch
+
+#define DF_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define DF_FETCH_PX(P, R, PX)                                                                                          \
+    {                                                                                                                  \
+        const unsigned dx_ = dsc[f_tap * DF_BM + (PX)].x;                                                              \
+        const unsigned o1_ = (dx_ & ~127u) + (unsigned)(f_cs * 128 + q * 16);                                          \
+        const unsigned oR_ = o1_ + ((dx_ & 16u) ? cin4 : 0u), oD_ = o1_ + ((dx_ & 32u) ? wcin4 : 0u);                  \
+        DF_LDX(P##c##R##0, o1_) DF_LDX(P##c##R##1, oR_) DF_LDX(P##c##R##2, oD_) DF_LDX(P##c##R##3, oD_ + (oR_ - o1_)) \
+    }
+#define DF_FETCH(P)                                                                                                    \
+    {                                                                                                                  \
+        DF_FETCH_PX(P, 0, prow) DF_FETCH_PX(P, 1, prow + 32)                                                           \
+        if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                                    \
+    }
+    // blend pixel R of register set P (sampled for tap TAP) and write its 4-channel unit into A buffer BUF
+#define DF_STASH_PX(P, R, PX, UNIT, TAP, BUF)                                                                          \
+    {                                                                                                                  \
+        const uintx4 d_ = dsc[(TAP) * DF_BM + (PX)];                                                                   \
+        const float lh_ = __uint_as_float(d_.y), lw_ = __uint_as_float(d_.z);                                          \
+        const float hh_ = 1.0f - lh_, hw_ = 1.0f - lw_;                                                                \
+        const float w1_ = hh_ * hw_, w2_ = hh_ * lw_, w3_ = lh_ * hw_, w4_ = lh_ * lw_;                                \
+        float4 v_;                                                                                                     \
+        v_.x = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).x, (P##c##R##1).x, (P##c##R##2).x, (P##c##R##3).x);     \
+        v_.y = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).y, (P##c##R##1).y, (P##c##R##2).y, (P##c##R##3).y);     \
+        v_.z = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).z, (P##c##R##1).z, (P##c##R##2).z, (P##c##R##3).z);     \
+        v_.w = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).w, (P##c##R##1).w, (P##c##R##2).w, (P##c##R##3).w);     \
+        if (MOD) { const float m_ = __uint_as_float(d_.w); v_.x = v_.x * m_; v_.y = v_.y * m_; v_.z = v_.z * m_; v_.w = v_.w * m_; } \
+        As[(BUF) * DF_ABUF + (UNIT)] = v_;                                                                             \
+    }
+#define DF_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 1024u, 0); \
+        breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define DF_FRAG(BUF, H, A0, A1)                                                                                        \
+    {                                                                                                                  \
+        const int q_ = 2 * (H) + lhalf;                                                                                \
+        A0 = As[(BUF) * DF_ABUF + q_ * DF_BM + (l32 ^ (2 * q_))];                                                      \
+        A1 = As[(BUF) * DF_ABUF + q_ * DF_BM + ((32 + l32) ^ (2 * q_))];                                               \
+    }
+    // One K step s (buffer BUF holds its blended A tile). Tap index of step s+1 (the one being stashed) is passed as STAP.
+    //   u = 0: gather of step s+2 into FSET;  u = 1, 2: blend + stash of step s+1 (SSET) into the other buffer;
+    //   u = 3: barrier, then the first fragments of step s+1;  every u: ring refill, next fragments, 8 MFMAs.
+#define DF_STEP(BUF, FSET, SSET, DO_FETCH, DO_STASH, STAP)                                                             \
+    {                                                                                                                  \
+        const bool do_fetch_ = (DO_FETCH), do_stash_ = (DO_STASH);                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                \
+            float4 n0_, n1_;                                                                                           \
+            if (u == 0 && do_fetch_) DF_FETCH(FSET)                                                                    \
+            if (u < 3) DF_FRAG(BUF, u + 1, n0_, n1_)                                                                   \
+            if (u == 1 && do_stash_) DF_STASH_PX(SSET, 0, prow, st0, STAP, (BUF) ^ 1)                                  \
+            if (u == 2 && do_stash_) DF_STASH_PX(SSET, 1, prow + 32, st1, STAP, (BUF) ^ 1)                             \
+            if (u == 3) { __syncthreads(); DF_FRAG((BUF) ^ 1, 0, n0_, n1_) }                                           \
+            const float4 bf_ = breg[u];                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf_.y, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);                                   \
+            DF_BLOAD(u, g + 4 + u)                                                                                     \
+            a0 = n0_; a1 = n1_;                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                              \
+        g += 4;                                                                                                        \
+    }
+
+    __syncthreads();   // descriptor table complete
+    // ---- prologue: step 0 -> buffer 0 (set X), gather of step 1 in flight (set Y), first ring of B fragments
+    DF_FETCH(x)
+#pragma unroll
+    for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, u)
+    if (SETS == 2 && nsl > 1) DF_FETCH(y)
+    DF_STASH_PX(x, 0, prow, st0, 0, 0)
+    DF_STASH_PX(x, 1, prow + 32, st1, 0, 0)
+    __syncthreads();
+    float4 a0, a1;
+    DF_FRAG(0, 0, a0, a1)
+    int g = 0;
+    int s_tap = ntap > 1 ? 1 : 0;   // tap of step s+1
+    if (SETS == 2) {
+        for (int s = 0; s < nsl; s += 2) {
+            DF_STEP(0, x, y, s + 2 < nsl, s + 1 < nsl, s_tap)
+            if (++s_tap == ntap) s_tap = 0;
+            if (s + 1 >= nsl) break;
+            DF_STEP(1, y, x, s + 3 < nsl, s + 2 < nsl, s_tap)
+            if (++s_tap == ntap) s_tap = 0;
+        }
+    } else {
+        for (int s = 0; s < nsl; s += 2) {
+            DF_STEP(0, x, x, s + 1 < nsl, s + 1 < nsl, s_tap)
+            if (++s_tap == ntap) s_tap = 0;
+            if (s + 1 >= nsl) break;
+            DF_STEP(1, x, x, s + 2 < nsl, s + 2 < nsl, s_tap)
+            if (++s_tap == ntap) s_tap = 0;
+        }
+    }
+#undef DF_LDX
+#undef DF_FETCH_PX
+#undef DF_FETCH
+#undef DF_STASH_PX
+#undef DF_BLOAD
+#undef DF_FRAG
+#undef DF_STEP
+
+    // ---- epilogue: + bias, ReLU, NHWC store. Accumulator element r of lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3),
+    // column l32 of the 32x32 block
+    const int co = 32 * cb + l32;
+    const bool co_ok = co < p.Cout;
+    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long pbase = p0 + 32 * i + 4 * lhalf;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long pp = pbase + (r & 3) + 8 * (r >> 2);
+            float v = i == 0 ? acc0[r] : acc1[r];
+            v = v + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+        }
+    }
+}
+
+// development knob for A/B runs: 1 = one corner set at 3 waves / SIMD (default), 2 = two sets at 2 waves / SIMD,
+// 3 = one set at 4, 0 = two sets at 3 (the last two spill: kept for measurements only)
+static int g_dcn_variant = 1;
+extern "C" void upsnet_dcn_tuning(int variant) { g_dcn_variant = variant; }
+
+extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                             const float *const mask[], float *const out[], const int height[], const int width[],
+                                             int cin, int cout, int kh, int kw, int pad, int stride, int dil, const float *wpack,
+                                             const float *bias, int relu)
+{
+    UPS_REQUIRE(nlev >= 1 && nlev <= 4 && offset, "deform_conv_fused_nhwc: nlev must be 1..4 and offsets given");
+    for (int l = 0; l < nlev; ++l) UPS_REQUIRE(offset[l] && (!mask || mask[l]), "deform_conv_fused_nhwc: null offset/mask at level %d", l);
+    UPS_REQUIRE(kh * kw >= 1 && kh * kw <= 25, "deform_conv_fused_nhwc: at most 25 taps (got %dx%d)", kh, kw);
+    ConvParams p;
+    const int ldw = (cout + 31) / 32 * 32;
+    int rc = conv_fill(p, "deform_conv_fused_nhwc", nlev, x, nullptr, offset, mask, out, nullptr, height, width, cin, cout, wpack, ldw, bias,
+                       kh, kw, stride, pad, dil, relu);
+    if (rc) return rc;
+    int tiles = 0;
+    for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + DF_BM - 1) / DF_BM); }
+    p.m_tiles = tiles;
+    p.n_tiles = (cout + DF_BN - 1) / DF_BN;
+    const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * 16;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    const int v = g_dcn_variant;
+#define DF_LAUNCH(SETS, WPE)                                                                                           \
+    if (mask) hipLaunchKernelGGL((dcn_fused_f32_kernel<true, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p); \
+    else hipLaunchKernelGGL((dcn_fused_f32_kernel<false, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else if (v == 3) { DF_LAUNCH(1, 4) } else { DF_LAUNCH(2, 3) }
+#undef DF_LAUNCH
+    UPS_CHECK_LAUNCH("dcn_fused_f32_kernel");
+    return 0;
+}

@@ -4,6 +4,8 @@ Every function here launches hand-written HIP kernels from libupsnet_hip.so on t
 stream. Nothing falls back to PyTorch/CPU; non-CUDA inputs raise (as the reference's Functions do,
 functions/deform_conv.py:40-41, functions/roialign.py:34-35).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -168,9 +170,32 @@ def roi_align_backward(pooled_h, pooled_w, sampling_ratio, spatial_scale, top_gr
     return 1
 
 
-def pack_dcn_weight(weight):
-    """[Cout,Cin,kh,kw] -> (wpack [kh*kw*Cin, ldw], ldw): same packing as the dense convolution."""
+# Deformable-convolution kernel generation: 'frag' = csrc/deform_fused.hip (default), 'igemm' = the first-generation loader mode of
+# the dense kernel (csrc/conv.hip), kept for A/B measurements and for geometries the new kernel does not take.
+DCN_KERNEL = os.environ.get('UPSNET_DCN_KERNEL', 'frag')
+
+
+def pack_dcn_weight(weight, kind=None):
+    """[Cout,Cin,kh,kw] -> packed weight for deform_conv_fused: ('frag', wp) in MFMA fragment order for csrc/deform_fused.hip, or
+    (wpack [kh*kw*Cin, ldw], ldw) -- the dense convolution's packing -- for the first-generation kernel."""
+    kind = kind or DCN_KERNEL
+    cout, cin, kh, kw = weight.shape
+    if kind == 'frag' and cin % 32 == 0 and kh * kw <= 25:
+        w = f32c(weight)
+        wp = torch.empty((lib().upsnet_dcn_packed_weight_floats(cout, cin, kh, kw),), dtype=torch.float32, device=w.device)
+        check(lib().upsnet_dcn_pack_weight(stream(), ptr(w), cout, cin, kh, kw, ptr(wp)), "dcn_pack_weight")
+        return ('frag', wp)
     return pack_conv_weight(weight)
+
+
+def cached_dcn_pack(weight):
+    """Packed deformable-convolution weight cached ON the weight tensor (re-packed when it changes or moves)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL)
+    ent = weight.__dict__.get('_ups_dcn_pack')
+    if ent is None or ent[0] != key:
+        ent = (key, pack_dcn_weight(weight.detach()))
+        weight.__dict__['_ups_dcn_pack'] = ent
+    return ent[1]
 
 
 def fused_dcn_supported(cin, cout, deformable_groups, groups):
@@ -185,8 +210,8 @@ def _nhwc_out(n, c, h, w, device):
 def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, dil, masks=None, relu=False):
     """Fused deformable conv over up to 4 maps sharing weights. xs/offsets/masks: lists of logical NCHW
     tensors with batch 1; wpack = (packed weight, ldw) from pack_dcn_weight; returns channels_last outputs."""
-    wp, ldw = wpack
-    require_cuda(wp, *xs)
+    wp, ldw = wpack     # ('frag', packed) or (packed, ldw)
+    require_cuda(ldw if isinstance(wp, str) else wp, *xs)
     n = len(xs)
     assert 1 <= n <= 4 and len(offsets) == n
     xs = [nhwc(x.float()) for x in xs]
@@ -205,12 +230,21 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().upsnet_deform_conv_forward_nhwc(stream(), n, ptr_array(xs), ptr_array(offsets),
-                                                ptr_array(masks) if masks is not None else None, ptr_array(outs),
-                                                int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
-                                                int(cin), int(cout), ksize[0], ksize[1], pad[0], pad[1], stride[0], stride[1],
-                                                dil[0], dil[1], 1, ptr(wp), int(ldw), ptr(b), int(bool(relu))),
-          "deform_conv_forward_nhwc")
+    if wp == 'frag':   # (kind, packed) from pack_dcn_weight: second-generation kernel
+        if not (pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]):
+            raise RuntimeError("deform_conv_fused: square pad / stride / dilation only")
+        check(lib().upsnet_deform_conv_fused_nhwc(stream(), n, ptr_array(xs), ptr_array(offsets),
+                                                  ptr_array(masks) if masks is not None else None, ptr_array(outs),
+                                                  int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
+                                                  int(cin), int(cout), ksize[0], ksize[1], pad[0], stride[0], dil[0], ptr(ldw), ptr(b),
+                                                  int(bool(relu))), "deform_conv_fused_nhwc")
+    else:
+        check(lib().upsnet_deform_conv_forward_nhwc(stream(), n, ptr_array(xs), ptr_array(offsets),
+                                                    ptr_array(masks) if masks is not None else None, ptr_array(outs),
+                                                    int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
+                                                    int(cin), int(cout), ksize[0], ksize[1], pad[0], pad[1], stride[0], stride[1],
+                                                    dil[0], dil[1], 1, ptr(wp), int(ldw), ptr(b), int(bool(relu))),
+              "deform_conv_forward_nhwc")
     if PROFILE['enabled']:
         ev1.record()
         npix = sum(o.shape[2] * o.shape[3] for o in outs)
