@@ -12,13 +12,14 @@
 //   * K is walked CHANNEL SLAB outermost, tap innermost: for 32 channels (one 128-byte line per pixel) all kh*kw taps follow
 //     each other. The corners of neighbouring taps coincide or are adjacent, so a line is re-used out of L1 / L2 eight slabs
 //     later at most (working set per workgroup and slab: ~3 rows x 66 pixels x 128 B = 25 KiB).
-//   * The per-(pixel, tap) sampling descriptors -- corner address, validity bits, the two bilinear fractions (and the v2
-//     modulation) computed with the reference's exact fp32 arithmetic -- are built ONCE per workgroup into an LDS table
-//     (16 B x 64 pixels x taps) instead of living in registers / being recomputed per tap: no spills, and the slab-outer walk
-//     costs one ds_read_b128 per pixel and slab.
+//   * The per-(pixel, tap) sampling data -- the four corner addresses (out-of-image corners point beyond the buffer, where a
+//     buffer load returns the reference's 0), the four bilinear weights (and the v2 modulation), computed with the reference's
+//     exact fp32 expressions -- are built ONCE per workgroup into an LDS table (36 B x 64 pixels x taps) instead of living in
+//     registers / being recomputed per tap and channel: no spills, no validity selects, and the slab-outer walk costs two
+//     ds_read_b128 per pixel and step.
 //   * The B operand (weights) never touches LDS: packed in MFMA fragment order it is one 16-byte buffer load per lane and step,
 //     prefetched four steps ahead in a register ring (as conv_wino.hip). LDS holds only the blended A tile (2 x 8 KiB) and the
-//     table, so occupancy is set by registers alone (3 workgroups / CU) and two register sets of corners are in flight: the
+//     table (34 KiB for 3x3), so occupancy is set by registers alone (3 workgroups / CU) and two register sets of corners are in flight: the
 //     gather of slab s+2 is issued while slab s+1 is blended and slab s is contracted.
 // Tile: 64 output pixels x 128 output channels per workgroup (4 waves; wave w owns column block w and both 32-row blocks), fp32
 // products and accumulation on v_mfma_f32_32x32x2_f32 in a fixed order (bit-repeatable). Epilogue: + bias, ReLU, NHWC store.
@@ -66,22 +67,6 @@ extern "C" int upsnet_dcn_pack_weight(void *stream, const float *weight, int cou
     return 0;
 }
 
-// one bilinear blend with the reference's expression order (deform_conv_kernel.cu:88-118): w1*v1 + w2*v2 + w3*v3 + w4*v4 left to
-// right, corners outside the image contribute 0; v2: times the modulation (mod_deform_conv_kernel.cu:245).
-__device__ static inline float df_blend(const unsigned vb, const float w1, const float w2, const float w3, const float w4, float v1,
-                                        float v2, float v3, float v4)
-{
-    v1 = (vb & 1u) ? v1 : 0.f;
-    v2 = (vb & 2u) ? v2 : 0.f;
-    v3 = (vb & 4u) ? v3 : 0.f;
-    v4 = (vb & 8u) ? v4 : 0.f;
-    float val = w1 * v1;
-    val = val + w2 * v2;
-    val = val + w3 * v3;
-    val = val + w4 * v4;
-    return val;
-}
-
 // SETS: corner register sets in flight (2: the gather of step s+2 overlaps the blend of step s+1; 1: one step of lookahead);
 // WPE: waves per SIMD the register budget is set for.
 template <bool MOD, int SETS, int WPE>
@@ -89,7 +74,11 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *As = reinterpret_cast<float4 *>(smem_raw);                       // [2][8 q][64 px ^ 2q]
-    uintx4 *dsc = reinterpret_cast<uintx4 *>(smem_raw + 2 * DF_ABUF * 16);   // [tap][64 px]: (corner byte offset | vb, lh, lw, m)
+    // sampling table [tap][64 px]: byte offsets of the 4 corners' channel vectors (bit 31 set = outside the image: the buffer load
+    // then returns 0, the value the reference substitutes), the 4 bilinear weights, v2: the modulation
+    uintx4 *dsc_o = reinterpret_cast<uintx4 *>(smem_raw + 2 * DF_ABUF * 16);
+    float4 *dsc_w = reinterpret_cast<float4 *>(dsc_o + p.KH * p.KW * DF_BM);
+    float *dsc_m = reinterpret_cast<float *>(dsc_w + p.KH * p.KW * DF_BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lhalf = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles (vertically adjacent
@@ -115,44 +104,51 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const int nsl = cslabs * ntap;                 // (channel slab, tap) steps of the K walk, tap innermost
     const long HoWo = (long)sg.Ho * sg.Wo;
 
-    // ---- sampling descriptors of this tile, once: deform_conv_kernel.cu:227-240 (positions), :88-118 (corners, fractions)
-    for (int idx = tid; idx < ntap * DF_BM; idx += 256) {
-        const int tap = idx >> 6, px = idx & 63;
-        const long pp = p0 + px;
-        uintx4 d;
-        d.x = 0u; d.y = 0u; d.z = 0u; d.w = __float_as_uint(1.0f);
-        if (pp < sg.M) {
-            const int n = (int)(pp / HoWo);
-            const int rem = (int)(pp - (long)n * HoWo);
-            const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
-            const int ki = tap / p.KW, kj = tap - ki * p.KW;
-            const int h_base = ho * p.stride - p.pad + ki * p.dil, w_base = wo * p.stride - p.pad + kj * p.dil;
-            const float off_h = sg.off[pp * (2 * ntap) + 2 * tap];
-            const float off_w = sg.off[pp * (2 * ntap) + 2 * tap + 1];
-            const float h_im = (float)h_base + off_h;   // integer part converted to float before the add (:227-228)
-            const float w_im = (float)w_base + off_w;
-            const int H = sg.H, W = sg.W;
-            unsigned pix = (unsigned)(n * H * W);
-            if (h_im > -1 && w_im > -1 && h_im < (float)H && w_im < (float)W) {
-                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                const int h_high = h_low + 1, w_high = w_low + 1;
-                d.y = __float_as_uint(h_im - (float)h_low);
-                d.z = __float_as_uint(w_im - (float)w_low);
-                const bool a = h_low >= 0, b = h_high <= H - 1, c = w_low >= 0, e = w_high <= W - 1;
-                pix += (unsigned)((a ? h_low : 0) * W + (c ? w_low : 0));
-                // bits 0-3: corner inside the image; bit 4 / 5: the right / lower neighbour is a distinct in-range pixel (otherwise
-                // the clamped pair coincides and the invalid one is masked)
-                d.x = (a && c ? 1u : 0u) | (a && e ? 2u : 0u) | (b && c ? 4u : 0u) | (b && e ? 8u : 0u) | (c && e ? 16u : 0u) | (a && b ? 32u : 0u);
+    // ---- sampling table of this tile, once: deform_conv_kernel.cu:227-240 (positions), :88-118 (corners, weights -- the same fp32
+    // expressions, evaluated here instead of per channel)
+    {
+        const unsigned cin4_ = 4u * (unsigned)p.Cin;
+        for (int idx = tid; idx < ntap * DF_BM; idx += 256) {
+            const int tap = idx >> 6, px = idx & 63;
+            const long pp = p0 + px;
+            uintx4 o;
+            o.x = o.y = o.z = o.w = 0x80000000u;
+            float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+            float m = 1.0f;
+            if (pp < sg.M) {
+                const int n = (int)(pp / HoWo);
+                const int rem = (int)(pp - (long)n * HoWo);
+                const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+                const int ki = tap / p.KW, kj = tap - ki * p.KW;
+                const int h_base = ho * p.stride - p.pad + ki * p.dil, w_base = wo * p.stride - p.pad + kj * p.dil;
+                const float off_h = sg.off[pp * (2 * ntap) + 2 * tap];
+                const float off_w = sg.off[pp * (2 * ntap) + 2 * tap + 1];
+                const float h_im = (float)h_base + off_h;   // integer part converted to float before the add (:227-228)
+                const float w_im = (float)w_base + off_w;
+                const int H = sg.H, W = sg.W;
+                if (h_im > -1 && w_im > -1 && h_im < (float)H && w_im < (float)W) {
+                    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                    const float hh = 1.0f - lh, hw = 1.0f - lw;
+                    wt = make_float4(hh * hw, hh * lw, lh * hw, lh * lw);
+                    const bool a = h_low >= 0, b = h_high <= H - 1, c = w_low >= 0, e = w_high <= W - 1;
+                    const unsigned base = (unsigned)(n * H * W) * cin4_;
+                    if (a && c) o.x = base + (unsigned)(h_low * W + w_low) * cin4_;
+                    if (a && e) o.y = base + (unsigned)(h_low * W + w_high) * cin4_;
+                    if (b && c) o.z = base + (unsigned)(h_high * W + w_low) * cin4_;
+                    if (b && e) o.w = base + (unsigned)(h_high * W + w_high) * cin4_;
+                }
+                if (MOD) m = sg.mask[pp * ntap + tap];
             }
-            d.x |= pix * 4u * (unsigned)p.Cin;           // byte offset of the top-left corner's channel vector: a multiple of 128
-            if (MOD) d.w = __float_as_uint(sg.mask[pp * ntap + tap]);
+            dsc_o[idx] = o;
+            dsc_w[idx] = wt;
+            if (MOD) dsc_m[idx] = m;
         }
-        dsc[idx] = d;
     }
 
     // ---- loader geometry: thread = (pixel prow [+32], channel quarter q of the slab)
     const int q = tid & 7, prow = tid >> 3;
-    const unsigned cin4 = 4u * (unsigned)p.Cin, wcin4 = cin4 * (unsigned)sg.W;   // byte steps to the right / lower pixel
     // corners are fetched with buffer loads: uniform resource (base, size) + one 32-bit byte offset per lane -- no 64-bit address
     // VALU, and (unlike flat loads) nothing that the LDS wait counter has to wait for
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
@@ -180,31 +176,28 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 
 #define DF_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
-#define DF_FETCH_PX(P, R, PX)                                                                                          \
+#define DF_FETCH_PX(P, R, O)                                                                                           \
     {                                                                                                                  \
-        const unsigned dx_ = dsc[f_tap * DF_BM + (PX)].x;                                                              \
-        const unsigned o1_ = (dx_ & ~127u) + (unsigned)(f_cs * 128 + q * 16);                                          \
-        const unsigned oR_ = o1_ + ((dx_ & 16u) ? cin4 : 0u), oD_ = o1_ + ((dx_ & 32u) ? wcin4 : 0u);                  \
-        DF_LDX(P##c##R##0, o1_) DF_LDX(P##c##R##1, oR_) DF_LDX(P##c##R##2, oD_) DF_LDX(P##c##R##3, oD_ + (oR_ - o1_)) \
+        const unsigned c_ = (unsigned)(f_cs * 128 + q * 16);                                                           \
+        DF_LDX(P##c##R##0, (O).x + c_) DF_LDX(P##c##R##1, (O).y + c_) DF_LDX(P##c##R##2, (O).z + c_) DF_LDX(P##c##R##3, (O).w + c_) \
     }
+    // gather of the step whose corner offsets were pre-read into no0 / no1; then pre-read the offsets of the step after it
 #define DF_FETCH(P)                                                                                                    \
     {                                                                                                                  \
-        DF_FETCH_PX(P, 0, prow) DF_FETCH_PX(P, 1, prow + 32)                                                           \
+        DF_FETCH_PX(P, 0, no0) DF_FETCH_PX(P, 1, no1)                                                                  \
         if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                                    \
     }
+#define DF_NEXT_OFFSETS { no0 = dsc_o[f_tap * DF_BM + prow]; no1 = dsc_o[f_tap * DF_BM + prow + 32]; }
     // blend pixel R of register set P (sampled for tap TAP) and write its 4-channel unit into A buffer BUF
 #define DF_STASH_PX(P, R, PX, UNIT, TAP, BUF)                                                                          \
     {                                                                                                                  \
-        const uintx4 d_ = dsc[(TAP) * DF_BM + (PX)];                                                                   \
-        const float lh_ = __uint_as_float(d_.y), lw_ = __uint_as_float(d_.z);                                          \
-        const float hh_ = 1.0f - lh_, hw_ = 1.0f - lw_;                                                                \
-        const float w1_ = hh_ * hw_, w2_ = hh_ * lw_, w3_ = lh_ * hw_, w4_ = lh_ * lw_;                                \
+        const float4 w_ = dsc_w[(TAP) * DF_BM + (PX)];                                                                 \
         float4 v_;                                                                                                     \
-        v_.x = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).x, (P##c##R##1).x, (P##c##R##2).x, (P##c##R##3).x);     \
-        v_.y = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).y, (P##c##R##1).y, (P##c##R##2).y, (P##c##R##3).y);     \
-        v_.z = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).z, (P##c##R##1).z, (P##c##R##2).z, (P##c##R##3).z);     \
-        v_.w = df_blend(d_.x, w1_, w2_, w3_, w4_, (P##c##R##0).w, (P##c##R##1).w, (P##c##R##2).w, (P##c##R##3).w);     \
-        if (MOD) { const float m_ = __uint_as_float(d_.w); v_.x = v_.x * m_; v_.y = v_.y * m_; v_.z = v_.z * m_; v_.w = v_.w * m_; } \
+        v_.x = ((w_.x * (P##c##R##0).x + w_.y * (P##c##R##1).x) + w_.z * (P##c##R##2).x) + w_.w * (P##c##R##3).x;      \
+        v_.y = ((w_.x * (P##c##R##0).y + w_.y * (P##c##R##1).y) + w_.z * (P##c##R##2).y) + w_.w * (P##c##R##3).y;      \
+        v_.z = ((w_.x * (P##c##R##0).z + w_.y * (P##c##R##1).z) + w_.z * (P##c##R##2).z) + w_.w * (P##c##R##3).z;      \
+        v_.w = ((w_.x * (P##c##R##0).w + w_.y * (P##c##R##1).w) + w_.z * (P##c##R##2).w) + w_.w * (P##c##R##3).w;      \
+        if (MOD) { const float m_ = dsc_m[(TAP) * DF_BM + (PX)]; v_.x = v_.x * m_; v_.y = v_.y * m_; v_.z = v_.z * m_; v_.w = v_.w * m_; } \
         As[(BUF) * DF_ABUF + (UNIT)] = v_;                                                                             \
     }
 #define DF_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 1024u, 0); \
@@ -239,6 +232,7 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);                                   \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);                                   \
             DF_BLOAD(u, g + 4 + u)                                                                                     \
+            if (u == 3 && do_fetch_) DF_NEXT_OFFSETS                                                                   \
             a0 = n0_; a1 = n1_;                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
         }                                                                                                              \
@@ -247,10 +241,13 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 
     __syncthreads();   // descriptor table complete
     // ---- prologue: step 0 -> buffer 0 (set X), gather of step 1 in flight (set Y), first ring of B fragments
+    uintx4 no0, no1;                                           // corner offsets of the next step to fetch (pre-read from the table)
+    DF_NEXT_OFFSETS
     DF_FETCH(x)
 #pragma unroll
     for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, u)
-    if (SETS == 2 && nsl > 1) DF_FETCH(y)
+    DF_NEXT_OFFSETS
+    if (SETS == 2 && nsl > 1) { DF_FETCH(y) DF_NEXT_OFFSETS }
     DF_STASH_PX(x, 0, prow, st0, 0, 0)
     DF_STASH_PX(x, 1, prow + 32, st1, 0, 0)
     __syncthreads();
@@ -320,11 +317,13 @@ extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float
     int rc = conv_fill(p, "deform_conv_fused_nhwc", nlev, x, nullptr, offset, mask, out, nullptr, height, width, cin, cout, wpack, ldw, bias,
                        kh, kw, stride, pad, dil, relu);
     if (rc) return rc;
+    for (int i = 0; i < p.nseg; ++i)   // bit 31 of a corner offset flags "outside the image": offsets of real pixels must stay below it
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * cin < (1L << 29), "deform_conv_fused_nhwc: feature map %d exceeds 2 GiB; split the batch", i);
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + DF_BM - 1) / DF_BM); }
     p.m_tiles = tiles;
     p.n_tiles = (cout + DF_BN - 1) / DF_BN;
-    const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * 16;
+    const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * (16 + 16 + 4);
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
     const int v = g_dcn_variant;
 #define DF_LAUNCH(SETS, WPE)                                                                                           \
