@@ -246,6 +246,16 @@ void upsnet_conv_tuning(int winograd_tiles, int force_tile);
 /* weight [Cout, Cin, kh, kw] (nn.Conv2d layout) -> wpack [kh*kw*Cin, ldw] (tap-major rows, zero-padded columns). */
 int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, float *wpack);
 
+/* 1x1 convolution (stride 1 / 2) as a lean fp32 MFMA GEMM (csrc/conv1x1.hip): the 1x1 layers of the ResNet bottlenecks
+ * (upsnet/models/resnet.py:53-100: conv1 / conv3 / downsample) and the FPN laterals with their top-down add (fpn.py:78-104).
+ * out = relu?(conv1x1(x; stride) + bias + residual); x [N,H,W,Cin] NHWC, out [N,Ho,Wo,Cout] NHWC (Ho = (H-1)/stride + 1);
+ * residual like out, or -- residual_up != 0 -- [N,Ho/2,Wo/2,Cout] read through a nearest x2 upsampling. Cin % 32 == 0.
+ * wpack: upsnet_dcn_pack_weight(weight [Cout,Cin,1,1], cout, cin, 1, 1) (MFMA fragment order, read straight from L2).
+ * upsnet_conv1x1_tuning: development knob (0 auto, 64 / 128: output channels per workgroup). */
+int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
+                                 int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu, int residual_up);
+void upsnet_conv1x1_tuning(int bn);
+
 /* ============================== NMS ============================== */
 
 /* Drop-in for `_nms` (upsnet/nms/gpu_nms.hpp:15, nms_kernel.cu:97-150): HOST pointers in and out,

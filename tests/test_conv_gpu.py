@@ -41,6 +41,74 @@ def test_conv2d_nhwc_vs_torch(N, Cin, Cout, H, W, k, stride, pad, relu, res, bia
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride,relu,res,bias,bn", [
+    (1, 256, 64, 40, 56, 1, True, None, True, 0),        # res2 conv1 shape family (BN = 64: Cout <= 64)
+    (1, 64, 256, 40, 56, 1, True, 'same', True, 0),      # conv3 + shortcut
+    (1, 256, 512, 41, 57, 2, False, None, True, 0),      # strided downsample, odd size, tail tile
+    (1, 512, 128, 33, 31, 1, True, None, False, 128),
+    (1, 512, 128, 33, 31, 1, True, None, False, 64),
+    (2, 1024, 256, 16, 24, 1, False, 'up', True, 0),     # FPN lateral + top-down add through the nearest x2 upsampling
+    (1, 2048, 256, 16, 16, 1, False, 'up', True, 128),
+    (1, 32, 96, 7, 5, 1, True, 'same', True, 0),         # one K step, Cout not a multiple of 64, map smaller than a tile
+    (3, 96, 160, 9, 9, 2, True, None, True, 128),
+])
+def test_conv1x1_gemm_kernel_vs_torch(N, Cin, Cout, H, W, stride, relu, res, bias, bn):
+    """csrc/conv1x1.hip (the lean fp32 MFMA GEMM the 1x1 layers of the backbone / FPN run on) vs torch float64, 1e-4; its two tile
+    forms agree bit for bit (same K order), and hipconv routes a big enough nn.Conv2d(1x1) through it."""
+    from upsnet_amd import ops
+    from upsnet_amd._lib import lib
+    torch.manual_seed(N + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride)
+    r = None
+    if res == 'same':
+        r = torch.randn_like(ref).float()
+        ref = ref + r.double()
+    elif res == 'up':
+        r = torch.randn(N, Cout, ref.shape[2] // 2, ref.shape[3] // 2, device='cuda')
+        ref = ref + F.interpolate(r.double(), scale_factor=2, mode='nearest')
+    if relu:
+        ref = ref.clamp_min(0)
+    wp = ops.pack_conv1x1_weight(w)
+    outs = []
+    try:
+        for t in ((bn,) if bn else (64, 128)):
+            lib().upsnet_conv1x1_tuning(t)
+            outs.append(ops.conv1x1_frag(x, wp, b, Cout, stride, relu=relu, residual=r, residual_up=(res == 'up')))
+    finally:
+        lib().upsnet_conv1x1_tuning(0)
+    assert outs[0].shape == ref.shape
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    out2 = ops.conv1x1_frag(x.contiguous(memory_format=torch.channels_last), wp, b, Cout, stride, relu=relu, residual=r, residual_up=(res == 'up'))
+    assert torch.equal(out2, outs[-1] if not bn else out2)
+
+
+def test_hipconv_routes_1x1_layers_to_the_gemm_kernel():
+    from upsnet_amd import ops
+    from upsnet_amd.models import hipconv
+    torch.manual_seed(0)
+    m = torch.nn.Conv2d(256, 512, 1, stride=2, bias=True).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(1, 256, 128, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+    small = torch.randn(1, 256, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    assert hipconv._use_conv1x1(m, x) and not hipconv._use_conv1x1(m, small)
+    ops.PROFILE['events'], ops.PROFILE['enabled'] = [], True
+    try:
+        with torch.no_grad():
+            y = hipconv.conv(m, x, relu=True)
+            ys = hipconv.conv(m, small, relu=True)
+    finally:
+        ops.PROFILE['enabled'] = False
+    kinds = [e[5] for e in ops.PROFILE['events']]
+    assert '(gemm)' in kinds[0] and '(gemm)' not in kinds[1], kinds
+    with torch.no_grad():
+        np.testing.assert_allclose(y.cpu().numpy(), F.relu(m(x)).cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ys.cpu().numpy(), F.relu(m(small)).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("S,H,W,nlev,bias", [(19, 32, 64, 4, True), (133, 24, 40, 4, True), (5, 8, 8, 2, False), (19, 16, 16, 1, True)])
 def test_fcn_score_combine_vs_oracle(S, H, W, nlev, bias):
     """Bit-exact vs the C oracle (same expression order, no FMA)."""

@@ -30,6 +30,13 @@ cases = [  # name, Cin, Cout, H, W, k, stride
     ("res4 conv3 1x1 256->1024 @64x128", 256, 1024, 64, 128, 1, 1),
     ("res5 conv2 3x3 512->512 @32x64", 512, 512, 32, 64, 3, 1),
     ("fpn lat 1x1 2048->256 @32x64", 2048, 256, 32, 64, 1, 1),
+    ("fpn lat 1x1 256->256 @256x512", 256, 256, 256, 512, 1, 1),
+    ("res3 conv3 1x1 128->512 @128x256", 128, 512, 128, 256, 1, 1),
+    ("res3 conv1 1x1 512->128 @128x256", 512, 128, 128, 256, 1, 1),
+    ("res4 conv1 1x1 1024->256 @64x128", 1024, 256, 64, 128, 1, 1),
+    ("res3 down 1x1/2 256->512 @256x512", 256, 512, 256, 512, 1, 2),
+    ("res5 conv3 1x1 512->2048 @32x64", 512, 2048, 32, 64, 1, 1),
+    ("res5 conv1 1x1 2048->512 @32x64", 2048, 512, 32, 64, 1, 1),
 ]
 only = os.environ.get('ONLY')
 for name, cin, cout, H, W, k, st in cases:
@@ -42,6 +49,12 @@ for name, cin, cout, H, W, k, st in cases:
     fl = 2.0 * cout * cin * k * k * Ho * Wo
     by = 4.0 * (cin * H * W + cout * Ho * Wo + cout * cin * k * k)
     bench("hip  " + name, lambda: ops.conv2d_nhwc(x, wp, ldw, b, cout, k, st, k // 2, relu=True), fl, by)
+    if k == 1 and cin % 32 == 0 and cout >= 32:
+        wf = ops.pack_conv1x1_weight(w)
+        for t in (64, 128):
+            lib().upsnet_conv1x1_tuning(t)
+            bench("gemm%-3d %s" % (t, name), lambda: ops.conv1x1_frag(x, wf, b, cout, st, relu=True), fl, by)
+        lib().upsnet_conv1x1_tuning(0)
     if not os.environ.get('NOTORCH'):
         wt = w.contiguous(memory_format=torch.channels_last)
         bench("torch " + name, lambda: F.relu(F.conv2d(x, wt, b, stride=st, padding=k // 2)), fl, by)

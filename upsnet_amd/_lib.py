@@ -32,6 +32,8 @@ _SIGNATURES = {
     "upsnet_dcn_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_deform_conv_fused_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 7 + [P, P, c_int]),
     "upsnet_dcn_tuning": (None, [c_int]),
+    "upsnet_conv1x1_frag_nhwc_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int]),
+    "upsnet_conv1x1_tuning": (None, [c_int]),
     "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_tuning": (None, [c_int, c_int]),
     "upsnet_conv_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

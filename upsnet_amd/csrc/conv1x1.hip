@@ -1,0 +1,248 @@
+// conv1x1.hip -- 1x1 convolution (stride 1 / 2) as a lean fp32 MFMA GEMM: out[pixel, co] = sum_c x[pixel, c] * w[co, c].
+//
+// Reference: the 1x1 nn.Conv2d layers of the ResNet bottlenecks (conv1 / conv3 / downsample, upsnet/models/resnet.py:53-100)
+// and the FPN laterals with their top-down add (fpn.py:78-104), each followed by separate frozen-BN / ReLU / add passes.
+//
+// Why a second kernel next to conv_igemm_f32_kernel (conv.hip): per image the 1x1 layers are 36 of the 48 direct launches and
+// ran at 52-65 % of the attainable fp32 MFMA rate (profiles/r05, r06g). The general kernel pays for its generality exactly
+// there: one ds_read_b32 per operand and MFMA (2 LDS reads per MFMA), four ds_write_b32 per staged float4 (the [k][pixel]
+// transposition), B through LDS, ~100 address instructions per tap change. A 1x1 convolution on NHWC needs none of it:
+//   * A: a lane's MFMA fragment is four CONSECUTIVE channels of one pixel = the float4 the loader already holds. It is staged
+//     with one ds_write_b128 into 16-byte units [channel quarter][pixel ^ swizzle] and read back with one ds_read_b128 per four
+//     (BN = 64) or eight (BN = 128) MFMAs -- conflict-free both ways (same layout as deform_fused.hip / conv_wino.hip).
+//   * B never touches LDS: packed in fragment order (upsnet_dcn_pack_weight with kh = kw = 1) it is one 16-byte buffer load per
+//     lane and step from L2, prefetched four steps ahead in a register ring.
+//   * a K step (32 channels) costs a thread 2 global loads + 2 LDS writes; the loads of step s+2 are issued while step s is
+//     contracted (8 registers), pixels beyond the map read as 0 through the buffer bounds check.
+// Tile: 64 pixels x 128 channels (4 waves = 4 column blocks x both row blocks) or 64 x 64 (2 x 2 waves) for Cout <= 64 and for
+// maps with few tiles. Epilogue fused: + bias (folded frozen-BN shift), + residual (optionally read through the FPN's nearest x2
+// upsampling), ReLU, one NHWC store. Fixed accumulation order (bit-repeatable).
+#include "conv_params.h"
+#include "upsnet_hip.h"
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define C1_BM 64
+#define C1_ABUF (8 * C1_BM)   // float4 units of one A buffer: 8 channel quarters x 64 pixels
+#define C1_RING 4
+
+// NW: waves along N (4: BN = 128, every wave owns both 32-row blocks of one column block; 2: BN = 64, waves 2 x 2).
+// RESUP: the residual lives at half resolution and is read through a nearest x2 upsampling (fpn.py:34,90-96).
+template <int NW, bool RESUP>
+__global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvParams p)
+{
+    constexpr int BN = 32 * NW;
+    constexpr int NR = NW == 4 ? 2 : 1;          // 32-row blocks per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *As = reinterpret_cast<float4 *>(smem_raw);   // [2][8 q][64 px ^ 2q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    const int wn = NW == 4 ? wave : (wave >> 1), wm = NW == 4 ? 0 : (wave & 1);
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): contiguous m-tile range per XCD, all n-tiles of an m-tile together
+    int m_t, n_t;
+    {
+        const int nt = p.n_tiles;
+        const int per = (p.m_tiles + 7) >> 3;
+        const int bid = (int)blockIdx.x;
+        const int qq = bid >> 3;
+        n_t = qq % nt;
+        const int local = qq / nt;
+        m_t = (bid & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
+    }
+    const ConvSeg sg = p.seg[0];
+    const long p0 = (long)m_t * C1_BM;
+    const int nsl = p.Cin >> 5;
+    const long HoWo = (long)sg.Ho * sg.Wo;
+
+    // ---- loader geometry: thread = (pixel prow [+32], channel quarter q); byte offset of the pixel's channel vector, bit 31 set
+    // beyond the map (the buffer load then returns 0)
+    const int q = tid & 7, prow = tid >> 3;
+    unsigned po0, po1;
+    {
+        unsigned po[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long pp = p0 + prow + 32 * r;
+            po[r] = 0x80000000u;
+            if (pp < sg.M) {
+                const int n = (int)(pp / HoWo);
+                const int rem = (int)(pp - (long)n * HoWo);
+                const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+                po[r] = (unsigned)((n * sg.H + ho * p.stride) * sg.W + wo * p.stride) * 4u * (unsigned)p.Cin + 16u * (unsigned)q;
+            }
+        }
+        po0 = po[0]; po1 = po[1];
+    }
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    const unsigned st0 = (unsigned)(q * C1_BM + (prow ^ (2 * q))), st1 = (unsigned)(q * C1_BM + ((prow + 32) ^ (2 * q)));
+    // B: lane's float4 of global step g = 4 s + h sits at wbase(cb) + g * 1024 + lhalf * 512 + l32 * 16
+    const int cb = NW * n_t + wn;
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)cb * (size_t)nsl * 4096u;
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 4096, 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
+    const int gmax = nsl * 4 - 1;
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float4 xa0, xa1;          // staged pixels of the K step in flight
+    float4 breg[C1_RING];
+
+#define C1_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define C1_FETCH(S) { const unsigned c_ = (unsigned)(S) * 128u; C1_LDX(xa0, po0 + c_) C1_LDX(xa1, po1 + c_) }
+#define C1_STASH(BUF) { As[(BUF) * C1_ABUF + st0] = xa0; As[(BUF) * C1_ABUF + st1] = xa1; }
+#define C1_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 1024u, 0); \
+        breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define C1_FRAG(BUF, H, A0, A1)                                                                                        \
+    {                                                                                                                  \
+        const int q_ = 2 * (H) + lhalf;                                                                                \
+        A0 = As[(BUF) * C1_ABUF + q_ * C1_BM + ((32 * wm + l32) ^ (2 * q_))];                                          \
+        if (NR == 2) A1 = As[(BUF) * C1_ABUF + q_ * C1_BM + ((32 + l32) ^ (2 * q_))];                                  \
+    }
+
+    // ---- prologue: step 0 -> buffer 0, step 1 in flight, first ring of B fragments
+    C1_FETCH(0)
+#pragma unroll
+    for (int u = 0; u < C1_RING; ++u) C1_BLOAD(u, u)
+    C1_STASH(0)
+    if (nsl > 1) C1_FETCH(1)
+    __syncthreads();
+    float4 a0, a1;
+    C1_FRAG(0, 0, a0, a1)
+    int g = 0;
+    for (int s = 0; s < nsl; ++s) {
+        const int cur = s & 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 n0_, n1_;
+            if (u < 3) C1_FRAG(cur, u + 1, n0_, n1_)
+            if (u == 1 && s + 1 < nsl) C1_STASH(cur ^ 1)                 // step s+1 (fetched during step s-1)
+            if (u == 2 && s + 2 < nsl) C1_FETCH(s + 2)
+            if (u == 3) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
+            const float4 bf_ = breg[u];
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
+            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);
+            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf_.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);
+            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);
+            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);
+            C1_BLOAD(u, g + 4 + u)
+            a0 = n0_;
+            if (NR == 2) a1 = n1_;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        g += 4;
+    }
+#undef C1_LDX
+#undef C1_FETCH
+#undef C1_STASH
+#undef C1_BLOAD
+#undef C1_FRAG
+
+    // ---- epilogue: + bias, + residual (RESUP: through the nearest x2 upsampling), ReLU, NHWC store. Accumulator element r of
+    // lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3), column l32 of the 32x32 block
+    const int co = 32 * cb + l32;
+    const bool co_ok = co < p.Cout;
+    const int coc = co_ok ? co : 0;
+    const float bv = p.bias != nullptr ? p.bias[coc] : 0.f;
+    const bool has_res = sg.res != nullptr;
+    const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const long pbase = p0 + 32 * (NR == 2 ? i : wm) + 4 * lhalf;
+        float rr[16];
+        if (has_res) {
+            long ridx[16];
+            if (RESUP) {
+                const long pb = pbase < sg.M ? pbase : sg.M - 1;
+                const int n_b = (int)(pb / HoWo);
+                const int rem_b = (int)(pb - (long)n_b * HoWo);
+                const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+                const bool fast = sg.Wo >= 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    int n = n_b, h = h_b, w = w_b;
+                    if (pbase + off < sg.M) {
+                        if (fast) {
+                            w += off;
+                            if (w >= sg.Wo) { w -= sg.Wo; ++h; }
+                            if (h >= sg.Ho) { h -= sg.Ho; ++n; }
+                        } else {
+                            const long pp = pbase + off;
+                            n = (int)(pp / HoWo);
+                            const int rem = (int)(pp - (long)n * HoWo);
+                            h = rem / sg.Wo; w = rem - h * sg.Wo;
+                        }
+                    }
+                    ridx[r] = ((long)n * Hr + (h >> 1)) * Wr + (w >> 1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long pp = pbase + (r & 3) + 8 * (r >> 2);
+                pp = pp < sg.M ? pp : sg.M - 1;
+                rr[r] = sg.res[(RESUP ? ridx[r] : pp) * p.Cout + coc];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long pp = pbase + (r & 3) + 8 * (r >> 2);
+            float v = i == 0 ? acc0[r] : acc1[r];
+            if (p.bias != nullptr) v = v + bv;
+            if (has_res) v = v + rr[r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+        }
+    }
+}
+
+// development knob: 0 auto, 64 / 128 forced BN
+static int g_c1_bn = 0;
+extern "C" void upsnet_conv1x1_tuning(int bn) { g_c1_bn = bn; }
+
+/* out = relu?(conv1x1(x, w; stride) + bias + residual). x [N,H,W,Cin] NHWC, out [N,Ho,Wo,Cout] NHWC, residual like out, or -- with
+ * residual_up -- [N,Ho/2,Wo/2,Cout] read through a nearest x2 upsampling. wpack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). */
+extern "C" int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const float *residual, float *out, int batch, int height,
+                                            int width, int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu,
+                                            int residual_up)
+{
+    const float *xs[1] = {x}, *rs[1] = {residual};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    const int ldw = (Cout + 31) / 32 * 32;
+    int rc = conv_fill(p, "conv1x1_frag_nhwc_f32", 1, xs, residual ? rs : nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias,
+                       1, 1, stride, 0, 1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "conv1x1_frag_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    if (residual_up) {
+        UPS_REQUIRE(residual, "conv1x1_frag_nhwc_f32: residual_up without a residual");
+        UPS_REQUIRE(p.seg[0].Ho % 2 == 0 && p.seg[0].Wo % 2 == 0, "conv1x1_frag_nhwc_f32: residual_up needs even output dims");
+    }
+    p.seg[0].tile_start = 0;
+    p.m_tiles = (int)((p.seg[0].M + C1_BM - 1) / C1_BM);
+    // BN = 128 halves the A traffic per output and doubles the MFMAs per LDS fragment; BN = 64 for narrow layers and for maps whose
+    // 128-wide tiling would leave CUs idle (fewer than 2 workgroups per CU)
+    int bn = g_c1_bn;
+    if (!bn) bn = (Cout > 64 && (long)p.m_tiles * ((Cout + 127) / 128) >= 512) ? 128 : 64;
+    if (Cout <= 64) bn = 64;
+    p.n_tiles = (Cout + bn - 1) / bn;
+    const size_t smem = (size_t)2 * C1_ABUF * 16;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+#define C1_LAUNCH(NW, RU) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<NW, RU>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p)
+    if (bn == 128) { if (residual_up) C1_LAUNCH(4, true); else C1_LAUNCH(4, false); }
+    else { if (residual_up) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
+#undef C1_LAUNCH
+    UPS_CHECK_LAUNCH("conv1x1_frag_f32_kernel");
+    return 0;
+}

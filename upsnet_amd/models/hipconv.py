@@ -21,6 +21,10 @@ ENABLED = True
 WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_WORKGROUPS = int(os.environ.get('UPSNET_WINOGRAD_MIN_WG', '128'))
 SPLITK = os.environ.get('UPSNET_SPLITK', '1') != '0'
+# 1x1 convolutions (stride 1 / 2) with >= CONV1X1_MIN_WG workgroups of 64 pixels x 64 channels go through the lean GEMM kernel
+# (csrc/conv1x1.hip); smaller ones (res5's 2048-pixel maps: split-K) and Cout < 32 heads stay on the general kernel.
+CONV1X1 = os.environ.get('UPSNET_CONV1X1', '1') != '0'
+CONV1X1_MIN_WG = int(os.environ.get('UPSNET_CONV1X1_MIN_WG', '256'))
 # Arithmetic of the dense convolutions: 'fp32' (default; exact fp32 products on the fp32 MFMA, the configuration every headline
 # number is measured on), 'bf16x3' (bf16 matrix cores, 3-term split, fp32-equivalent to ~1e-5) or 'bf16' (BASELINE.json
 # configs[2]: bf16 products, fp32 accumulation). The stem, the deconvolution, the FPN top-down laterals and the deformable
@@ -48,6 +52,25 @@ def _plan(m):
         ent = (key, wp, ldw)
         _plans(m)['direct'] = ent
     return ent[1], ent[2]
+
+
+def _conv1x1_plan(m):
+    w = m.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('c1x1')
+    if ent is None or ent[0] != key:
+        ent = (key, ops.pack_conv1x1_weight(w.detach()))
+        _plans(m)['c1x1'] = ent
+    return ent[1]
+
+
+def _use_conv1x1(m, x):
+    if not (CONV1X1 and tuple(m.kernel_size) == (1, 1) and tuple(m.padding) == (0, 0) and m.stride[0] in (1, 2) and
+            m.in_channels % 32 == 0 and m.out_channels >= 32):
+        return False
+    st = m.stride[0]
+    pix = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
+    return -(-pix // 64) * -(-m.out_channels // 64) >= CONV1X1_MIN_WG
 
 
 def supported(m, x):
@@ -143,6 +166,9 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
                 return ops.conv2d_winograd_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu, residual=residual)
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0]
+        if _use_conv1x1(m, x):
+            return ops.conv1x1_frag(x, _conv1x1_plan(m), m.bias, m.out_channels, m.stride[0], relu=relu, residual=residual,
+                                    residual_up=residual_up)
         wp, ldw = _plan(m)
         ks = 1 if residual_up else _ksplit(m, x, ldw)
         if ks > 1:

@@ -531,6 +531,45 @@ def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, resid
                              residual_up)[0]
 
 
+def pack_conv1x1_weight(weight):
+    """[Cout,Cin,1,1] -> fragment-order pack for conv1x1_frag (csrc/conv1x1.hip; the layout of csrc/deform_fused.hip with one tap)."""
+    require_cuda(weight)
+    w = f32c(weight)
+    cout, cin = w.shape[0], w.shape[1]
+    wp = torch.empty((lib().upsnet_dcn_packed_weight_floats(cout, cin, 1, 1),), dtype=torch.float32, device=w.device)
+    check(lib().upsnet_dcn_pack_weight(stream(), ptr(w), cout, cin, 1, 1, ptr(wp)), "dcn_pack_weight")
+    return wp
+
+
+def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, residual_up=False):
+    """1x1 convolution (stride 1 / 2) on the lean fp32 MFMA GEMM kernel of csrc/conv1x1.hip: out = relu?(conv(x) + bias + residual),
+    residual_up: the residual is at half resolution and is added through a nearest x2 upsampling (FPN top-down path).
+    x: logical NCHW (any batch), returns channels_last [N,Cout,Ho,Wo]."""
+    require_cuda(wpack, x)
+    x = nhwc(x.float())
+    N, cin, H, W = x.shape
+    out = _nhwc_out(N, cout, (H - 1) // stride + 1, (W - 1) // stride + 1, x.device)
+    res = None
+    if residual is not None:
+        res = nhwc(residual.float())
+        want = (N, cout, out.shape[2] // 2, out.shape[3] // 2) if residual_up else tuple(out.shape)
+        if tuple(res.shape) != want or (residual_up and (out.shape[2] % 2 or out.shape[3] % 2)):
+            raise RuntimeError("conv1x1_frag: residual shape %s != %s" % (tuple(res.shape), want))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv1x1_frag_nhwc_f32(stream(), ptr(x), ptr(res), ptr(out), N, H, W, int(cin), ptr(wpack),
+                                             ptr(None if bias is None else f32c(bias)), int(cout), int(stride), int(bool(relu)),
+                                             int(bool(residual_up and res is not None))), "conv1x1_frag_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = out.shape[0] * out.shape[2] * out.shape[3]
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * npix,
+                                  4.0 * (cin * npix + cout * npix * (2 if res is not None else 1) + cout * cin),
+                                  "direct 1x1/%d %d->%d [%s]%s (gemm)" % (stride, cin, cout, tuple(x.shape[0:1] + x.shape[2:]), " +res" if res is not None else "")))
+    return out
+
+
 def fcn_score_combine(parts, bias=None):
     """score = bias + parts[0] + sum_l bilinear_up_{2^l}(parts[l]); parts[l]: logical NCHW [1,S,H>>l,W>>l] (channels_last
     memory). Returns a channels_last [1,S,H,W] tensor (fcn.py:94-100 with the 1x1 conv commuted below the upsampling)."""
