@@ -212,12 +212,16 @@ def test_bf16_matrix_core_convs_end_to_end(setup, precision, min_agree):
     assert agree >= min_agree, agree
 
 
-def test_hip_graph_replay_equals_eager(setup):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_hip_graph_replay_equals_eager(setup, overlap):
     """The static-shape part of the forward (trunk, semantic head on the side stream, proposal / detection chain) is captured as a
     HIP graph on the third image of a shape; replays must equal the eager forward on every output, for changing images of that
-    shape and when another shape is interleaved."""
+    shape and when another shape is interleaved. overlap=False: the purely LINEAR capture (UPSNET_OVERLAP=0) with one and with
+    two instances -- the configuration that faulted on the GPU at replay in r01-r05 (root cause: hipMemsetAsync nodes captured
+    into a linear graph; the forward now zero-fills with kernels, csrc/fill.hip)."""
     from upsnet_amd.synthetic import make_image
     model, _ = setup
+    was_overlap, model.overlap_streams = model.overlap_streams, overlap
     imgs = [make_image(256, 512, seed=11 + j, device='cuda') for j in range(3)] + [make_image(192, 320, seed=20, device='cuda')]
     keys = ('panoptic_outputs', 'pred_boxes', 'cls_probs', 'cls_inds', 'mask_probs', 'panoptic_cls_inds', 'fcn_outputs')
     with torch.no_grad():
@@ -257,6 +261,7 @@ def test_hip_graph_replay_equals_eager(setup):
         pending[1].result()
     model._graphs.clear()
     model.graph_slots = 2
+    model.overlap_streams = was_overlap
 
 
 def test_hip_graph_fallback_when_assumptions_fail(setup):

@@ -30,6 +30,10 @@ int ups_set_error(const char *fmt, ...);
 
 static inline int ups_divup(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) on `st` with an ordinary kernel launch instead of hipMemsetAsync, so that a
+// captured forward consists of kernel nodes only (fill.hip; UPSNET_HIP_MEMSET=1 restores hipMemsetAsync for A/B runs).
+int ups_zero_async(void *ptr, size_t bytes, hipStream_t st);
+
 // Monotonic map float -> uint32 (a < b  <=>  key(a) < key(b)); used to build sortable 64-bit keys.
 __host__ __device__ static inline uint32_t ups_float_key(float f)
 {

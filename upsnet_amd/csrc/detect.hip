@@ -225,7 +225,7 @@ extern "C" int upsnet_mask_roi(void *stream, const float *rois, const float *bbo
     int *csrc = (int *)(ws + m.src), *ccls = (int *)(ws + m.cls), *counts = (int *)(ws + m.counts);
     int *keep = (int *)(ws + m.keep), *keepcnt = (int *)(ws + m.keepcnt), *status = (int *)(ws + m.status);
     hipStream_t st = (hipStream_t)stream;
-    UPS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (ups_zero_async(status, sizeof(int), st)) return 1;
     hipLaunchKernelGGL(mroi_candidates_kernel, dim3(P), dim3(DET_T), 0, st, rois, bbox_delta, cls_prob, num_rois, num_rois_dev,
                        num_classes, im_info, class_agnostic, score_thresh, reg_weights[0], reg_weights[1], reg_weights[2],
                        reg_weights[3], nmax, cboxes, cscores, csrc, ccls, counts, status);

@@ -596,7 +596,7 @@ extern "C" int upsnet_soft_nms_batched(void *stream, float *boxes, int64_t *inds
     UPS_REQUIRE(method >= 0 && method <= 2, "soft_nms_batched: method must be 0 (hard), 1 (linear) or 2 (gaussian)");
     if (P == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (nmax == 0) { UPS_CHECK_HIP(hipMemsetAsync(n_out, 0, (size_t)P * sizeof(int), st)); return 0; }
+    if (nmax == 0) { return ups_zero_async(n_out, (size_t)P * sizeof(int), st); }
     if (nmax <= SNMS_LDS_MAX) {
         const int T = nmax <= 64 * SNMS_KMAX ? 64 : 256;
         const int cap = (nmax + 3) & ~3;

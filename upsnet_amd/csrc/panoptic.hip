@@ -212,9 +212,9 @@ extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const f
     int *sums = (int *)(ws + pl.sums), *sorted_idx = (int *)(ws + pl.sorted);
     uint8_t *kept = ws + pl.kept;
     hipStream_t st = (hipStream_t)stream;
-    UPS_CHECK_HIP(hipMemsetAsync(occ, 0, (size_t)ncls * H * pl.WW * 8, st));
-    UPS_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)m * 4, st));
-    UPS_CHECK_HIP(hipMemsetAsync(kept, 0, (size_t)m, st));
+    if (ups_zero_async(occ, (size_t)ncls * H * pl.WW * 8, st)) return 1;
+    if (ups_zero_async(sums, (size_t)m * 4, st)) return 1;
+    if (ups_zero_async(kept, ((size_t)m + 3) & ~(size_t)3, st)) return 1;   // (its slot is 256-byte aligned and padded)
     hipLaunchKernelGGL(mask_bits_kernel, dim3(m, 32), dim3(256), 0, st, mask_rois, mask_logit, m, m_dev, mask_size, H, W, pl.WW, bits, sums);
     UPS_CHECK_LAUNCH("mask_bits_kernel");
     hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, cls_idx, m, m_dev, H, W, pl.WW,

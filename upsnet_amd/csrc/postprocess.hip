@@ -141,7 +141,7 @@ extern "C" int upsnet_unified_pan_result(void *stream, const int64_t *pan, const
     hipStream_t st = (hipStream_t)stream;
     UniPanWs *ws = (UniPanWs *)workspace;
     const long npix = (long)height * width;
-    UPS_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(UniPanWs), st));
+    if (ups_zero_async(ws, sizeof(UniPanWs), st)) return 1;
     const long threads = (npix + UP_RUN - 1) / UP_RUN;
     int nrow = id_last_stuff + 1 + num_inst + 1;   // stuff ids, instance ids, void
     if ((size_t)nrow * num_seg_classes * sizeof(int) > 60 * 1024) nrow = (int)(60 * 1024 / sizeof(int) / num_seg_classes);  // rest: global atomics

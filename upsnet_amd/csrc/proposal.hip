@@ -349,7 +349,7 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     if (gx > 1024) gx = 1024;
     unsigned *hist = (unsigned *)(ws + plan.off_hist);
     PropSel *sel = (PropSel *)(ws + plan.off_sel);
-    UPS_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)nlev * PROP_BINS * 4, st));
+    if (ups_zero_async(hist, (size_t)nlev * PROP_BINS * 4, st)) return 1;
     hipLaunchKernelGGL(prop_key_kernel, dim3(gx, nlev), dim3(256), 0, st, lv, kbuf[0], sel, pre_n);
     UPS_CHECK_LAUNCH("prop_key_kernel");
 

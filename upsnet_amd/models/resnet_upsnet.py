@@ -67,13 +67,11 @@ class resnet_upsnet(resnet_rcnn):
         # forward_async() can launch image i+1 while the caller still reads the outputs of image i (they stay valid for
         # graph_slots forwards of that shape)
         self.graph_slots = max(1, int(os.environ.get('UPSNET_GRAPH_SLOTS', '2')))
-        if not self.overlap_streams:
-            # OPEN ISSUE (tools/diag_graph_stream.py): the purely linear capture of UPSNET_OVERLAP=0 -- a debug configuration --
-            # faults on the GPU (memory access fault) at the SECOND replay of an instance as soon as there are two instances or
-            # the instance is captured on its own stream; with one instance on torch's capture stream it replays fine, and the
-            # forked default capture has replayed bit-identically to the eager forward in every run (tests + bench re-check).
-            # Cause not understood; the debug configuration therefore keeps a single instance.
-            self.graph_slots = 1
+        # (r01-r05 kept a single instance for the linear capture of UPSNET_OVERLAP=0: it faulted on the GPU at replay. Root cause,
+        # found by bisection (tools/diag_graph_matrix.sh): the hipMemsetAsync calls of the selection ops became MEMSET NODES of the
+        # captured graph, and a linear graph with memset nodes faults on this ROCm stack at replay; the forked capture happened
+        # to survive. The ops now zero their scratch with an ordinary kernel (csrc/fill.hip), a captured forward holds kernel
+        # nodes only, and every configuration replays -- tests/test_model_gpu.py::test_hip_graph_replay_equals_eager[False].)
         self.graph_outputs_alias = os.environ.get('UPSNET_GRAPH_ALIAS', '1') != '0'
         self.early_mask_head = os.environ.get('UPSNET_EARLY_MASK', '1') != '0'
         self.taps = None  # set to a dict to record the inputs/outputs of every custom-op stage (parity tests)
