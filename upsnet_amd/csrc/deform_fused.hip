@@ -21,7 +21,7 @@
 //     prefetched four steps ahead in a register ring (as conv_wino.hip). LDS holds only the blended A tile (2 x 8 KiB) and the
 //     table (34 KiB for 3x3), so occupancy is set by registers alone (3 workgroups / CU) and two register sets of corners are in flight: the
 //     gather of slab s+2 is issued while slab s+1 is blended and slab s is contracted.
-// Tile: 64 output pixels x 128 output channels per workgroup (4 waves; wave w owns column block w and both 32-row blocks), fp32
+// Tile: 8 x 8 output pixels x 128 output channels per workgroup (4 waves; wave w owns column block w and both 32-row blocks), fp32
 // products and accumulation on v_mfma_f32_32x32x2_f32 in a fixed order (bit-repeatable). Epilogue: + bias, ReLU, NHWC store.
 #include "conv_params.h"
 #include "upsnet_hip.h"
@@ -98,11 +98,16 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 #pragma unroll
     for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
     const ConvSeg sg = p.seg[si];
-    const long p0 = (long)(m_t - sg.tile_start) * DF_BM;
+    // 2-D pixel tile: 8 x 8 output pixels (pixel px of the tile = (px >> 3, px & 7)). The samples of a tile then cover
+    // ~(8 + 2r)^2 input pixels for offsets of radius r instead of ~(64 + 2r) x (3 + 2r) for a 64 x 1 row segment: at r = 3 that is
+    // 25 KiB instead of 80 KiB per 32-channel slab, so the 96 workgroups of an XCD keep their corner lines in its 4 MiB L2.
+    const int tiles_x = (sg.Wo + 7) >> 3, tiles_y = (sg.Ho + 7) >> 3;
+    const int t_loc = m_t - sg.tile_start;
+    const int t_n = t_loc / (tiles_x * tiles_y), t_rem = t_loc - t_n * (tiles_x * tiles_y);
+    const int t_y = t_rem / tiles_x, t_x = t_rem - t_y * tiles_x;
     const int ntap = p.KH * p.KW;
     const int cslabs = p.Cin >> 5;
     const int nsl = cslabs * ntap;                 // (channel slab, tap) steps of the K walk, tap innermost
-    const long HoWo = (long)sg.Ho * sg.Wo;
 
     // ---- sampling table of this tile, once: deform_conv_kernel.cu:227-240 (positions), :88-118 (corners, weights -- the same fp32
     // expressions, evaluated here instead of per channel)
@@ -110,15 +115,15 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
         const unsigned cin4_ = 4u * (unsigned)p.Cin;
         for (int idx = tid; idx < ntap * DF_BM; idx += 256) {
             const int tap = idx >> 6, px = idx & 63;
-            const long pp = p0 + px;
+            const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
+            const bool inside = ho < sg.Ho && wo < sg.Wo;
+            const long pp = ((long)t_n * sg.Ho + ho) * sg.Wo + wo;
             uintx4 o;
             o.x = o.y = o.z = o.w = 0x80000000u;
             float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
             float m = 1.0f;
-            if (pp < sg.M) {
-                const int n = (int)(pp / HoWo);
-                const int rem = (int)(pp - (long)n * HoWo);
-                const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+            if (inside) {
+                const int n = t_n;
                 const int ki = tap / p.KW, kj = tap - ki * p.KW;
                 const int h_base = ho * p.stride - p.pad + ki * p.dil, w_base = wo * p.stride - p.pad + kj * p.dil;
                 const float off_h = sg.off[pp * (2 * ntap) + 2 * tap];
@@ -287,14 +292,14 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const long pbase = p0 + 32 * i + 4 * lhalf;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long pp = pbase + (r & 3) + 8 * (r >> 2);
+            const int px = 32 * i + 4 * lhalf + (r & 3) + 8 * (r >> 2);       // = tile row 4 i + (r >> 2), column 4 lhalf + (r & 3)
+            const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
             float v = i == 0 ? acc0[r] : acc1[r];
             v = v + bv;
             if (p.relu) v = fmaxf(v, 0.f);
-            if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+            if (co_ok && ho < sg.Ho && wo < sg.Wo) sg.out[(((long)t_n * sg.Ho + ho) * sg.Wo + wo) * p.Cout + co] = v;
         }
     }
 }
@@ -320,7 +325,10 @@ extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float
     for (int i = 0; i < p.nseg; ++i)   // bit 31 of a corner offset flags "outside the image": offsets of real pixels must stay below it
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * cin < (1L << 29), "deform_conv_fused_nhwc: feature map %d exceeds 2 GiB; split the batch", i);
     int tiles = 0;
-    for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + DF_BM - 1) / DF_BM); }
+    for (int i = 0; i < p.nseg; ++i) {   // 8 x 8 pixel tiles
+        p.seg[i].tile_start = tiles;
+        tiles += p.seg[i].N * ((p.seg[i].Ho + 7) / 8) * ((p.seg[i].Wo + 7) / 8);
+    }
     p.m_tiles = tiles;
     p.n_tiles = (cout + DF_BN - 1) / DF_BN;
     const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * (16 + 16 + 4);

@@ -39,9 +39,14 @@ nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ score
     u64 *keys = reinterpret_cast<u64 *>(smem_raw);
     const int p = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
     const int n = min(counts[p], nmax);
-    for (int i = tid; i < M; i += bd)
+    // sort only as many keys as this problem holds (the class-agnostic selection reserves 8192 slots and usually fills ~100:
+    // 55 barrier-separated stages instead of 91)
+    int Mp = 64;
+    while (Mp < n) Mp <<= 1;
+    Mp = min(Mp, M);
+    for (int i = tid; i < Mp; i += bd)
         keys[i] = i < n ? ups_make_key(scores[(long)p * nmax + i], (unsigned)i, tie_mode) : 0ULL;
-    ups_block_sort_desc(keys, M);
+    ups_block_sort_desc(keys, Mp);
     const float4 *b4 = reinterpret_cast<const float4 *>(boxes) + (long)p * nmax;
     for (int i = tid; i < n; i += bd) {
         const int idx = (int)ups_key_index(keys[i], tie_mode);
@@ -50,9 +55,11 @@ nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ score
     }
 }
 
+// diagT[p][c]: for sorted box c, the 64-bit word of the boxes of ITS OWN 64-block that suppress it (bit j: box 64 (c/64) + j, j < c % 64,
+// overlaps c above the threshold) -- the transpose of the diagonal tile, which is what the scan needs to resolve a block in parallel.
 __global__ void __launch_bounds__(64)
 nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ counts, const int nmax, const int CB,
-                const float thresh, const int ge, u64 *__restrict__ mask)
+                const float thresh, const int ge, u64 *__restrict__ mask, u64 *__restrict__ diagT)
 {
     const int p = blockIdx.z;
     const int n = min(counts[p], nmax);
@@ -63,17 +70,34 @@ nms_mask_kernel(const float4 *__restrict__ sboxes, const int *__restrict__ count
     const int tid = threadIdx.x;
     if (tid < col_size) cb[tid] = sboxes[(long)p * nmax + col_start * 64 + tid];
     __syncthreads();
-    if (tid < row_size) {
-        const int cur = row_start * 64 + tid;
-        const float4 a = sboxes[(long)p * nmax + cur];
-        u64 t = 0;
-        const int start = (row_start == col_start) ? tid + 1 : 0;
-        for (int i = start; i < col_size; ++i) {
-            const float4 b = cb[i];
-            const float ov = ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
-            if (ge ? ov >= thresh : ov > thresh) t |= 1ULL << i;   // nms_kernel.cu:73-80 is ">", cpu_nms.pyx:77 ">="
+    const bool row_ok = tid < row_size;
+    const int cur = row_start * 64 + tid;
+    const float4 a = sboxes[(long)p * nmax + (row_ok ? cur : row_start * 64)];
+    u64 t = 0;
+    if (row_start != col_start) {
+        if (row_ok) {
+            for (int i = 0; i < col_size; ++i) {
+                const float4 b = cb[i];
+                const float ov = ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+                if (ge ? ov >= thresh : ov > thresh) t |= 1ULL << i;   // nms_kernel.cu:73-80 is ">", cpu_nms.pyx:77 ">="
+            }
+            mask[((long)p * nmax + cur) * CB + col_start] = t;
         }
+        return;
+    }
+    // diagonal tile: uniform loop over the columns, so that one ballot per column yields the column's (transposed) word
+    u64 tw = 0;
+    for (int i = 0; i < col_size; ++i) {
+        const float4 b = cb[i];
+        const float ov = ups_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+        const bool hit = row_ok && i > tid && (ge ? ov >= thresh : ov > thresh);
+        if (hit) t |= 1ULL << i;
+        const u64 colw = __ballot(hit);
+        if (tid == i) tw = colw;
+    }
+    if (row_ok) {
         mask[((long)p * nmax + cur) * CB + col_start] = t;
+        diagT[(long)p * nmax + cur] = tw;
     }
 }
 
@@ -87,13 +111,22 @@ __device__ static inline u64 readlane64(u64 v, int src)
 }
 
 #define NMS_SCAN_T 256
-#define NMS_LDS_ROWS 1024   // problems up to this many boxes keep their whole suppression mask in LDS (128 KiB)
+#define NMS_LDS_ROWS 1024   // problems up to this many boxes keep their whole suppression mask in LDS (<= 128 KiB)
 
-// One workgroup per problem; all threads stage the mask rows into LDS (when they fit), wave 0 does the greedy scan.
+// One workgroup per problem. All threads stage the mask rows into LDS (problems of <= 1024 boxes; row pitch = a power of two,
+// no division), then wave 0 walks the 64-blocks in order:
+//   * a block is resolved IN PARALLEL from the transposed diagonal words (nms_mask_kernel): kept = alive; repeat kept' = alive &
+//     ~{ c : T_c & kept & (bits below c) != 0 } until nothing changes. After t rounds the first t+1 live boxes of the block are
+//     final, and a fixed point satisfies the greedy recurrence "c is kept iff it is alive and no kept predecessor suppresses it"
+//     for every c, whose solution is unique -- so the result IS the sequential scan of nms_kernel.cu:130-146, typically after 2-5
+//     rounds of ~6 instructions instead of up to 64 dependent ctz / readlane / and trips;
+//   * the suppression words of the kept rows are ORed into the per-column-block state by all 64 lanes: lane = (column block w,
+//     phase tq) reads the rows 4k + tq of the block (16 independent LDS reads), two xor-shuffles combine the four phases.
+// r05's scan (one dependent LDS read per kept row, sequential diagonal) took 120-140 us for 1000 boxes; this one ~15.
 __global__ void __launch_bounds__(NMS_SCAN_T)
-nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, const int *__restrict__ counts,
-                const uint8_t *__restrict__ pre_removed, const int nmax, const int CB, const int use_lds,
-                int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
+nms_scan_kernel(const u64 *__restrict__ mask, const u64 *__restrict__ diagT, const int *__restrict__ order,
+                const int *__restrict__ counts, const uint8_t *__restrict__ pre_removed, const int nmax, const int CB,
+                const int use_lds, int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *smask = reinterpret_cast<u64 *>(smem_raw);
@@ -101,60 +134,60 @@ nms_scan_kernel(const u64 *__restrict__ mask, const int *__restrict__ order, con
     const int n = min(counts[p], nmax);
     const int nb = (n + 63) >> 6;
     const u64 *mp = mask + (long)p * nmax * CB;
+    int lg = 0;
+    while ((1 << lg) < nb) ++lg;
+    const int pitch = use_lds ? (1 << lg) : CB;          // u64 words per mask row as the scan reads it
     if (use_lds) {
         // only words (row i, column block >= i/64) were produced by nms_mask_kernel; copy exactly those
-        for (int idx = tid; idx < n * nb; idx += NMS_SCAN_T) {
-            const int i = idx / nb, cb = idx - i * nb;
-            if (cb >= (i >> 6)) smask[i * nb + cb] = mp[(long)i * CB + cb];
+        for (int idx = tid; idx < (n << lg); idx += NMS_SCAN_T) {
+            const int i = idx >> lg, cb = idx & (pitch - 1);
+            if (cb < nb && cb >= (i >> 6)) smask[idx] = mp[(long)i * CB + cb];
         }
         __syncthreads();
     }
     if (tid >= 64) return;
+    const u64 *rows = use_lds ? smask : mp;
     const int lane = tid;
     const int *ord = order ? order + (long)p * nmax : nullptr;
-    u64 remv0 = 0, remv1 = 0;  // suppression words `lane` and `lane + 64`
+    const u64 below = (1ULL << lane) - 1ULL;
     int nkeep = 0;
-    const int w0 = lane, w1 = lane + 64;
+    // suppression state: lane w holds the words of column blocks w and w + 64 (nmax <= 8192)
+    u64 remv0 = 0, remv1 = 0;
+    const int wq = lane & 15, tq = lane >> 4;            // OR phase: column block slot, row phase
     for (int b = 0; b < nb; ++b) {
         const u64 cur = readlane64(b < 64 ? remv0 : remv1, b & 63);
         const int i = b * 64 + lane;
         const bool valid = i < n;
         const int oi = valid ? (ord ? ord[i] : i) : 0;
         const bool pre = valid && pre_removed && pre_removed[(long)p * nmax + oi];
-        const u64 diag = valid ? (use_lds ? smask[i * nb + b] : mp[(long)i * CB + b]) : 0;
-        u64 alive = ~cur & __ballot(valid) & ~__ballot(pre);
-        u64 kept = 0;
-        while (alive) {
-            const int t = __builtin_ctzll(alive);
-            kept |= 1ULL << t;
-            alive &= ~readlane64(diag, t);
-            alive &= ~(1ULL << t);
+        const u64 tw = valid ? diagT[(long)p * nmax + i] : 0;      // boxes of this block that suppress box i
+        const u64 alive = ~cur & __ballot(valid) & ~__ballot(pre);
+        u64 kept = alive;
+        for (;;) {
+            const u64 nk = alive & ~__ballot((tw & kept & below) != 0);
+            if (nk == kept) break;
+            kept = nk;
         }
         if ((kept >> lane) & 1ULL)
-            keep_idx[(long)p * nmax + nkeep + __builtin_popcountll(kept & ((1ULL << lane) - 1ULL))] = oi;
+            keep_idx[(long)p * nmax + nkeep + __builtin_popcountll(kept & below)] = oi;
         nkeep += __builtin_popcountll(kept);
-        const bool a0 = w0 > b && w0 < nb, a1 = w1 > b && w1 < nb;
-        u64 kk = kept;
-        if (use_lds) {
+        // OR the rows of the kept boxes into the state of the later column blocks, 16 column blocks per pass
+        for (int w0 = (b + 1) & ~15; w0 < nb; w0 += 16) {
+            const int w = w0 + wq;
             u64 acc = 0;
-            while (kk) { const int t = __builtin_ctzll(kk); kk &= kk - 1; if (a0) acc |= smask[(b * 64 + t) * nb + w0]; }
-            remv0 |= acc;
-        } else {
-            while (kk) {  // 4 independent row reads in flight per trip
-                long r[4];
-                int cnt = 0;
+            if (w > b && w < nb) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (kk) { r[q] = (long)(b * 64 + __builtin_ctzll(kk)) * CB; kk &= kk - 1; cnt = q + 1; } else r[q] = -1;
+                for (int k = 0; k < 16; ++k) {
+                    const int t = 4 * k + tq;
+                    if ((kept >> t) & 1ULL) acc |= rows[(long)(b * 64 + t) * pitch + w];
                 }
-                u64 v0[4], v1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v0[q] = (a0 && q < cnt) ? mp[r[q] + w0] : 0;
-                    v1[q] = (a1 && q < cnt) ? mp[r[q] + w1] : 0;
-                }
-                remv0 |= v0[0] | v0[1] | v0[2] | v0[3];
-                remv1 |= v1[0] | v1[1] | v1[2] | v1[3];
+            }
+            acc |= shfl64(acc, lane ^ 16);
+            acc |= shfl64(acc, lane ^ 32);
+            // lane `wq` of each 16-group now holds the OR for column block w0 + wq; hand it to the lane that owns that block
+            const u64 mine0 = shfl64(acc, lane & 15);               // value for column block w0 + (lane & 15)
+            if (lane >= (w0 & 63) && lane < (w0 & 63) + 16) {
+                if (w0 < 64) remv0 |= mine0; else remv1 |= mine0;
             }
         }
     }
@@ -166,6 +199,7 @@ static inline int next_pow2(int v) { int m = 64; while (m < v) m <<= 1; return m
 struct NmsWs {
     float4 *sorted_boxes;
     int *order;
+    u64 *diagT;
     u64 *mask;
 };
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -175,6 +209,7 @@ static NmsWs nms_carve(void *ws, int P, int nmax)
     unsigned char *b = (unsigned char *)ws;
     w.sorted_boxes = (float4 *)b; b += align256((size_t)P * nmax * sizeof(float4));
     w.order = (int *)b; b += align256((size_t)P * nmax * sizeof(int));
+    w.diagT = (u64 *)b; b += align256((size_t)P * nmax * sizeof(u64));
     w.mask = (u64 *)b;
     return w;
 }
@@ -184,7 +219,7 @@ extern "C" size_t upsnet_nms_workspace_bytes(int P, int nmax)
     if (P <= 0 || nmax <= 0) return 256;
     size_t CB = (nmax + 63) / 64;
     return align256((size_t)P * nmax * sizeof(float4)) + align256((size_t)P * nmax * sizeof(int)) +
-           align256((size_t)P * nmax * CB * sizeof(u64)) + 256;
+           align256((size_t)P * nmax * sizeof(u64)) + align256((size_t)P * nmax * CB * sizeof(u64)) + 256;
 }
 
 // internal: tie_mode-selectable version used by the proposal / detection pipelines
@@ -201,10 +236,12 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(M < 1024 ? M : 1024), (size_t)M * sizeof(u64), st, boxes, scores,
                        counts, nmax, M, tie_mode, w.sorted_boxes, w.order);
     UPS_CHECK_LAUNCH("nms_sort_kernel");
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, ge, w.mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, ge, w.mask, w.diagT);
     UPS_CHECK_LAUNCH("nms_mask_kernel");
     const int use_lds = nmax <= NMS_LDS_ROWS;
-    const size_t scan_smem = use_lds ? (size_t)nmax * CB * sizeof(u64) : 0;
+    int cbp = 1;
+    while (cbp < CB) cbp <<= 1;
+    const size_t scan_smem = use_lds ? (size_t)nmax * cbp * sizeof(u64) : 0;
     if (scan_smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -213,7 +250,7 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(NMS_SCAN_T), scan_smem, st, w.mask, w.order, counts, pre_removed, nmax, CB,
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(NMS_SCAN_T), scan_smem, st, w.mask, w.diagT, w.order, counts, pre_removed, nmax, CB,
                        use_lds, keep_idx, keep_cnt);
     UPS_CHECK_LAUNCH("nms_scan_kernel");
     return 0;
@@ -260,10 +297,11 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
     UPS_CHECK_HIP(hipGetDevice(&cur));
     if (cur != device_id) UPS_CHECK_HIP(hipSetDevice(device_id));
     const int n = boxes_num, CB = (n + 63) / 64;
-    float *raw = nullptr; float4 *packed = nullptr; u64 *mask = nullptr; int *cnt = nullptr, *keep = nullptr, *kc = nullptr;
+    float *raw = nullptr; float4 *packed = nullptr; u64 *mask = nullptr, *diagT = nullptr; int *cnt = nullptr, *keep = nullptr, *kc = nullptr;
     UPS_CHECK_HIP(hipMalloc(&raw, (size_t)n * boxes_dim * sizeof(float)));
     UPS_CHECK_HIP(hipMalloc(&packed, (size_t)n * sizeof(float4)));
     UPS_CHECK_HIP(hipMalloc(&mask, (size_t)n * CB * sizeof(u64)));
+    UPS_CHECK_HIP(hipMalloc(&diagT, (size_t)n * sizeof(u64)));
     UPS_CHECK_HIP(hipMalloc(&cnt, sizeof(int)));
     UPS_CHECK_HIP(hipMalloc(&keep, (size_t)n * sizeof(int)));
     UPS_CHECK_HIP(hipMalloc(&kc, sizeof(int)));
@@ -272,8 +310,8 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
         if (hipMemcpy(raw, boxes_host, (size_t)n * boxes_dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = ups_set_error("nms_host: H2D copy failed"); break; }
         hipLaunchKernelGGL(nms_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, raw, n, boxes_dim, packed);
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, 0, mask);
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_T), 0, 0, mask, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, 0, mask, diagT);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_T), 0, 0, mask, diagT, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
                            n, CB, 0, keep, kc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { rc = ups_set_error("nms_host: launch failed: %s", hipGetErrorString(e)); break; }
@@ -282,7 +320,7 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
             rc = ups_set_error("nms_host: D2H copy failed"); break;
         }
     } while (0);
-    (void)hipFree(raw); (void)hipFree(packed); (void)hipFree(mask); (void)hipFree(cnt); (void)hipFree(keep); (void)hipFree(kc);
+    (void)hipFree(raw); (void)hipFree(packed); (void)hipFree(mask); (void)hipFree(diagT); (void)hipFree(cnt); (void)hipFree(keep); (void)hipFree(kc);
     return rc;
 }
 
