@@ -315,6 +315,17 @@ int upsnet_pyramid_proposals(void *stream, int nlev, const float *const cls_prob
                              int post_nms_top_n, float nms_thresh, float min_size, float *rois_out,
                              float *scores_out, int *num_out, void *workspace);
 
+/* Same operator on strided inputs, so that channel slices of NHWC maps (the RPN head's [H,W,15] output: 3 scores + 12 deltas per
+ * pixel) are consumed in place instead of being copied to NCHW first: element (channel c, pixel) of level l's score map is
+ * cls_prob[l][c * cls_chan_stride[l] + pixel * cls_pix_stride[l]], likewise for the deltas. A NULL stride array means NCHW
+ * (channel stride H*W, pixel stride 1). */
+int upsnet_pyramid_proposals_strided(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                     const long *cls_chan_stride, const long *cls_pix_stride, const long *box_chan_stride,
+                                     const long *box_pix_stride, const int *heights_host, const int *widths_host,
+                                     const int *strides_host, const float *anchors_host, int num_anchors, const float *im_info,
+                                     int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float *rois_out,
+                                     float *scores_out, int *num_out, void *workspace);
+
 /* ============================== Detection selection (MaskROI) ============================== */
 
 /* Replaces MaskROI.forward (upsnet/operators/modules/mask_roi.py:36-146): decode + clip, per-class (or
@@ -339,6 +350,12 @@ int upsnet_mask_roi(void *stream, const float *rois, const float *bbox_delta, co
 int upsnet_mask_roi_dedup(void *stream, const int *a_src, const int64_t *a_cls, const int *num_a, int cap_a, const int *b_src,
                           const int64_t *b_cls, const float *b_boxes, const int *num_b, int cap_b, int *map_out,
                           float *extra_boxes, int *num_extra);
+
+/* out[k, :] = mask_logit[row[k], cls[k], :] for k < K: the class plane of each panoptic detection's mask logits
+ * (upsnet/models/resnet_upsnet.py:215-221) as one gather. mask_logit is addressed by element strides (stride_n per ROI, stride_c
+ * per class, stride_e per spatial element: NHWC or NCHW); row int32 [K], cls int64 [K] are clamped to the valid range; out [K, hw]. */
+int upsnet_mask_logit_gather(void *stream, const float *mask_logit, int n_rows, int num_classes, int hw, long stride_n,
+                             long stride_c, long stride_e, const int *row, const int64_t *cls, int K, float *out);
 
 /* ============================== Panoptic head ============================== */
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libupsnet_hip.so")
 
-c_int, c_float, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+c_int, c_float, c_double, c_void_p, c_size_t, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long
 P = c_void_p
 
 _SIGNATURES = {
@@ -46,10 +46,12 @@ _SIGNATURES = {
     "upsnet_soft_nms_workspace_bytes": (c_size_t, [c_int]),
     "upsnet_soft_nms": (c_int, [P, P, P, c_int, c_float, c_float, c_float, c_int, P, P]),
     "upsnet_proposal_workspace_bytes": (c_size_t, [c_int, P, P, c_int, c_int, c_int]),
+    "upsnet_pyramid_proposals_strided": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "upsnet_pyramid_proposals": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "upsnet_mask_roi_capacity": (c_int, [c_int, c_int, c_int]),
     "upsnet_mask_roi_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "upsnet_mask_roi": (c_int, [P, P, P, P, c_int, P, c_int, P, c_int, c_float, c_float, c_int, P, P, P, P, P, P, P]),
+    "upsnet_mask_logit_gather": (c_int, [P, P, c_int, c_int, c_int, c_long, c_long, c_long, P, P, c_int, P]),
     "upsnet_mask_removal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "upsnet_mask_removal": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_double, P, P, P, P]),
     "upsnet_mask_paste": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

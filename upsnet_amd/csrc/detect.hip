@@ -289,3 +289,32 @@ extern "C" int upsnet_mask_roi_dedup(void *stream, const int *a_src, const int64
     UPS_CHECK_LAUNCH("mroi_dedup_kernel");
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// pan_logit[k] = mask_logit[row[k]][cls[k]] (resnet_upsnet.py:215-221: the mask head's class plane of every panoptic detection), as
+// ONE gather: out [K, hw] contiguous; the source is addressed by strides (NHWC or NCHW). Rows / classes are clamped so that the
+// call can sit inside a captured graph on fixed-capacity buffers before the host knows the counts (rows past the count are ignored
+// downstream). Replaces clamp + long + index_select (a [K, C, 28, 28] copy) + clamp + expand + gather = 6 launches.
+__global__ void __launch_bounds__(256)
+mask_logit_gather_kernel(const float *__restrict__ src, const int n_rows, const int C, const int hw, const long s_n, const long s_c,
+                         const long s_e, const int *__restrict__ row, const int64_t *__restrict__ cls, float *__restrict__ out)
+{
+    const int k = blockIdx.x;
+    const int r = min(max(row[k], 0), n_rows - 1);
+    const int c = (int)min(max(cls[k], (int64_t)0), (int64_t)(C - 1));
+    const float *__restrict__ sp = src + (long)r * s_n + (long)c * s_c;
+    for (int e = threadIdx.x; e < hw; e += blockDim.x) out[(long)k * hw + e] = sp[(long)e * s_e];
+}
+
+extern "C" int upsnet_mask_logit_gather(void *stream, const float *mask_logit, int n_rows, int num_classes, int hw, long stride_n,
+                                        long stride_c, long stride_e, const int *row, const int64_t *cls, int K, float *out)
+{
+    UPS_REQUIRE(mask_logit && row && cls && out, "mask_logit_gather: null pointer");
+    UPS_REQUIRE(n_rows > 0 && num_classes > 0 && hw > 0 && K >= 0, "mask_logit_gather: bad sizes");
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(mask_logit_gather_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, mask_logit, n_rows, num_classes, hw, stride_n,
+                       stride_c, stride_e, row, cls, out);
+    UPS_CHECK_LAUNCH("mask_logit_gather_kernel");
+    return 0;
+}

@@ -28,6 +28,8 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
 struct PropLevels {
     const float *cls[PROP_MAXLEV];
     const float *box[PROP_MAXLEV];
+    long cls_cs[PROP_MAXLEV], cls_ps[PROP_MAXLEV];   // element strides of the score map: per anchor channel, per pixel
+    long box_cs[PROP_MAXLEV], box_ps[PROP_MAXLEV];   // ... of the delta map
     int H[PROP_MAXLEV], W[PROP_MAXLEV], stride[PROP_MAXLEV];
     int n[PROP_MAXLEV];        // anchors per level
     long key_off[PROP_MAXLEV]; // offset of the level's key segment
@@ -46,7 +48,8 @@ struct PropSel {
 
 #define PROP_BINS 2048
 
-// scores [A,H,W] (NCHW) -> keys at (h*W + w)*A + a
+// scores (anchor a, pixel) at cls[a * cls_cs + pixel * cls_ps] (NCHW: cs = H*W, ps = 1; a channel slice of an NHWC map: cs = 1,
+// ps = channels of the map) -> keys at (h*W + w)*A + a
 __global__ void __launch_bounds__(256)
 prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys, PropSel *__restrict__ sel, const int k)
 {
@@ -64,7 +67,7 @@ prop_key_kernel(const PropLevels lv, ups_u64 *__restrict__ keys, PropSel *__rest
         const int a = (int)(i / hw);
         const long pix = i % hw;
         const unsigned idx = (unsigned)(pix * A + a);
-        out[idx] = ups_make_key(s[i], idx, 1);
+        out[idx] = ups_make_key(s[a * lv.cls_cs[l] + pix * lv.cls_ps[l]], idx, 1);
     }
 }
 
@@ -197,13 +200,13 @@ prop_decode_kernel(const PropLevels lv, const ups_u64 *keys, int pre_n, const fl
     const int a = idx % A;
     const int pix = idx / A;
     const int h = pix / W, w = pix % W;
-    const long hw = (long)lv.H[l] * W;
     const float sx = (float)(w * lv.stride[l]), sy = (float)(h * lv.stride[l]);
     const float ax1 = lv.anchors[l][a][0] + sx, ay1 = lv.anchors[l][a][1] + sy;
     const float ax2 = lv.anchors[l][a][2] + sx, ay2 = lv.anchors[l][a][3] + sy;
-    const float *__restrict__ d = lv.box[l] + (long)(a * 4) * hw + pix;
+    const long bcs = lv.box_cs[l];
+    const float *__restrict__ d = lv.box[l] + (long)(a * 4) * bcs + (long)pix * lv.box_ps[l];
     float o[4];
-    ups_decode_clip(ax1, ay1, ax2, ay2, d[0], d[hw], d[2 * hw], d[3 * hw], 1.f, 1.f, 1.f, 1.f, im_info[0], im_info[1],
+    ups_decode_clip(ax1, ay1, ax2, ay2, d[0], d[bcs], d[2 * bcs], d[3 * bcs], 1.f, 1.f, 1.f, 1.f, im_info[0], im_info[1],
                     true, o);
     b[0] = o[0]; b[1] = o[1]; b[2] = o[2]; b[3] = o[3];
     scores[(long)l * pre_n + i] = ups_key_score(key);
@@ -301,8 +304,8 @@ extern "C" size_t upsnet_proposal_workspace_bytes(int nlev, const int *heights, 
     return prop_plan(nlev, heights, widths, num_anchors, pre_nms_top_n).total;
 }
 
-extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
-                                        const int *heights, const int *widths, const int *strides, const float *anchors,
+extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                        const long *cls_cs, const long *cls_ps, const long *box_cs, const long *box_ps, const int *heights, const int *widths, const int *strides, const float *anchors,
                                         int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
                                         float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace)
 {
@@ -333,6 +336,9 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     for (int l = 0; l < nlev; ++l) {
         UPS_REQUIRE(cls_prob[l] && bbox_pred[l] && heights[l] > 0 && widths[l] > 0, "pyramid_proposals: bad level %d", l);
         lv.cls[l] = cls_prob[l]; lv.box[l] = bbox_pred[l];
+        const long hw_ = (long)heights[l] * widths[l];
+        lv.cls_cs[l] = cls_cs ? cls_cs[l] : hw_; lv.cls_ps[l] = cls_ps ? cls_ps[l] : 1;
+        lv.box_cs[l] = box_cs ? box_cs[l] : hw_; lv.box_ps[l] = box_ps ? box_ps[l] : 1;
         lv.H[l] = heights[l]; lv.W[l] = widths[l]; lv.stride[l] = strides[l];
         lv.n[l] = heights[l] * widths[l] * num_anchors;
         for (int a = 0; a < num_anchors; ++a)
@@ -390,3 +396,15 @@ extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *con
     return 0;
 }
 
+
+
+// NCHW-contiguous inputs ([A,H,W] scores, [4A,H,W] deltas per level): the strided entry with the default strides
+extern "C" int upsnet_pyramid_proposals(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                        const int *heights, const int *widths, const int *strides, const float *anchors,
+                                        int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
+                                        float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace)
+{
+    return upsnet_pyramid_proposals_strided(stream, nlev, cls_prob, bbox_pred, nullptr, nullptr, nullptr, nullptr, heights, widths, strides,
+                                            anchors, num_anchors, im_info, pre_n, post_n, nms_thresh, min_size, rois_out, scores_out,
+                                            num_out, workspace);
+}

@@ -243,7 +243,7 @@ def clear_cache(model=None):
             m.__dict__.pop('_hip_plans', None)
 
 
-def conv_multi_cat(ms, xs):
+def conv_multi_cat(ms, xs, return_flat=False):
     """Several sibling convolutions of the same geometry (the RPN's objectness and box-delta 1x1 heads) on the same maps as ONE
     launch over the concatenated output channels: the input maps are read once instead of once per head. Returns one list of
     per-map outputs per module (channel slices of the shared output). Every output channel is computed exactly as in a separate
@@ -256,7 +256,8 @@ def conv_multi_cat(ms, xs):
     # (the instance is chosen by ldw: the concatenation must stay on the one the separate heads would use)
     if (not same or PRECISION != 'fp32' or len(xs) > 5 or not all(supported(m0, x) for x in xs) or
             (sum(couts) + 31) // 32 != 1 or _use_winograd(m0, xs)):
-        return [conv_multi(m, xs) for m in ms]
+        res = [conv_multi(m, xs) for m in ms]
+        return (res, None, None) if return_flat else res
     key = tuple((m.weight.data_ptr(), m.weight._version, tuple(m.weight.shape), None if m.bias is None else m.bias._version) for m in ms)
     ent = _plans(m0).get('cat')
     if ent is None or ent[0] != key:
@@ -271,5 +272,7 @@ def conv_multi_cat(ms, xs):
     for c in couts:
         res.append([o[:, c0:c0 + c] for o in outs])
         c0 += c
+    if return_flat:
+        return res, getattr(outs[0], '_ups_flat', None), outs
     return res
 

@@ -273,9 +273,7 @@ class resnet_upsnet(resnet_rcnn):
             # panoptic detections); the host checks the counters after the replay and redoes this part eagerly otherwise.
             K = min(256, pan_boxes.shape[0])
             pb, ps, pc = pan_boxes[:K], pan_scores[:K], pan_cls[:K]
-            row = pan_row[:K].clamp(0, max_det - 1).long()
-            ms = config.network.mask_size
-            pan_logit = mask_det.index_select(0, row).gather(1, pc.clamp(0, mask_det.shape[1] - 1).view(-1, 1, 1, 1).expand(-1, -1, ms, ms))
+            pan_logit = ops.mask_logit_gather(mask_det, pan_row[:K], pc)   # rows / classes clamped inside: one launch
             H, W = fcn.shape[2] * 4, fcn.shape[3] * 4
             keep, num_keep, real_keep = self.mask_removal.select(pb[:, 1:], ps, pan_logit, pc, (H, W), num_dev=pan_num)
             num_stuff = self.num_seg_classes - (self.num_classes - 1)

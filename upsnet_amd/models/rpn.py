@@ -30,7 +30,16 @@ class RPN(nn.Module):
 
 
 def rpn_forward_levels(rpn, feats):
-    """All pyramid levels through the shared RPN head: 2 launches (3x3 conv; both 1x1 heads together) instead of 3 per level."""
+    """All pyramid levels through the shared RPN head: 3 launches (3x3 conv; both 1x1 heads together; ONE sigmoid over the flat
+    buffer that backs the head outputs of every level) instead of 4 per level. The probabilities are returned as channel slices of
+    NHWC maps; the proposal kernels consume them in place (strided)."""
     xs = hipconv.conv_multi(rpn.conv_proposal[0], feats, relu=True)
-    scores, boxes = hipconv.conv_multi_cat([rpn.cls_score, rpn.bbox_pred], xs)
-    return scores, boxes, [torch.sigmoid(s) for s in scores]
+    (scores, boxes), flat, outs = hipconv.conv_multi_cat([rpn.cls_score, rpn.bbox_pred], xs, return_flat=True)
+    if flat is None:
+        return scores, boxes, [torch.sigmoid(s) for s in scores]
+    sig = torch.sigmoid(flat)     # (also over the 12 box-delta channels of each pixel: 2.6 M elements, one launch)
+    probs, A = [], rpn.cls_score.out_channels
+    for o in outs:
+        view = torch.as_strided(sig, o.shape, o.stride(), o.storage_offset() - flat.storage_offset())
+        probs.append(view[:, :A])
+    return scores, boxes, probs

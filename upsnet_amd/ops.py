@@ -345,8 +345,16 @@ def pyramid_proposals(cls_probs, bbox_preds, im_info, anchors, strides, pre_nms_
     Returns fixed-size (rois [post,5], scores [post], num device int32)."""
     require_cuda(im_info, *cls_probs)
     L = len(cls_probs)
-    cls_probs = [f32c(c) for c in cls_probs]
-    bbox_preds = [f32c(b) for b in bbox_preds]
+
+    def pixel_linear(t):
+        """(tensor, channel stride, pixel stride) if (c, h, w) -> c*cs + (h*W + w)*ps addresses t in place (NCHW, or a channel
+        slice of an NHWC map), else a contiguous NCHW copy."""
+        if t.dtype == torch.float32 and t.shape[0] == 1 and (t.shape[2] == 1 or t.stride(2) == t.shape[3] * t.stride(3)):
+            return t, t.stride(1), t.stride(3)
+        t = f32c(t)
+        return t, t.stride(1), t.stride(3)
+    cls_probs, cls_cs, cls_ps = zip(*[pixel_linear(c) for c in cls_probs])
+    bbox_preds, box_cs, box_ps = zip(*[pixel_linear(b) for b in bbox_preds])
     A = cls_probs[0].shape[1]
     Hs = [c.shape[2] for c in cls_probs]
     Ws = [c.shape[3] for c in cls_probs]
@@ -363,8 +371,10 @@ def pyramid_proposals(cls_probs, bbox_preds, im_info, anchors, strides, pre_nms_
     scores = torch.empty((post_nms_top_n,), dtype=torch.float32, device=dev)
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     anc = float_array(np.asarray(anchors, np.float32).reshape(-1).tolist())
-    check(lib().upsnet_pyramid_proposals(stream(), L, ptr_array(cls_probs), ptr_array(bbox_preds), hs, ws_,
-                                         int_array(strides), anc, A, ptr(f32c(im_info)), int(pre_nms_top_n),
+    long_array = lambda v: (_lib.c_long * len(v))(*[int(x) for x in v])
+    check(lib().upsnet_pyramid_proposals_strided(stream(), L, ptr_array(cls_probs), ptr_array(bbox_preds), long_array(cls_cs),
+                                                 long_array(cls_ps), long_array(box_cs), long_array(box_ps), hs, ws_,
+                                                 int_array(strides), anc, A, ptr(f32c(im_info)), int(pre_nms_top_n),
                                          int(post_nms_top_n), float(nms_thresh), float(min_size), ptr(rois), ptr(scores),
                                          ptr(num), ptr(ws)), "pyramid_proposals")
     return rois, scores, num
@@ -391,6 +401,22 @@ def mask_roi(rois, bbox_delta, cls_prob, im_info, class_agnostic, score_thresh, 
                                 int(max_det), float_array(reg_weights), ptr(boxes), ptr(scores), ptr(cls), ptr(src),
                                 ptr(num), ptr(ws)), "mask_roi")
     return boxes, scores, cls, src, num
+
+
+def mask_logit_gather(mask_logit, row, cls, K=None):
+    """pan_logit [K,1,ms,ms] with pan_logit[k] = mask_logit[row[k], cls[k]] (rows / classes clamped): one gather kernel instead of
+    clamp + index_select + expand + gather. mask_logit: [n,C,ms,ms] in any dense layout (NCHW or channels_last)."""
+    require_cuda(mask_logit, row, cls)
+    n, C, mh, mw = mask_logit.shape
+    t = mask_logit if mask_logit.dtype == torch.float32 else mask_logit.float()
+    if not (t.stride(2) == mw * t.stride(3)):
+        t = t.contiguous()
+    K = row.shape[0] if K is None else int(K)
+    out = torch.empty((K, 1, mh, mw), dtype=torch.float32, device=t.device)
+    check(lib().upsnet_mask_logit_gather(stream(), ptr(t), n, C, mh * mw, t.stride(0), t.stride(1), t.stride(3),
+                                         ptr(row.to(torch.int32).contiguous()), ptr(cls.to(torch.int64).contiguous()), K, ptr(out)),
+          "mask_logit_gather")
+    return out
 
 
 # ----------------------------------------------------------------------------- panoptic head
@@ -494,11 +520,21 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
     xs = [nhwc(x.float()) for x in xs]
     cin = xs[0].shape[1]
     outs, ress = [], None
+    shapes = []
     for x in xs:
         N, C, H, W = x.shape
         if C != cin:
             raise RuntimeError("conv2d_nhwc_multi: channel mismatch")
-        outs.append(_nhwc_out(N, cout, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, x.device))
+        shapes.append((N, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, cout))
+    # the outputs of a multi-map launch are carved from ONE allocation (outs[0]._ups_flat), so that a following elementwise op over
+    # all maps (the RPN's sigmoid over 5 levels) is one launch over the flat buffer instead of one per map
+    sizes = [n * h * w * c for n, h, w, c in shapes]
+    flat = torch.empty((sum(sizes),), dtype=torch.float32, device=xs[0].device)
+    off = 0
+    for (n, h, w, c), sz in zip(shapes, sizes):
+        outs.append(flat[off:off + sz].view(n, h, w, c).permute(0, 3, 1, 2))
+        off += sz
+    outs[0]._ups_flat = flat
     if residuals is not None:
         ress = [nhwc(r.float()) for r in residuals]
         for r, o in zip(ress, outs):
