@@ -20,8 +20,10 @@
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 
-#define CB_BM 64
-#define CB_BN 64
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define CB_BM 128
+#define CB_BN 128
 #define CB_BK 32
 #define CB_PITCH 40   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
 
@@ -36,8 +38,13 @@ __device__ static inline void cb_split4(const float4 v, const bool valid, bf16x4
     }
 }
 
+// Tile (r06): 128 pixels x 128 channels per workgroup, 4 waves of 64 x 64 (2 x 2 MFMA blocks, 64 accumulator registers). The r01
+// form (64 x 64 per workgroup, 32 x 32 per wave) moved 16 KiB from L2 for every 2 MFMAs of a wave: 21.8 flop per L2 byte, i.e.
+// 20 TB/s of L2 traffic at the 445 TFLOP/s it reached -- it was L2-bound at 18 % of the bf16 peak. This form doubles the
+// arithmetic intensity (43.7 flop/B: A 16 KiB fp32 + B 8 KiB bf16 per 32-channel slab of a 128 x 128 tile), issues 8 (bf16) or
+// 24 (bf16x3) MFMAs per wave between two barriers instead of 2 / 6, and reads 4 LDS fragments per 4 / 12 MFMAs instead of 2 per 1 / 3.
 template <int SPLIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
 {
     __shared__ __attribute__((aligned(16))) __bf16 Ah[2][CB_BM][CB_PITCH];
@@ -67,69 +74,80 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     const int ntap = p.KH * p.KW;
     const int nslabs = ntap * (p.Cin / CB_BK);
 
-    // A staging: thread -> channels 4*ch4..+3 of pixels prow and prow + 32
+    // A staging: thread -> channels 4*ch4..+3 of pixels prow + 32 r, r = 0..3. The byte offset of every (tap, pixel) input
+    // position is tabulated once in LDS (bit 31 = outside the image / beyond the map: the buffer load then returns the zero
+    // padding), and K is walked channel slab outermost, TAP innermost: the 128-byte lines of a slab are shared by neighbouring
+    // taps (a 3x3 tap shifts the 128-pixel window by one pixel / one row), so 8 of 9 tap loads of a line hit the CU's L1
+    // instead of all of them going to L2 (the tap-outer walk touched 128 KiB of lines per tap: nothing survived in 32 KiB).
     const int ch4 = tid & 7, prow = tid >> 3;
-    int pix_n[2], pix_h[2], pix_w[2];
     const long HoWo = (long)sg.Ho * sg.Wo;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const long pp = p0 + prow + 32 * r;
+    __shared__ unsigned toff[9][CB_BM];
+    for (int idx = tid; idx < ntap * CB_BM; idx += 256) {
+        const int tap = idx / CB_BM, px = idx - tap * CB_BM;
+        const long pp = p0 + px;
+        unsigned o = 0x80000000u;
         if (pp < sg.M) {
             const int n = (int)(pp / HoWo);
             const int rem = (int)(pp - (long)n * HoWo);
-            pix_n[r] = n; pix_h[r] = (rem / sg.Wo) * p.stride - p.pad; pix_w[r] = (rem % sg.Wo) * p.stride - p.pad;
-        } else { pix_n[r] = -1; pix_h[r] = 0; pix_w[r] = 0; }
+            const int ki = tap / p.KW, kj = tap - ki * p.KW;
+            const int hi = (rem / sg.Wo) * p.stride - p.pad + ki * p.dil, wi = (rem % sg.Wo) * p.stride - p.pad + kj * p.dil;
+            if (hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W) o = 4u * (unsigned)(((n * sg.H + hi) * sg.W + wi) * p.Cin);
+        }
+        toff[tap][px] = o;
     }
-    const char *xbase = reinterpret_cast<const char *>(sg.x);
-    // B staging: thread -> 8 consecutive k (one 16-byte octet) of column bcol
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    // B staging: thread -> 8 consecutive k (one 16-byte octet) of columns bcol and bcol + 64
     const int bcol = tid >> 2, boct = tid & 3;
     const unsigned slab_bytes = (unsigned)p.ldw * CB_BK * 2u;
-    unsigned ob = ((unsigned)(n0 + bcol) * CB_BK + 8u * boct) * 2u;   // byte offset inside the packed weights, advances one slab per fetch
+    const unsigned ob0 = ((unsigned)(n0 + bcol) * CB_BK + 8u * boct) * 2u;   // byte offset inside a slab of the packed weights
     const char *whb = reinterpret_cast<const char *>(whi), *wlb = reinterpret_cast<const char *>(wlo);
+    const int cslabs = p.Cin / CB_BK;
 
-    unsigned oa0 = 0, oa1 = 0;
-    bool cv0 = false, cv1 = false;
-    int f_cs = 0, f_ki = 0, f_kj = 0;
-    bool f_newtap = true;
-    float4 ra0, ra1;
-    bool rv0 = false, rv1 = false;
-    uint4 rbh, rbl;
+    int f_cs = 0, f_tap = 0;   // (channel slab, tap) of the next step to fetch
+    float4 ra0, ra1, ra2, ra3;
+    uint4 rbh0, rbh1, rbl0, rbl1;
+    const unsigned ob64 = 64u * CB_BK * 2u;   // byte distance of column bcol + 64 inside a slab
 
-    floatx16 acc;
+    floatx16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();   // offset table complete
 
-#define CB_TAP(R)                                                                                         \
-    {                                                                                                     \
-        const int hi = pix_h[R] + f_ki * p.dil, wi = pix_w[R] + f_kj * p.dil;                             \
-        cv##R = pix_n[R] >= 0 && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;                            \
-        const int hc = min(max(hi, 0), sg.H - 1), wc = min(max(wi, 0), sg.W - 1), nc = max(pix_n[R], 0); \
-        oa##R = 4u * (unsigned)(((nc * sg.H + hc) * sg.W + wc) * p.Cin + 4 * ch4);                        \
-    }
+#define CB_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
 #define CB_FETCH                                                                                          \
     {                                                                                                     \
-        if (f_newtap) { CB_TAP(0) CB_TAP(1) }                                                             \
-        ra0 = *reinterpret_cast<const float4 *>(xbase + oa0); rv0 = cv0; oa0 += 4u * CB_BK;               \
-        ra1 = *reinterpret_cast<const float4 *>(xbase + oa1); rv1 = cv1; oa1 += 4u * CB_BK;               \
-        rbh = *reinterpret_cast<const uint4 *>(whb + ob);                                                 \
-        if (SPLIT == 3) rbl = *reinterpret_cast<const uint4 *>(wlb + ob);                                 \
-        ob += slab_bytes;                                                                                 \
-        f_cs += CB_BK;                                                                                    \
-        f_newtap = f_cs == p.Cin;                                                                         \
-        if (f_newtap) { f_cs = 0; if (++f_kj == p.KW) { f_kj = 0; ++f_ki; } }                             \
+        const unsigned c_ = (unsigned)(f_cs * (CB_BK * 4) + ch4 * 16);                                    \
+        CB_LDX(ra0, toff[f_tap][prow] + c_) CB_LDX(ra1, toff[f_tap][prow + 32] + c_)                      \
+        CB_LDX(ra2, toff[f_tap][prow + 64] + c_) CB_LDX(ra3, toff[f_tap][prow + 96] + c_)                 \
+        const unsigned ob = ob0 + (unsigned)(f_tap * cslabs + f_cs) * slab_bytes;                         \
+        rbh0 = *reinterpret_cast<const uint4 *>(whb + ob);                                                \
+        rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                                         \
+        if (SPLIT == 3) { rbl0 = *reinterpret_cast<const uint4 *>(wlb + ob); rbl1 = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
+        if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                       \
+    }
+#define CB_STASH_PX(BUF, R)                                                                               \
+    {                                                                                                     \
+        bf16x4 h_, l_;                                                                                    \
+        cb_split4(ra##R, true, h_, l_);                                                                  \
+        *reinterpret_cast<bf16x4 *>(&Ah[BUF][prow + 32 * R][4 * ch4]) = h_;                               \
+        if (SPLIT == 3) *reinterpret_cast<bf16x4 *>(&Al[BUF][prow + 32 * R][4 * ch4]) = l_;               \
     }
 #define CB_STASH(BUF)                                                                                     \
     {                                                                                                     \
-        bf16x4 h0, l0, h1, l1;                                                                            \
-        cb_split4(ra0, rv0, h0, l0);                                                                      \
-        cb_split4(ra1, rv1, h1, l1);                                                                      \
-        *reinterpret_cast<bf16x4 *>(&Ah[BUF][prow][4 * ch4]) = h0;                                        \
-        *reinterpret_cast<bf16x4 *>(&Ah[BUF][prow + 32][4 * ch4]) = h1;                                   \
-        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][8 * boct]) = rbh;                                       \
+        CB_STASH_PX(BUF, 0) CB_STASH_PX(BUF, 1) CB_STASH_PX(BUF, 2) CB_STASH_PX(BUF, 3)                   \
+        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][8 * boct]) = rbh0;                                      \
+        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][8 * boct]) = rbh1;                                 \
         if (SPLIT == 3) {                                                                                 \
-            *reinterpret_cast<bf16x4 *>(&Al[BUF][prow][4 * ch4]) = l0;                                    \
-            *reinterpret_cast<bf16x4 *>(&Al[BUF][prow + 32][4 * ch4]) = l1;                               \
-            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][8 * boct]) = rbl;                                   \
+            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][8 * boct]) = rbl0;                                  \
+            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol + 64][8 * boct]) = rbl1;                             \
         }                                                                                                 \
     }
 
@@ -143,47 +161,69 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
 #pragma unroll
         for (int t = 0; t < CB_BK / 16; ++t) {
             const int ko = (2 * t + akr) * 8;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&Ah[buf][wm * 32 + aij][ko]);
-            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(&Bh[buf][wn * 32 + aij][ko]);
-            if (SPLIT == 3) {   // small terms first
-                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&Al[buf][wm * 32 + aij][ko]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(&Bl[buf][wn * 32 + aij][ko]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            bf16x8 ah[2], bh[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[buf][wm * 64 + 32 * i + aij][ko]);
+                bh[i] = *reinterpret_cast<const bf16x8 *>(&Bh[buf][wn * 64 + 32 * i + aij][ko]);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            if (SPLIT == 3) {   // small terms first
+                bf16x8 al[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    al[i] = *reinterpret_cast<const bf16x8 *>(&Al[buf][wm * 64 + 32 * i + aij][ko]);
+                    bl[i] = *reinterpret_cast<const bf16x8 *>(&Bl[buf][wn * 64 + 32 * i + aij][ko]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
         if (more) CB_STASH(buf ^ 1)
         __syncthreads();
     }
-#undef CB_TAP
+#undef CB_LDX
 #undef CB_FETCH
 #undef CB_STASH
 
-    // ---- epilogue: + bias, + residual, ReLU (as conv.hip)
+    // ---- epilogue: + bias, + residual, ReLU (as conv.hip), per 32 x 32 block of the wave
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
-    const int co = n0 + wn * 32 + aij;
-    const bool co_ok = co < p.Cout;
-    const int coc = co_ok ? co : 0;
-    const float bv = has_bias ? p.bias[coc] : 0.f;
-    const long pbase = p0 + wm * 32 + 4 * akr;
-    float rr[16];
-    if (has_res) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            long pp = pbase + (r & 3) + 8 * (r >> 2);
-            pp = pp < sg.M ? pp : sg.M - 1;
-            rr[r] = sg.res[pp * p.Cout + coc];
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + 32 * j + aij;
+        const bool co_ok = co < p.Cout;
+        const int coc = co_ok ? co : 0;
+        const float bv = has_bias ? p.bias[coc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long pbase = p0 + wm * 64 + 32 * i + 4 * akr;
+            float rr[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long pp = pbase + (r & 3) + 8 * (r >> 2);
+                    pp = pp < sg.M ? pp : sg.M - 1;
+                    rr[r] = sg.res[pp * p.Cout + coc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long pp = pbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r];
+                if (has_bias) v = v + bv;
+                if (has_res) v = v + rr[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+            }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long pp = pbase + (r & 3) + 8 * (r >> 2);
-        float v = acc[r];
-        if (has_bias) v = v + bv;
-        if (has_res) v = v + rr[r];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
     }
 }
 
@@ -197,6 +237,9 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
                        reinterpret_cast<const float *>(wpack_hi), ldw, bias, KH, KW, stride, pad, 1, relu);
     if (rc) return rc;
     UPS_REQUIRE(ldw % CB_BN == 0, "conv2d_nhwc_bf16: ldw must be a multiple of %d (got %d)", CB_BN, ldw);
+    UPS_REQUIRE(KH * KW <= 9, "conv2d_nhwc_bf16: at most 9 taps");
+    for (int i = 0; i < p.nseg; ++i)   // bit 31 of a pixel offset flags the zero padding
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * Cin < (1L << 29), "conv2d_nhwc_bf16: feature map %d exceeds 2 GiB; split the batch", i);
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + CB_BM - 1) / CB_BM); }
     p.m_tiles = tiles;

@@ -79,6 +79,24 @@ def supported(m, x):
             m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
 
 
+# the bf16 kernels work on 128 x 128 tiles: layers with fewer workgroups than this (res5, the P5 / P6 maps, narrow heads) would leave
+# most CUs idle and stay on the fp32 kernels (exact, and faster there)
+BF16_MIN_WG = int(os.environ.get('UPSNET_BF16_MIN_WG', '192'))
+
+
+def _use_bf16(m, xs, always=False):
+    if PRECISION == 'fp32' or m.kernel_size[0] * m.kernel_size[1] > 9 or m.out_channels < 64:
+        return False
+    if always:   # layers whose batch size varies at run time: the choice (hence the rounding) must not depend on it
+        return True
+    k, st, pd, dl = m.kernel_size[0], m.stride[0], m.padding[0], m.dilation[0]
+    wgs = 0
+    for x in xs:
+        ho, wo = (x.shape[2] + 2 * pd - (dl * (k - 1) + 1)) // st + 1, (x.shape[3] + 2 * pd - (dl * (k - 1) + 1)) // st + 1
+        wgs += -(-(x.shape[0] * ho * wo) // 128)
+    return wgs * -(-m.out_channels // 128) >= BF16_MIN_WG
+
+
 def _bf16_plan(m):
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version, PRECISION)
@@ -155,7 +173,7 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
     winograd=False / 'always' pins the direct / the Winograd form (layers whose batch size varies at run time: the choice,
     hence the rounding, must not depend on it)."""
     if supported(m, x):
-        if PRECISION != 'fp32' and not residual_up:
+        if not residual_up and _use_bf16(m, [x], always=(winograd == 'always')):
             hi, lo, ldw = _bf16_plan(m)
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual])[0]
@@ -186,7 +204,7 @@ def conv_multi(m, xs, relu=False):
     """The same conv module applied to several feature maps (FPN levels) in ONE launch."""
     xs = list(xs)
     if len(xs) <= 5 and all(supported(m, x) for x in xs):
-        if PRECISION != 'fp32':
+        if _use_bf16(m, xs):
             hi, lo, ldw = _bf16_plan(m)
             return ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu)
         if _use_winograd(m, xs):

@@ -847,7 +847,7 @@ def pack_conv_weight_bf16(weight, split=True):
     require_cuda(weight)
     weight = f32c(weight)
     Cout, Cin, kh, kw = weight.shape
-    ldw = (Cout + 63) // 64 * 64
+    ldw = (Cout + 127) // 128 * 128
     shape = (kh * kw * Cin // 32, ldw, 32)
     hi = torch.empty(shape, dtype=torch.bfloat16, device=weight.device)
     lo = torch.empty(shape, dtype=torch.bfloat16, device=weight.device) if split else None
