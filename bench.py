@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (32x32x16), 2495 measured
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the same guide)
 
 
@@ -163,8 +164,8 @@ def main():
         n_w, t_w, f_w, _ = agg('conv', 'winograd')
         f_exec = f_c - f_w * (1.0 - 16.0 / 36.0)
         ex = f_exec / t_c / 1e12
-        roofline = {'kernel': 'dense convolution family: conv_igemm_f32_kernel (direct, csrc/conv.hip) + conv_wino16_f32_kernel '
-                              '(Winograd F(2x2,3x3), csrc/conv_wino.hip)', 'bound': 'mfma',
+        roofline = {'kernel': 'dense convolution family: conv1x1_frag_f32_kernel (csrc/conv1x1.hip) + conv_igemm_f32_kernel (csrc/conv.hip) + '
+                              'conv_wino16_f32_kernel (Winograd F(2x2,3x3), csrc/conv_wino.hip)', 'bound': 'mfma',
                     'achieved': round(ex, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
                     'achieved_algorithmic': round(alg, 3), 'frac_algorithmic': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -183,8 +184,19 @@ def main():
                     'direct': {'launches_timed': n_c - n_w, 'ms_per_image': round(1000.0 * (t_c - t_w) / n_sampled, 3),
                                'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3),
                                'frac': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
+        n_b, t_b, f_b, b_b = agg('conv_bf16')
+        if n_b and t_b > 0:   # --conv-precision bf16 / bf16x3 (BASELINE configs[2]): the layers that ran on the bf16 matrix cores
+            mult = 3.0 if args.conv_precision == 'bf16x3' else 1.0
+            roofline['bf16_matrix_cores'] = {
+                'kernel': 'conv_bf16_kernel (csrc/conv_bf16.hip, v_mfma_f32_32x32x16_bf16, fp32 accumulate; %s)' %
+                          ('3 MFMAs per product: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi' if mult == 3.0 else 'one MFMA per product'),
+                'bound': 'mfma', 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'achieved': round(mult * f_b / t_b / 1e12, 3), 'frac': round(mult * f_b / t_b / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                'achieved_algorithmic': round(f_b / t_b / 1e12, 3), 'launches_timed': n_b, 'ms_per_image': round(1000.0 * t_b / n_sampled, 3),
+                'note': 'layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem, the deconvolution, the FPN laterals with the '
+                        'upsampled add and the deformable convolutions stay on the fp32 kernels (they are in the fp32 family above)'}
         if n_d and t_d > 0:
-            roofline['deformable'] = {'kernel': 'conv_igemm_f32_kernel (deformable instances = fused DCN v1)', 'bound': 'mfma',
+            roofline['deformable'] = {'kernel': 'dcn_fused_f32_kernel (csrc/deform_fused.hip: fused deformable convolution v1, fp32 MFMA)', 'bound': 'mfma',
                                       'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                       'launches_timed': n_d, 'avg_launch_ms': round(1000.0 * t_d / n_d, 4),
                                       'algorithmic_flops_per_launch': f_d / n_d, 'algorithmic_bytes_per_launch': b_d / n_d,
@@ -259,11 +271,12 @@ def main():
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
-                   'dense_convs': 'hand-written fp32 MFMA implicit GEMM (csrc/conv.hip) for every convolution incl. the 7x7 stem and the 2x2 '
-                                  'deconvolution, NHWC, frozen BN folded, bias/residual/ReLU fused; 3x3 / stride-1 layers with >= 128 workgroups '
-                                  'of tiles (FPN, RPN, res2-res5 conv2, DCN offset convs, mask head) on the fp32 Winograd F(2x2,3x3) kernel '
-                                  '(csrc/conv_wino.hip, split-K below 160 workgroups); max-pool + FC GEMMs on PyTorch-ROCm',
-                   'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (fp32 MFMA), MaskROI, mask removal, '
+                   'dense_convs': 'hand-written fp32 MFMA kernels for every convolution, NHWC, frozen BN folded, bias/residual/ReLU fused: 1x1 layers on the '
+                                  'lean GEMM kernel (csrc/conv1x1.hip), 3x3 / stride-1 layers with >= 128 workgroups of tiles (FPN, RPN, res2-res5 conv2, '
+                                  'DCN offset convs, mask head) on the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip, split-K below 160 workgroups), '
+                                  'the rest (7x7 stem, strided 3x3, 2x2 deconvolution, narrow heads) on the implicit-GEMM kernel (csrc/conv.hip); '
+                                  'max-pool + FC GEMMs on PyTorch-ROCm',
+                   'custom_ops': 'HIP (libupsnet_hip.so): proposals, NMS, FPN ROIAlign, fused DCN (csrc/deform_fused.hip, fp32 MFMA), MaskROI, mask removal, '
                                  'panoptic fusion incl. x4 upsampling',
                    'parallelism': 'one image per rank (image i -> rank i mod N), one final RCCL gather of the label maps to rank 0', 'ranks': world,
                    'streams': 'whole forward (trunk, semantic head + mask head on a side stream concurrent with the proposal/detection '

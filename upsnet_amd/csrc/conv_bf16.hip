@@ -25,7 +25,8 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 #define CB_BM 128
 #define CB_BN 128
 #define CB_BK 32
-#define CB_PITCH 40   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+#define CB_PITCH 32   // bf16 elements per LDS row (64 bytes, no padding): the four 16-byte octets of a row are XOR-swizzled by (row >> 2) & 3
+#define CB_SW(ROW, OCT) (8 * ((OCT) ^ (((ROW) >> 2) & 3)))   // element offset of octet OCT inside row ROW (conflict-free b64 / b128)
 
 __device__ static inline void cb_split4(const float4 v, const bool valid, bf16x4 &hi, bf16x4 &lo)
 {
@@ -43,14 +44,17 @@ __device__ static inline void cb_split4(const float4 v, const bool valid, bf16x4
 // 20 TB/s of L2 traffic at the 445 TFLOP/s it reached -- it was L2-bound at 18 % of the bf16 peak. This form doubles the
 // arithmetic intensity (43.7 flop/B: A 16 KiB fp32 + B 8 KiB bf16 per 32-channel slab of a 128 x 128 tile), issues 8 (bf16) or
 // 24 (bf16x3) MFMAs per wave between two barriers instead of 2 / 6, and reads 4 LDS fragments per 4 / 12 MFMAs instead of 2 per 1 / 3.
-template <int SPLIT>
+// WN: 32-column MFMA blocks per wave: 2 -> 128 output channels per workgroup (used by both modes: 69 KiB of LDS for bf16x3 with
+// the unpadded swizzled rows = two workgroups per CU), 1 -> 64 (kept for measurements: slower, 629 vs ~520 us on FPN P2).
+template <int SPLIT, int WN>
 __global__ void __launch_bounds__(256, 2)
 conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
 {
+    constexpr int BN = 64 * WN;
     __shared__ __attribute__((aligned(16))) __bf16 Ah[2][CB_BM][CB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][CB_BN][CB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BN][CB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? CB_BM : 1][CB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? CB_BN : 1][CB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? BN : 1][CB_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -70,7 +74,7 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
     const ConvSeg sg = p.seg[si];
     const long p0 = (long)(m_t - sg.tile_start) * CB_BM;
-    const int n0 = n_t * CB_BN;
+    const int n0 = n_t * BN;
     const int ntap = p.KH * p.KW;
     const int nslabs = ntap * (p.Cin / CB_BK);
 
@@ -111,11 +115,11 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     uint4 rbh0, rbh1, rbl0, rbl1;
     const unsigned ob64 = 64u * CB_BK * 2u;   // byte distance of column bcol + 64 inside a slab
 
-    floatx16 acc[2][2];
+    floatx16 acc[2][WN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();   // offset table complete
@@ -129,25 +133,25 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
         CB_LDX(ra2, toff[f_tap][prow + 64] + c_) CB_LDX(ra3, toff[f_tap][prow + 96] + c_)                 \
         const unsigned ob = ob0 + (unsigned)(f_tap * cslabs + f_cs) * slab_bytes;                         \
         rbh0 = *reinterpret_cast<const uint4 *>(whb + ob);                                                \
-        rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                                         \
-        if (SPLIT == 3) { rbl0 = *reinterpret_cast<const uint4 *>(wlb + ob); rbl1 = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
+        if (WN == 2) rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                            \
+        if (SPLIT == 3) { rbl0 = *reinterpret_cast<const uint4 *>(wlb + ob); if (WN == 2) rbl1 = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
         if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                       \
     }
 #define CB_STASH_PX(BUF, R)                                                                               \
     {                                                                                                     \
         bf16x4 h_, l_;                                                                                    \
         cb_split4(ra##R, true, h_, l_);                                                                  \
-        *reinterpret_cast<bf16x4 *>(&Ah[BUF][prow + 32 * R][4 * ch4]) = h_;                               \
-        if (SPLIT == 3) *reinterpret_cast<bf16x4 *>(&Al[BUF][prow + 32 * R][4 * ch4]) = l_;               \
+        *reinterpret_cast<bf16x4 *>(&Ah[BUF][prow + 32 * R][CB_SW(prow + 32 * R, ch4 >> 1) + 4 * (ch4 & 1)]) = h_;                               \
+        if (SPLIT == 3) *reinterpret_cast<bf16x4 *>(&Al[BUF][prow + 32 * R][CB_SW(prow + 32 * R, ch4 >> 1) + 4 * (ch4 & 1)]) = l_;               \
     }
 #define CB_STASH(BUF)                                                                                     \
     {                                                                                                     \
         CB_STASH_PX(BUF, 0) CB_STASH_PX(BUF, 1) CB_STASH_PX(BUF, 2) CB_STASH_PX(BUF, 3)                   \
-        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][8 * boct]) = rbh0;                                      \
-        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][8 * boct]) = rbh1;                                 \
+        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][CB_SW(bcol, boct)]) = rbh0;                                      \
+        if (WN == 2) *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbh1;                   \
         if (SPLIT == 3) {                                                                                 \
-            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][8 * boct]) = rbl0;                                  \
-            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol + 64][8 * boct]) = rbl1;                             \
+            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][CB_SW(bcol, boct)]) = rbl0;                                  \
+            if (WN == 2) *reinterpret_cast<uint4 *>(&Bl[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbl1;                \
         }                                                                                                 \
     }
 
@@ -160,24 +164,22 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
         if (more) CB_FETCH
 #pragma unroll
         for (int t = 0; t < CB_BK / 16; ++t) {
-            const int ko = (2 * t + akr) * 8;
-            bf16x8 ah[2], bh[2];
+            const int ko = 2 * t + akr;   // octet of the slab this lane's fragment holds
+            bf16x8 ah[2], bh[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[buf][wm * 64 + 32 * i + aij][ko]);
-                bh[i] = *reinterpret_cast<const bf16x8 *>(&Bh[buf][wn * 64 + 32 * i + aij][ko]);
-            }
+            for (int i = 0; i < 2; ++i) ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[buf][wm * 64 + 32 * i + aij][CB_SW(wm * 64 + 32 * i + aij, ko)]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[buf][wn * (32 * WN) + 32 * j + aij][CB_SW(wn * (32 * WN) + 32 * j + aij, ko)]);
             if (SPLIT == 3) {   // small terms first
-                bf16x8 al[2], bl[2];
+                bf16x8 al[2], bl[WN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    al[i] = *reinterpret_cast<const bf16x8 *>(&Al[buf][wm * 64 + 32 * i + aij][ko]);
-                    bl[i] = *reinterpret_cast<const bf16x8 *>(&Bl[buf][wn * 64 + 32 * i + aij][ko]);
-                }
+                for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const bf16x8 *>(&Al[buf][wm * 64 + 32 * i + aij][CB_SW(wm * 64 + 32 * i + aij, ko)]);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[buf][wn * (32 * WN) + 32 * j + aij][CB_SW(wn * (32 * WN) + 32 * j + aij, ko)]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < WN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     }
@@ -185,7 +187,7 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
         if (more) CB_STASH(buf ^ 1)
         __syncthreads();
@@ -197,8 +199,8 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     // ---- epilogue: + bias, + residual, ReLU (as conv.hip), per 32 x 32 block of the wave
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + 32 * j + aij;
+    for (int j = 0; j < WN; ++j) {
+        const int co = n0 + wn * (32 * WN) + 32 * j + aij;
         const bool co_ok = co < p.Cout;
         const int coc = co_ok ? co : 0;
         const float bv = has_bias ? p.bias[coc] : 0.f;
@@ -243,11 +245,11 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + CB_BM - 1) / CB_BM); }
     p.m_tiles = tiles;
+    const __bf16 *hi = reinterpret_cast<const __bf16 *>(wpack_hi), *lo = reinterpret_cast<const __bf16 *>(wpack_lo);
     p.n_tiles = ldw / CB_BN;
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-    const __bf16 *hi = reinterpret_cast<const __bf16 *>(wpack_hi), *lo = reinterpret_cast<const __bf16 *>(wpack_lo);
-    if (lo) hipLaunchKernelGGL(conv_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
-    else hipLaunchKernelGGL(conv_bf16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+    if (lo) hipLaunchKernelGGL((conv_bf16_kernel<3, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+    else hipLaunchKernelGGL((conv_bf16_kernel<1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
     UPS_CHECK_LAUNCH("conv_bf16_kernel");
     return 0;
 }
