@@ -86,7 +86,7 @@ mroi_finalize_kernel(const int P, const int nmax, const int max_det, const float
                      const float *__restrict__ cscores, const int *__restrict__ csrc, const int *__restrict__ ccls,
                      const int *__restrict__ keep_idx, const int *__restrict__ keep_cnt, float *__restrict__ boxes_out,
                      float *__restrict__ scores_out, int64_t *__restrict__ cls_out, int *__restrict__ src_out,
-                     int *__restrict__ num_out)
+                     int *__restrict__ num_out, const int *__restrict__ status)
 {
     __shared__ int sh[DET_T / 64];
     __shared__ unsigned hist[256];
@@ -164,7 +164,9 @@ mroi_finalize_kernel(const int P, const int nmax, const int max_det, const float
             scores_out[0] = 1.f; cls_out[0] = 0; src_out[0] = 0;
             cnt = 1;
         }
-        *num_out = cnt;
+        // more candidates than the fixed capacity (class-agnostic mode: 8192) were above the score threshold: the result would
+        // silently differ from the reference -- report it through the count (negative), the host raises
+        *num_out = *status ? -cnt : cnt;
     }
 }
 
@@ -233,7 +235,7 @@ extern "C" int upsnet_mask_roi(void *stream, const float *rois, const float *bbo
     int rc = ups_nms_batched_impl(st, cboxes, cscores, counts, nullptr, P, nmax, nms_thresh, 0, keep, keepcnt, ws + m.nms, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(mroi_finalize_kernel, dim3(1), dim3(DET_T), 0, st, P, nmax, max_det, cboxes, cscores, csrc, ccls, keep,
-                       keepcnt, boxes_out, scores_out, cls_out, src_out, num_out);
+                       keepcnt, boxes_out, scores_out, cls_out, src_out, num_out, status);
     UPS_CHECK_LAUNCH("mroi_finalize_kernel");
     return 0;
 }

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..config.config import config
 from ..operators.modules.mask_removal import MaskRemoval
-from ..operators.modules.mask_roi import MaskROI
+from ..operators.modules.mask_roi import MaskROI, check_count
 from ..operators.modules.pyramid_proposal import PyramidProposal
 from ..operators.modules.unary_logits import SegTerm
 from . import hipconv
@@ -356,6 +356,7 @@ class resnet_upsnet(resnet_rcnn):
         t = st.get('tail')
         if t is not None:   # whole forward was in the graph: ONE host read
             n_det, n_pan, n_extra, k = counters if counters is not None else t['counters'].tolist()
+            check_count(n_det), check_count(n_pan)
             if n_extra == 0 and n_det <= st['max_det'] and n_pan <= min(256, st['pan_boxes'].shape[0]):
                 # every output is a view into the graph's buffers: no launch after the replay. They are valid until this graph
                 # instance is replayed again, graph_slots forwards of this shape later (the usual contract of graph-replayed
@@ -368,6 +369,7 @@ class resnet_upsnet(resnet_rcnn):
                 return out if self.graph_outputs_alias else {key: v.clone() for key, v in out.items()}
         else:
             n_det, n_pan, n_extra = st['nums'].tolist()
+            check_count(n_det), check_count(n_pan)
         det_boxes, det_scores, det_cls = st['det_boxes'][:n_det], st['det_scores'][:n_det], st['det_cls'][:n_det]
         if graphed:   # results handed to the caller must not alias the graph's static buffers (overwritten by the next replay)
             det_boxes, det_scores, det_cls = det_boxes.clone(), det_scores.clone(), det_cls.clone()

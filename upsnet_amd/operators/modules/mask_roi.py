@@ -10,6 +10,15 @@ from ... import ops
 from ...config.config import config
 
 
+def check_count(n):
+    """The device selection reports a candidate overflow (more (ROI, class) pairs above score_thresh than its fixed capacity of
+    8192 in class-agnostic mode) as a negative count: the result would differ from the reference, so fail loudly."""
+    if n < 0:
+        raise RuntimeError("MaskROI: more than 8192 class-agnostic candidates above score_thresh; raise the threshold or lower the "
+                           "number of proposals (the reference has no such limit, the device selection does)")
+    return n
+
+
 class MaskROI(nn.Module):
 
     def __init__(self, clip_boxes, bbox_class_agnostic, top_n, num_classes, nms_thresh=None, class_agnostic=False,
@@ -41,5 +50,5 @@ class MaskROI(nn.Module):
         if cls_score is not None or cls_label is not None:
             raise NotImplementedError("cls_score / cls_label are training-time inputs")
         boxes, scores, cls, src, num = self.forward_padded(bottom_rois, bbox_delta, cls_prob, im_info)
-        n = int(num.item())
+        n = check_count(int(num.item()))
         return scores[:n], boxes[:n], cls[:n]

@@ -485,6 +485,8 @@ def panoptic_fuse(fcn_output, num_stuff, mask_rois5, mask_logit, cls_idx, keep, 
     _, S, H, W = fcn.shape
     mask_rois5 = f32c(mask_rois5)
     m = mask_rois5.shape[0]
+    if m > 256:   # the kernels keep their instance table in LDS (FUSE_MAXK); more rows would be dropped silently
+        raise RuntimeError("panoptic_fuse: at most 256 instance rows (got %d); use mask_paste + seg_term + panoptic_argmax" % m)
     mask_logit = f32c(mask_logit).reshape(m, -1)
     ms = int(round(mask_logit.shape[1] ** 0.5))
     pan = torch.empty((1, H, W), dtype=torch.int64, device=fcn.device)
@@ -631,6 +633,8 @@ def panoptic_fuse_up(fcn_score, scale, num_stuff, mask_rois5, mask_logit, cls_id
     sc = sc if is_nhwc else sc.contiguous()
     mask_rois5 = f32c(mask_rois5)
     m = mask_rois5.shape[0]
+    if m > 256:   # the kernels keep their instance table in LDS (FUSE_MAXK); more rows would be dropped silently
+        raise RuntimeError("panoptic_fuse: at most 256 instance rows (got %d); use mask_paste + seg_term + panoptic_argmax" % m)
     mask_logit = f32c(mask_logit).reshape(m, -1)
     ms = int(round(mask_logit.shape[1] ** 0.5))
     H, W = Hs * scale, Ws * scale
