@@ -146,6 +146,14 @@ int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float *const x[]
                                   const float *const mask[], float *const out[], const int height[], const int width[],
                                   int cin, int cout, int kh, int kw, int pad, int stride, int dil, const float *wpack,
                                   const float *bias, int relu);
+/* Split-K form for ONE small map (the DCN bottlenecks of a ResNet-101-DCN backbone have 96-273 tiles for 256 CUs): the (channel slab,
+ * tap) walk is divided over ksplit (2..8) workgroups per tile, raw partial sums go to `workspace`
+ * (upsnet_deform_conv_fused_splitk_workspace_bytes) and a fixed-order reduce kernel adds bias / ReLU (deterministic). Cout % 4 == 0. */
+size_t upsnet_deform_conv_fused_splitk_workspace_bytes(int height, int width, int cout, int kh, int kw, int pad, int stride, int dil,
+                                                       int ksplit);
+int upsnet_deform_conv_fused_nhwc_splitk(void *stream, const float *x, const float *offset, const float *mask, float *out, int height,
+                                         int width, int cin, int cout, int kh, int kw, int pad, int stride, int dil,
+                                         const float *wpack, const float *bias, int relu, int ksplit, void *workspace);
 void upsnet_dcn_tuning(int variant);
 
 /* ============================== Input blob (the step before the path) ============================== */

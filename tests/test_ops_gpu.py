@@ -123,6 +123,31 @@ def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu, kind):
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)  # fp32 logits within 1e-4 (BASELINE.json)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(256, 256, 25, 42), (128, 128, 50, 84), (512, 512, 13, 21)])
+def test_deform_conv_fused_splitk_small_maps(U, cin, cout, H, W):
+    """The DCN bottlenecks of the R101-DCN backbone (configs[3]) are single small maps: the fused kernel splits K over up to 8
+    workgroups per tile + a fixed-order reduce. Same result as the unsplit kernel within fp32 summation order, 1e-4 vs the oracle."""
+    rng = np.random.default_rng(cin + H)
+    w = (rng.normal(size=(cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    x = rng.normal(size=(1, cin, H, W)).astype(np.float32)
+    off = (rng.normal(size=(1, 18, H, W)) * 2).astype(np.float32)
+    wp = U.pack_dcn_weight(cu(w), 'frag')
+    ks = U.dcn_ksplit([torch.empty(1, cout, H, W)], cin, cout, 9)
+    assert ks > 1
+    out = U.deform_conv_fused([cu(x)], [cu(off)], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True)[0].cpu().numpy()[0]
+    ref = _dcn_ref(x[0], off[0], w, b, 3, 1, 1, 1, None, True)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4)
+    U.DCN_SPLITK = False
+    try:
+        out1 = U.deform_conv_fused([cu(x)], [cu(off)], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True)[0].cpu().numpy()[0]
+    finally:
+        U.DCN_SPLITK = True
+    np.testing.assert_allclose(out, out1, rtol=1e-5, atol=1e-5)
+    again = U.deform_conv_fused([cu(x)], [cu(off)], wp, cu(b), cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True)[0].cpu().numpy()[0]
+    assert np.array_equal(out, again)     # fixed-order reduce: bit-repeatable
+
+
 @pytest.mark.parametrize("k,pad,stride,dil", [(3, 2, 1, 2), (3, 1, 2, 1), (1, 0, 1, 1), (5, 2, 1, 1)])
 def test_deform_conv_fused_geometries(U, k, pad, stride, dil):
     """Dilated (the reference's dilated res5 option), strided, 1x1 and 5x5 deformable kernels through csrc/deform_fused.hip; every

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "upsnet_dcn_packed_weight_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "upsnet_dcn_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_deform_conv_fused_nhwc": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 7 + [P, P, c_int]),
+    "upsnet_deform_conv_fused_splitk_workspace_bytes": (c_size_t, [c_int] * 9),
+    "upsnet_deform_conv_fused_nhwc_splitk": (c_int, [P, P, P, P, P] + [c_int] * 9 + [P, P, c_int, c_int, P]),
     "upsnet_dcn_tuning": (None, [c_int]),
     "upsnet_conv1x1_frag_nhwc_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int]),
     "upsnet_conv1x1_tuning": (None, [c_int]),

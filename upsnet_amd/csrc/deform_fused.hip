@@ -83,11 +83,15 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const int lhalf = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles (vertically adjacent
     // tiles share their sampling halos in that XCD's L2) and all n-tiles of an m-tile. Same scheme as conv_igemm_f32_kernel.
-    int m_t, n_t;
+    // Split-K (p.ksplit > 1, single small maps: the backbone's DCN bottlenecks have 96-273 tiles for 256 CUs): workgroup kz walks
+    // its share of the (channel slab, tap) steps and writes raw partial sums; conv_splitk_reduce adds bias / ReLU in a fixed order.
+    int m_t, n_t, kz;
     {
         const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
-        const int bid = (int)blockIdx.x;
+        const int base_grid = 8 * per * nt;
+        kz = (int)blockIdx.x / base_grid;
+        const int bid = (int)blockIdx.x - kz * base_grid;
         const int q = bid >> 3;
         n_t = q % nt;
         const int local = q / nt;
@@ -107,7 +111,10 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const int t_y = t_rem / tiles_x, t_x = t_rem - t_y * tiles_x;
     const int ntap = p.KH * p.KW;
     const int cslabs = p.Cin >> 5;
-    const int nsl = cslabs * ntap;                 // (channel slab, tap) steps of the K walk, tap innermost
+    const int nsl_all = cslabs * ntap;             // (channel slab, tap) steps of the K walk, tap innermost
+    const int s_per = (nsl_all + p.ksplit - 1) / p.ksplit;
+    const int s_begin = kz * s_per;
+    const int nsl = min(nsl_all - s_begin, s_per);  // steps of this workgroup (the launcher guarantees >= 1)
 
     // ---- sampling table of this tile, once: deform_conv_kernel.cu:227-240 (positions), :88-118 (corners, weights -- the same fp32
     // expressions, evaluated here instead of per channel)
@@ -164,11 +171,11 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     // fragment units of step h: quarter 2h + lhalf, rows l32 (block 0) and 32 + l32 (block 1)
     // B: lane's float4 of global step g = 4 s + h sits at wbase + g * 1024 + lhalf * 512 + l32 * 16
     const int cb = 4 * n_t + wave;
-    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)cb * (size_t)nsl * 4096u;
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)cb * (size_t)nsl_all * 4096u;
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl_all * 4096, 0x00020000);
     const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
-    const int gmax = nsl * 4 - 1;
+    const int gmax = nsl_all * 4 - 1;
 
     floatx16 acc0, acc1;
 #pragma unroll
@@ -177,7 +184,7 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     float4 xc00, xc01, xc02, xc03, xc10, xc11, xc12, xc13;   // register set X: [pixel][corner]
     float4 yc00, yc01, yc02, yc03, yc10, yc11, yc12, yc13;   // register set Y
     float4 breg[DF_RING];
-    int f_cs = 0, f_tap = 0;                                   // (channel slab, tap) of the NEXT step to fetch
+    int f_cs = s_begin / ntap, f_tap = s_begin - (s_begin / ntap) * ntap;   // (channel slab, tap) of the NEXT step to fetch
 
 #define DF_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
@@ -249,17 +256,18 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     uintx4 no0, no1;                                           // corner offsets of the next step to fetch (pre-read from the table)
     DF_NEXT_OFFSETS
     DF_FETCH(x)
+    const int tap0 = s_begin - (s_begin / ntap) * ntap;       // tap of this workgroup's first step
 #pragma unroll
-    for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, u)
+    for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, 4 * s_begin + u)
     DF_NEXT_OFFSETS
     if (SETS == 2 && nsl > 1) { DF_FETCH(y) DF_NEXT_OFFSETS }
-    DF_STASH_PX(x, 0, prow, st0, 0, 0)
-    DF_STASH_PX(x, 1, prow + 32, st1, 0, 0)
+    DF_STASH_PX(x, 0, prow, st0, tap0, 0)
+    DF_STASH_PX(x, 1, prow + 32, st1, tap0, 0)
     __syncthreads();
     float4 a0, a1;
     DF_FRAG(0, 0, a0, a1)
-    int g = 0;
-    int s_tap = ntap > 1 ? 1 : 0;   // tap of step s+1
+    int g = 4 * s_begin;
+    int s_tap = tap0 + 1 == ntap ? 0 : tap0 + 1;   // tap of step s+1
     if (SETS == 2) {
         for (int s = 0; s < nsl; s += 2) {
             DF_STEP(0, x, y, s + 2 < nsl, s + 1 < nsl, s_tap)
@@ -297,9 +305,14 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
             const int px = 32 * i + 4 * lhalf + (r & 3) + 8 * (r >> 2);       // = tile row 4 i + (r >> 2), column 4 lhalf + (r & 3)
             const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
             float v = i == 0 ? acc0[r] : acc1[r];
+            const long pp = ((long)t_n * sg.Ho + ho) * sg.Wo + wo;
+            if (p.ksplit > 1) {   // raw partial sums [kz][pixel][Cout]; bias / ReLU in the reduce kernel
+                if (co_ok && ho < sg.Ho && wo < sg.Wo) p.partial[((long)kz * p.m_total + pp) * p.Cout + co] = v;
+                continue;
+            }
             v = v + bv;
             if (p.relu) v = fmaxf(v, 0.f);
-            if (co_ok && ho < sg.Ho && wo < sg.Wo) sg.out[(((long)t_n * sg.Ho + ho) * sg.Wo + wo) * p.Cout + co] = v;
+            if (co_ok && ho < sg.Ho && wo < sg.Wo) sg.out[pp * p.Cout + co] = v;
         }
     }
 }
@@ -309,10 +322,9 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 static int g_dcn_variant = 1;
 extern "C" void upsnet_dcn_tuning(int variant) { g_dcn_variant = variant; }
 
-extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
-                                             const float *const mask[], float *const out[], const int height[], const int width[],
-                                             int cin, int cout, int kh, int kw, int pad, int stride, int dil, const float *wpack,
-                                             const float *bias, int relu)
+static int dcn_fused_launch(void *stream, int nlev, const float *const x[], const float *const offset[], const float *const mask[],
+                            float *const out[], const int height[], const int width[], int cin, int cout, int kh, int kw, int pad, int stride,
+                            int dil, const float *wpack, const float *bias, int relu, int ksplit, void *workspace)
 {
     UPS_REQUIRE(nlev >= 1 && nlev <= 4 && offset, "deform_conv_fused_nhwc: nlev must be 1..4 and offsets given");
     for (int l = 0; l < nlev; ++l) UPS_REQUIRE(offset[l] && (!mask || mask[l]), "deform_conv_fused_nhwc: null offset/mask at level %d", l);
@@ -331,8 +343,16 @@ extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float
     }
     p.m_tiles = tiles;
     p.n_tiles = (cout + DF_BN - 1) / DF_BN;
+    const int nsl = (cin / 32) * kh * kw;
+    if (ksplit > 1) {
+        UPS_REQUIRE(nlev == 1 && workspace && ksplit <= 8 && cout % 4 == 0, "deform_conv_fused_nhwc_splitk: one map, a workspace, ksplit <= 8, Cout %% 4 == 0");
+        UPS_REQUIRE(((nsl + ksplit - 1) / ksplit) * (ksplit - 1) < nsl, "deform_conv_fused_nhwc_splitk: %d K steps cannot be split %d ways", nsl, ksplit);
+        p.ksplit = ksplit;
+        p.partial = (float *)workspace;
+        p.m_total = p.seg[0].M;
+    }
     const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * (16 + 16 + 4);
-    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * p.ksplit;
     const int v = g_dcn_variant;
 #define DF_LAUNCH(SETS, WPE)                                                                                           \
     if (mask) hipLaunchKernelGGL((dcn_fused_f32_kernel<true, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p); \
@@ -340,5 +360,34 @@ extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float
     if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else if (v == 3) { DF_LAUNCH(1, 4) } else { DF_LAUNCH(2, 3) }
 #undef DF_LAUNCH
     UPS_CHECK_LAUNCH("dcn_fused_f32_kernel");
+    if (p.ksplit > 1)
+        return conv_splitk_reduce((hipStream_t)stream, p.partial, p.ksplit, p.m_total, p.seg[0].M, cout, bias, nullptr, relu, out[0]);
     return 0;
+}
+
+extern "C" int upsnet_deform_conv_fused_nhwc(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                             const float *const mask[], float *const out[], const int height[], const int width[],
+                                             int cin, int cout, int kh, int kw, int pad, int stride, int dil, const float *wpack,
+                                             const float *bias, int relu)
+{
+    return dcn_fused_launch(stream, nlev, x, offset, mask, out, height, width, cin, cout, kh, kw, pad, stride, dil, wpack, bias, relu, 1, nullptr);
+}
+
+extern "C" size_t upsnet_deform_conv_fused_splitk_workspace_bytes(int height, int width, int cout, int kh, int kw, int pad, int stride,
+                                                                   int dil, int ksplit)
+{
+    const long Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || ksplit < 1) return 0;
+    return (size_t)ksplit * Ho * Wo * cout * sizeof(float);
+}
+
+extern "C" int upsnet_deform_conv_fused_nhwc_splitk(void *stream, const float *x, const float *offset, const float *mask, float *out,
+                                                    int height, int width, int cin, int cout, int kh, int kw, int pad, int stride, int dil,
+                                                    const float *wpack, const float *bias, int relu, int ksplit, void *workspace)
+{
+    const float *xs[1] = {x}, *os_[1] = {offset}, *ms[1] = {mask};
+    float *outs[1] = {out};
+    const int hh[1] = {height}, ww[1] = {width};
+    return dcn_fused_launch(stream, 1, xs, os_, mask ? ms : nullptr, outs, hh, ww, cin, cout, kh, kw, pad, stride, dil, wpack, bias, relu,
+                            ksplit, workspace);
 }

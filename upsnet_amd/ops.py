@@ -207,6 +207,34 @@ def _nhwc_out(n, c, h, w, device):
     return torch.empty((n, h, w, c), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
 
 
+DCN_SPLITK = os.environ.get('UPSNET_DCN_SPLITK', '1') != '0'
+
+
+def dcn_ksplit(outs, cin, cout, taps):
+    """Split-K factor of the fused deformable kernel for one small map: enough workgroups for ~2 per CU, >= 9 K steps each."""
+    if not DCN_SPLITK or cout % 4:
+        return 1
+    o = outs[0]
+    wgs = o.shape[0] * -(-o.shape[2] // 8) * -(-o.shape[3] // 8) * -(-cout // 128)
+    nsl = cin // 32 * taps
+    ks = 1
+    while ks < 8 and wgs * ks < 384 and nsl // (ks + 1) >= 9:
+        ks += 1
+    while ks > 1 and -(-nsl // ks) * (ks - 1) >= nsl:
+        ks -= 1
+    return ks
+
+
+def _dcn_event(ev0, xs, outs, cin, cout, ksize):
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    npix = sum(o.shape[2] * o.shape[3] for o in outs)
+    taps = ksize[0] * ksize[1]
+    PROFILE['events'].append(('dcn_fused', ev0, ev1, 2.0 * cout * cin * taps * npix,
+                              4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps),
+                              "dcn %d->%d %s" % (cin, cout, [tuple(x.shape[2:]) for x in xs])))
+
+
 def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, dil, masks=None, relu=False):
     """Fused deformable conv over up to 4 maps sharing weights. xs/offsets/masks: lists of logical NCHW
     tensors with batch 1; wpack = (packed weight, ldw) from pack_dcn_weight; returns channels_last outputs."""
@@ -233,6 +261,18 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
     if wp == 'frag':   # (kind, packed) from pack_dcn_weight: second-generation kernel
         if not (pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]):
             raise RuntimeError("deform_conv_fused: square pad / stride / dilation only")
+        ks = dcn_ksplit(outs, cin, cout, ksize[0] * ksize[1]) if n == 1 else 1
+        if ks > 1:
+            wsb = lib().upsnet_deform_conv_fused_splitk_workspace_bytes(xs[0].shape[2], xs[0].shape[3], int(cout), ksize[0], ksize[1], pad[0],
+                                                                        stride[0], dil[0], ks)
+            ws = _ws(wsb, xs[0].device)
+            check(lib().upsnet_deform_conv_fused_nhwc_splitk(stream(), ptr(xs[0]), ptr(offsets[0]), ptr(masks[0]) if masks is not None else None,
+                                                             ptr(outs[0]), xs[0].shape[2], xs[0].shape[3], int(cin), int(cout), ksize[0],
+                                                             ksize[1], pad[0], stride[0], dil[0], ptr(ldw), ptr(b), int(bool(relu)), ks, ptr(ws)),
+                  "deform_conv_fused_nhwc_splitk")
+            if PROFILE['enabled']:
+                _dcn_event(ev0, xs, outs, cin, cout, ksize)
+            return outs
         check(lib().upsnet_deform_conv_fused_nhwc(stream(), n, ptr_array(xs), ptr_array(offsets),
                                                   ptr_array(masks) if masks is not None else None, ptr_array(outs),
                                                   int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
@@ -246,12 +286,7 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
                                                     dil[0], dil[1], 1, ptr(wp), int(ldw), ptr(b), int(bool(relu))),
               "deform_conv_forward_nhwc")
     if PROFILE['enabled']:
-        ev1.record()
-        npix = sum(o.shape[2] * o.shape[3] for o in outs)
-        taps = ksize[0] * ksize[1]
-        PROFILE['events'].append(('dcn_fused', ev0, ev1, 2.0 * cout * cin * taps * npix,
-                                  4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps),
-                                  "dcn %d->%d %s" % (cin, cout, [tuple(x.shape[2:]) for x in xs])))
+        _dcn_event(ev0, xs, outs, cin, cout, ksize)
     return outs
 
 
