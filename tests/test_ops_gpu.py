@@ -163,11 +163,11 @@ def test_deform_conv_fused_geometries(U, k, pad, stride, dil):
     from upsnet_amd._lib import lib
     outs = []
     try:
-        for variant in (1, 2, 3, 0):
+        for variant in (1, 2, 3, 4):
             lib().upsnet_dcn_tuning(variant)
             outs.append(U.deform_conv_fused([cu(x)], [cu(off)], wp, None, cin, cout, (k, k), (stride, stride), (pad, pad), (dil, dil))[0].cpu().numpy()[0])
     finally:
-        lib().upsnet_dcn_tuning(1)
+        lib().upsnet_dcn_tuning(0)
     np.testing.assert_allclose(outs[0], ref, rtol=1e-4, atol=1e-4)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])

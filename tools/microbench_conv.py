@@ -68,7 +68,7 @@ if not only or 'dcn' in only:
         hw = sum(h * w for h, w in sizes)
         for std in (2.0, 0.3):   # offset spread in pixels (the synthetic benchmark weights give ~0.3-3 px)
             offs = [(torch.randn(1, 18, h, w, device='cuda') * std).contiguous(memory_format=torch.channels_last) for h, w in sizes]
-            for kind, variants in (('igemm', (None,)), ('frag', (1, 2, 3, 0))):
+            for kind, variants in (('igemm', (None,)), ('frag', (1, 2))):
                 wp = ops.pack_dcn_weight(wgt, kind)
                 for v in variants:
                     if v is not None:
@@ -76,4 +76,4 @@ if not only or 'dcn' in only:
                     bench("dcn %s%s %d->%d 4 levels, offsets N(0,%.1f)" % (kind, '' if v is None else ' v%d' % v, cin, cout, std),
                           lambda: ops.deform_conv_fused(xs, offs, wp, None, cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True),
                           2.0 * cout * cin * 9 * hw, 4.0 * hw * (cin + 18 + cout))
-            lib().upsnet_dcn_tuning(1)
+            lib().upsnet_dcn_tuning(0)

@@ -23,6 +23,8 @@
 //     gather of slab s+2 is issued while slab s+1 is blended and slab s is contracted.
 // Tile: 8 x 8 output pixels x 128 output channels per workgroup (4 waves; wave w owns column block w and both 32-row blocks), fp32
 // products and accumulation on v_mfma_f32_32x32x2_f32 in a fixed order (bit-repeatable). Epilogue: + bias, ReLU, NHWC store.
+#include <stdlib.h>
+
 #include "conv_params.h"
 #include "upsnet_hip.h"
 
@@ -317,9 +319,9 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     }
 }
 
-// development knob for A/B runs: 1 = one corner set at 3 waves / SIMD (default), 2 = two sets at 2 waves / SIMD,
-// 3 = one set at 4, 0 = two sets at 3 (the last two spill: kept for measurements only)
-static int g_dcn_variant = 1;
+// development knob for A/B runs: 0 = auto (default), 1 = one corner set at 3 waves / SIMD, 2 = two sets at 2 waves / SIMD,
+// 3 = one set at 4, 4 = two sets at 3 (the last two spill: kept for measurements only)
+static int g_dcn_variant = 0;
 extern "C" void upsnet_dcn_tuning(int variant) { g_dcn_variant = variant; }
 
 static int dcn_fused_launch(void *stream, int nlev, const float *const x[], const float *const offset[], const float *const mask[],
@@ -353,7 +355,10 @@ static int dcn_fused_launch(void *stream, int nlev, const float *const x[], cons
     }
     const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * (16 + 16 + 4);
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * p.ksplit;
-    const int v = g_dcn_variant;
+    // auto = one corner set at 3 waves per SIMD everywhere. (Two sets -- deeper gather lookahead -- for grids below
+    // UPSNET_DCN_SMALL_GRID workgroups was measured on the R101-DCN backbone: 106.6 vs 107.7 img/s, so the default threshold is 0.)
+    const int dcn_small = atoi(getenv("UPSNET_DCN_SMALL_GRID") ? getenv("UPSNET_DCN_SMALL_GRID") : "0");
+    const int v = g_dcn_variant ? g_dcn_variant : (grid < dcn_small ? 2 : 1);
 #define DF_LAUNCH(SETS, WPE)                                                                                           \
     if (mask) hipLaunchKernelGGL((dcn_fused_f32_kernel<true, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p); \
     else hipLaunchKernelGGL((dcn_fused_f32_kernel<false, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
