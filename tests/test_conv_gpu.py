@@ -271,6 +271,9 @@ def test_winograd_splitk_vs_torch(N, H, W, Cin, Cout, ksplit, relu, res):
     (2, 256, 256, 14, 14, 3, 1, 1, True, False),
     (1, 512, 19, 24, 40, 1, 1, 0, False, False),
     (1, 2048, 256, 8, 16, 1, 1, 0, False, False),
+    (1, 128, 160, 37, 45, 3, 1, 1, True, True),       # haloed-patch 3x3 kernel: partial 8x16 tiles on both edges, Cout not % 128
+    (3, 32, 128, 9, 17, 3, 1, 1, False, False),       # batch > 1, one K slab, map barely larger than a tile
+    (1, 64, 64, 16, 32, 3, 2, 1, True, False),        # strided 3x3 stays on the general kernel
 ])
 @pytest.mark.parametrize("split", [True, False])
 def test_conv_bf16_matrix_cores_vs_torch(N, Cin, Cout, H, W, k, stride, pad, relu, res, split):

@@ -14,6 +14,8 @@
 // channels, double-buffered LDS, loads of slab s+1 in flight while slab s is contracted, one barrier per slab; operand
 // addressing (incremental 32-bit offsets), XCD-aware tile order, multi-map launches and the bias/residual/ReLU epilogue are
 // those of conv.hip.
+#include <stdlib.h>
+
 #include "conv_params.h"
 #include "upsnet_hip.h"
 
@@ -229,6 +231,219 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a HALOED INPUT PATCH in LDS (r06). The general kernel above stages the A tile of every
+// (channel slab, tap) step separately: 9 x 128 pixels x 32 channels per slab, although the nine taps look at the same
+// (8+2) x (16+2) pixels. Here a workgroup owns an 8 x 16 block of output pixels (x 128 output channels) and stages the 180-pixel
+// patch of a channel slab ONCE (bf16, 64 B per pixel, octets XOR-swizzled by (pixel >> 2) & 3); the A fragment of tap (ki, kj) is
+// the same LDS read shifted by 18 ki + kj pixels. Per slab the L2 -> LDS traffic of a workgroup falls from 9 x (16 KiB fp32 A +
+// 8 KiB B) = 216 KiB to 23 KiB A + 72 KiB B = 95 KiB (99 flop per byte instead of 43.7), the L1 -> LDS stream from 96 to 41 B/clk
+// per CU at the full MFMA rate, and the fp32 -> bf16 conversions are done once per pixel instead of 9 times.
+// B: one tap's [128 columns][32 k] tile per step through LDS (double-buffered), as above. One barrier per step (8 / 24 MFMAs).
+#define H3_TH 8
+#define H3_TW 16
+#define H3_PW (H3_TW + 2)
+#define H3_NPX ((H3_TH + 2) * H3_PW)                      // 180 patch pixels
+#define H3_LD 6                                           // float4 loads per thread and slab: 6 * 256 >= 180 * 8
+#define H3_SW(PIX, OCT) ((PIX) * 32 + 8 * ((OCT) ^ (((PIX) >> 2) & 3)))   // bf16 element offset of octet OCT of patch pixel PIX
+
+template <int SPLIT>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Ph[2][H3_NPX * 32];
+    __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? H3_NPX * 32 : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][CB_BN][CB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? CB_BN : 1][CB_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int akr = lane >> 5, aij = lane & 31;
+    int m_t, n_t;
+    {   // XCD-aware tile order (see conv.hip)
+        const int bid = blockIdx.x, nt = p.n_tiles;
+        const int per = (p.m_tiles + 7) >> 3;
+        const int q = bid >> 3;
+        n_t = q % nt;
+        const int local = q / nt;
+        m_t = (bid & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
+    }
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
+    const ConvSeg sg = p.seg[si];
+    const int n0 = n_t * CB_BN;
+    const int cslabs = p.Cin / CB_BK;
+    // tile (image t_n, 8 x 16 block (t_y, t_x)) of this workgroup
+    const int tiles_x = (sg.Wo + H3_TW - 1) / H3_TW, tiles_y = (sg.Ho + H3_TH - 1) / H3_TH;
+    const int t_loc = m_t - sg.tile_start;
+    const int t_n = t_loc / (tiles_x * tiles_y), t_rem = t_loc - t_n * (tiles_x * tiles_y);
+    const int t_y = t_rem / tiles_x, t_x = t_rem - t_y * tiles_x;
+    const int y0 = H3_TH * t_y - 1, x0 = H3_TW * t_x - 1;       // image position of patch pixel (0, 0)
+
+    // patch loader: element e = tid + 256 j -> patch pixel e >> 3, channels 4 (e & 7) .. +3 of the slab; byte offsets with bit 31 =
+    // zero padding / beyond the patch
+    unsigned po[H3_LD];
+#pragma unroll
+    for (int j = 0; j < H3_LD; ++j) {
+        const int e = tid + 256 * j, px = e >> 3;
+        const int hy = y0 + px / H3_PW, wx = x0 + px % H3_PW;
+        po[j] = 0x80000000u;
+        if (px < H3_NPX && hy >= 0 && hy < sg.H && wx >= 0 && wx < sg.W)
+            po[j] = 4u * (unsigned)(((t_n * sg.H + hy) * sg.W + wx) * p.Cin + 4 * (e & 7));
+    }
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    // B staging: thread -> 8 consecutive k (one 16-byte octet) of columns bcol and bcol + 64
+    const int bcol = tid >> 2, boct = tid & 3;
+    const unsigned slab_bytes = (unsigned)p.ldw * CB_BK * 2u;
+    const unsigned ob0 = ((unsigned)(n0 + bcol) * CB_BK + 8u * boct) * 2u;
+    const unsigned ob64 = 64u * CB_BK * 2u;
+    const char *whb = reinterpret_cast<const char *>(whi), *wlb = reinterpret_cast<const char *>(wlo);
+    // A fragments: row r = 32 i + aij of this wave's 64 pixels = tile pixel 64 wm + r = (y, x) -> patch pixel (y + ki, x + kj)
+    int pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int q = 64 * wm + 32 * i + aij; pb[i] = (q >> 4) * H3_PW + (q & 15); }
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[H3_LD];
+    uint4 rbh0, rbh1, rbl0, rbl1;
+
+#define H3_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define H3_FETCH_PATCH(CS) { _Pragma("unroll") for (int j = 0; j < H3_LD; ++j) H3_LDX(ra[j], po[j] + (unsigned)(CS) * (CB_BK * 4)) }
+#define H3_STASH_PATCH(BUF)                                                                               \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < H3_LD; ++j) {                                               \
+            const int e = tid + 256 * j, px = e >> 3, c4 = e & 7;                                         \
+            if (px < H3_NPX) {                                                                            \
+                bf16x4 h_, l_;                                                                            \
+                cb_split4(ra[j], true, h_, l_);                                                           \
+                *reinterpret_cast<bf16x4 *>(&Ph[BUF][H3_SW(px, c4 >> 1) + 4 * (c4 & 1)]) = h_;            \
+                if (SPLIT == 3) *reinterpret_cast<bf16x4 *>(&Pl[BUF][H3_SW(px, c4 >> 1) + 4 * (c4 & 1)]) = l_; \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define H3_FETCH_B(CS, TAP)                                                                               \
+    {                                                                                                     \
+        const unsigned ob = ob0 + (unsigned)((TAP) * cslabs + (CS)) * slab_bytes;                         \
+        rbh0 = *reinterpret_cast<const uint4 *>(whb + ob);                                                \
+        rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                                         \
+        if (SPLIT == 3) { rbl0 = *reinterpret_cast<const uint4 *>(wlb + ob); rbl1 = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
+    }
+#define H3_STASH_B(BUF)                                                                                   \
+    {                                                                                                     \
+        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][CB_SW(bcol, boct)]) = rbh0;                             \
+        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbh1;                   \
+        if (SPLIT == 3) {                                                                                 \
+            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][CB_SW(bcol, boct)]) = rbl0;                         \
+            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbl1;               \
+        }                                                                                                 \
+    }
+
+    // ---- prologue: patch of slab 0 and the weights of step (0, tap 0)
+    H3_FETCH_PATCH(0)
+    H3_FETCH_B(0, 0)
+    H3_STASH_PATCH(0)
+    H3_STASH_B(0)
+    __syncthreads();
+    int bb = 0;                                  // B buffer of the current step
+    // (the nine taps are unrolled: the tap shifts are immediates. A variant with a runtime tap loop and the weights of step s+2
+    // prefetched into a second register set was measured slower: 250 vs 221 us (bf16) / 449 vs 420 us (bf16x3) on FPN-P2.)
+    for (int cs = 0; cs < cslabs; ++cs) {
+        const int pbuf = cs & 1;
+        const bool more_slabs = cs + 1 < cslabs;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last = !more_slabs && tap == 8;
+            // loads of the next step's weights; the next slab's patch is fetched at tap 0 and stashed at tap 5
+            if (!last) { if (tap < 8) H3_FETCH_B(cs, tap + 1) else H3_FETCH_B(cs + 1, 0) }
+            if (tap == 0 && more_slabs) H3_FETCH_PATCH(cs + 1)
+            const int sh = (tap / 3) * H3_PW + (tap % 3);
+#pragma unroll
+            for (int t = 0; t < CB_BK / 16; ++t) {
+                const int ko = 2 * t + akr;
+                bf16x8 ah[2], bh[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ah[i] = *reinterpret_cast<const bf16x8 *>(&Ph[pbuf][H3_SW(pb[i] + sh, ko)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[bb][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
+                if (SPLIT == 3) {
+                    bf16x8 al[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const bf16x8 *>(&Pl[pbuf][H3_SW(pb[i] + sh, ko)]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[bb][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            if (!last) H3_STASH_B(bb ^ 1)
+            if (tap == 5 && more_slabs) H3_STASH_PATCH(pbuf ^ 1)
+            __syncthreads();
+            bb ^= 1;
+        }
+    }
+#undef H3_LDX
+#undef H3_FETCH_PATCH
+#undef H3_STASH_PATCH
+#undef H3_FETCH_B
+#undef H3_STASH_B
+
+    // ---- epilogue: + bias, + residual, ReLU; accumulator row -> tile pixel (y, x) -> output pixel
+    const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + 32 * j + aij;
+        const bool co_ok = co < p.Cout;
+        const int coc = co_ok ? co : 0;
+        const float bv = has_bias ? p.bias[coc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long opix[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 64 * wm + 32 * i + 4 * akr + (r & 3) + 8 * (r >> 2);
+                const int ho = H3_TH * t_y + (q >> 4), wo = H3_TW * t_x + (q & 15);
+                ok[r] = co_ok && ho < sg.Ho && wo < sg.Wo;
+                opix[r] = ((long)t_n * sg.Ho + min(ho, sg.Ho - 1)) * sg.Wo + min(wo, sg.Wo - 1);
+            }
+            float rr[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rr[r] = sg.res[opix[r] * p.Cout + coc];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r];
+                if (has_bias) v = v + bv;
+                if (has_res) v = v + rr[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (ok[r]) sg.out[opix[r] * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
 extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], const float *const residual[], float *const out[],
                                        const int batch[], const int height[], const int width[], int Cin, const void *wpack_hi,
                                        const void *wpack_lo, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,
@@ -242,10 +457,25 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
     UPS_REQUIRE(KH * KW <= 9, "conv2d_nhwc_bf16: at most 9 taps");
     for (int i = 0; i < p.nseg; ++i)   // bit 31 of a pixel offset flags the zero padding
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * Cin < (1L << 29), "conv2d_nhwc_bf16: feature map %d exceeds 2 GiB; split the batch", i);
+    const __bf16 *hi = reinterpret_cast<const __bf16 *>(wpack_hi), *lo = reinterpret_cast<const __bf16 *>(wpack_lo);
+    static const bool no_halo = getenv("UPSNET_BF16_HALO") != nullptr && getenv("UPSNET_BF16_HALO")[0] == '0';
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && !no_halo) {   // haloed-patch kernel: 8 x 16 pixel tiles
+        int t3 = 0;
+        for (int i = 0; i < p.nseg; ++i) {
+            p.seg[i].tile_start = t3;
+            t3 += p.seg[i].N * ((p.seg[i].Ho + H3_TH - 1) / H3_TH) * ((p.seg[i].Wo + H3_TW - 1) / H3_TW);
+        }
+        p.m_tiles = t3;
+        p.n_tiles = ldw / CB_BN;
+        const int g3 = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+        if (lo) hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<3>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+        else hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+        UPS_CHECK_LAUNCH("conv3x3_bf16_halo_kernel");
+        return 0;
+    }
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + CB_BM - 1) / CB_BM); }
     p.m_tiles = tiles;
-    const __bf16 *hi = reinterpret_cast<const __bf16 *>(wpack_hi), *lo = reinterpret_cast<const __bf16 *>(wpack_lo);
     p.n_tiles = ldw / CB_BN;
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
     if (lo) hipLaunchKernelGGL((conv_bf16_kernel<3, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
