@@ -23,7 +23,10 @@ shapes = [
     ("res4 1x1 1024->256", [(1, 64, 128)], 1024, 256, 1, 1), ("res5 1x1 2048->512", [(1, 32, 64)], 2048, 512, 1, 1),
     ("res4 1x1 s2 512->1024", [(1, 128, 256)], 512, 1024, 1, 2),
 ]
+only = os.environ.get('ONLY')
 for name, segs, cin, cout, k, st in shapes:
+    if only and only not in name:
+        continue
     xs = [torch.randn(n, cin, h, w, device='cuda').contiguous(memory_format=torch.channels_last) for n, h, w in segs]
     wgt = torch.randn(cout, cin, k, k, device='cuda') / (cin * k * k) ** 0.5
     b = torch.randn(cout, device='cuda')

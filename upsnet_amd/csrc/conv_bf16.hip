@@ -247,6 +247,14 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
 #define H3_LD 6                                           // float4 loads per thread and slab: 6 * 256 >= 180 * 8
 #define H3_SW(PIX, OCT) ((PIX) * 32 + 8 * ((OCT) ^ (((PIX) >> 2) & 3)))   // bf16 element offset of octet OCT of patch pixel PIX
 
+// MFMA row l (0..31) -> pixel of the 2 x 16 block: lanes {0-3,12-15,20-27} -> row 0, x = 0..15 in that order; the others -> row 1
+__device__ static inline int h3_perm(const int l)
+{
+    const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+    const int k = l < 4 ? l : l < 12 ? l - 4 : l < 16 ? l - 8 : l < 20 ? l - 8 : l < 28 ? l - 12 : l - 16;
+    return (g1 ? 16 : 0) + k;
+}
+
 template <int SPLIT>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
@@ -304,9 +312,13 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
     const unsigned ob64 = 64u * CB_BK * 2u;
     const char *whb = reinterpret_cast<const char *>(whi), *wlb = reinterpret_cast<const char *>(wlo);
     // A fragments: row r = 32 i + aij of this wave's 64 pixels = tile pixel 64 wm + r = (y, x) -> patch pixel (y + ki, x + kj)
+    // The 32 rows of an MFMA block are two image rows of 16 pixels. ds_read_b128 is serviced in the fixed lane groups
+    // {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS): MFMA row l is therefore mapped to pixel h3_perm(l) such
+    // that each group reads 16 CONSECUTIVE pixels of one image row -- with the (pixel >> 2) & 3 octet swizzle that is conflict-free
+    // for every tap shift (the identity mapping measured 24 % conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; now 0).
     int pb[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int q = 64 * wm + 32 * i + aij; pb[i] = (q >> 4) * H3_PW + (q & 15); }
+    for (int i = 0; i < 2; ++i) { const int q = 64 * wm + 32 * i + h3_perm(aij); pb[i] = (q >> 4) * H3_PW + (q & 15); }
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -358,7 +370,9 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
     __syncthreads();
     int bb = 0;                                  // B buffer of the current step
     // (the nine taps are unrolled: the tap shifts are immediates. A variant with a runtime tap loop and the weights of step s+2
-    // prefetched into a second register set was measured slower: 250 vs 221 us (bf16) / 449 vs 420 us (bf16x3) on FPN-P2.)
+    // prefetched into a second register set was measured slower: 250 vs 221 us (bf16) / 449 vs 420 us (bf16x3) on FPN-P2; with
+    // unrolled taps AND two weight sets the kernel needs > 256 registers. PMC on FPN-P2 (bf16): MFMA pipe 31 % busy, LDS 25 %,
+    // 0 bank-conflict cycles -- the step is latency-bound: weights fetched at its start are written to LDS at its end.)
     for (int cs = 0; cs < cslabs; ++cs) {
         const int pbuf = cs & 1;
         const bool more_slabs = cs + 1 < cslabs;
@@ -422,7 +436,7 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
             bool ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q = 64 * wm + 32 * i + 4 * akr + (r & 3) + 8 * (r >> 2);
+                const int q = 64 * wm + 32 * i + h3_perm(4 * akr + (r & 3) + 8 * (r >> 2));
                 const int ho = H3_TH * t_y + (q >> 4), wo = H3_TW * t_x + (q & 15);
                 ok[r] = co_ok && ho < sg.Ho && wo < sg.Wo;
                 opix[r] = ((long)t_n * sg.Ho + min(ho, sg.Ho - 1)) * sg.Wo + min(wo, sg.Wo - 1);
