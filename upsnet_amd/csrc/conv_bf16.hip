@@ -255,14 +255,17 @@ __device__ static inline int h3_perm(const int l)
     return (g1 ? 16 : 0) + k;
 }
 
-template <int SPLIT>
+// TPS: taps per step (= per barrier and per weight stage): 1 in both modes. TPS = 3 (one kernel row per barrier, 24 MFMAs per wave
+// and step in bf16 like bf16x3 has per tap) was measured SLOWER in bf16: 345 vs 227 us on FPN-P2 (244 registers, six weight
+// loads + stores per thread in a row); kept as a template parameter for further experiments.
+template <int SPLIT, int TPS>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
 {
     __shared__ __attribute__((aligned(16))) __bf16 Ph[2][H3_NPX * 32];
     __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? H3_NPX * 32 : 8];
-    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][CB_BN][CB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? CB_BN : 1][CB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][TPS][CB_BN][CB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? TPS : 1][SPLIT == 3 ? CB_BN : 1][CB_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -328,7 +331,7 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra[H3_LD];
-    uint4 rbh0, rbh1, rbl0, rbl1;
+    uint4 rbh0[TPS], rbh1[TPS], rbl0[TPS], rbl1[TPS];
 
 #define H3_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
@@ -345,73 +348,82 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
             }                                                                                             \
         }                                                                                                 \
     }
-#define H3_FETCH_B(CS, TAP)                                                                               \
+#define H3_FETCH_B(CS, TAP0)                                                                              \
     {                                                                                                     \
-        const unsigned ob = ob0 + (unsigned)((TAP) * cslabs + (CS)) * slab_bytes;                         \
-        rbh0 = *reinterpret_cast<const uint4 *>(whb + ob);                                                \
-        rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                                         \
-        if (SPLIT == 3) { rbl0 = *reinterpret_cast<const uint4 *>(wlb + ob); rbl1 = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
+        _Pragma("unroll") for (int u = 0; u < TPS; ++u) {                                                 \
+            const unsigned ob = ob0 + (unsigned)(((TAP0) + u) * cslabs + (CS)) * slab_bytes;              \
+            rbh0[u] = *reinterpret_cast<const uint4 *>(whb + ob);                                         \
+            rbh1[u] = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                                  \
+            if (SPLIT == 3) { rbl0[u] = *reinterpret_cast<const uint4 *>(wlb + ob); rbl1[u] = *reinterpret_cast<const uint4 *>(wlb + ob + ob64); } \
+        }                                                                                                 \
     }
 #define H3_STASH_B(BUF)                                                                                   \
     {                                                                                                     \
-        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][CB_SW(bcol, boct)]) = rbh0;                             \
-        *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbh1;                   \
-        if (SPLIT == 3) {                                                                                 \
-            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol][CB_SW(bcol, boct)]) = rbl0;                         \
-            *reinterpret_cast<uint4 *>(&Bl[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbl1;               \
+        _Pragma("unroll") for (int u = 0; u < TPS; ++u) {                                                 \
+            *reinterpret_cast<uint4 *>(&Bh[BUF][u][bcol][CB_SW(bcol, boct)]) = rbh0[u];                   \
+            *reinterpret_cast<uint4 *>(&Bh[BUF][u][bcol + 64][CB_SW(bcol + 64, boct)]) = rbh1[u];         \
+            if (SPLIT == 3) {                                                                             \
+                *reinterpret_cast<uint4 *>(&Bl[BUF][u][bcol][CB_SW(bcol, boct)]) = rbl0[u];               \
+                *reinterpret_cast<uint4 *>(&Bl[BUF][u][bcol + 64][CB_SW(bcol + 64, boct)]) = rbl1[u];     \
+            }                                                                                             \
         }                                                                                                 \
     }
 
-    // ---- prologue: patch of slab 0 and the weights of step (0, tap 0)
+    // ---- prologue: patch of slab 0 and the weights of step 0 (taps 0 .. TPS-1)
     H3_FETCH_PATCH(0)
     H3_FETCH_B(0, 0)
     H3_STASH_PATCH(0)
     H3_STASH_B(0)
     __syncthreads();
     int bb = 0;                                  // B buffer of the current step
-    // (the nine taps are unrolled: the tap shifts are immediates. A variant with a runtime tap loop and the weights of step s+2
-    // prefetched into a second register set was measured slower: 250 vs 221 us (bf16) / 449 vs 420 us (bf16x3) on FPN-P2; with
-    // unrolled taps AND two weight sets the kernel needs > 256 registers. PMC on FPN-P2 (bf16): MFMA pipe 31 % busy, LDS 25 %,
-    // 0 bank-conflict cycles -- the step is latency-bound: weights fetched at its start are written to LDS at its end.)
+    // (the steps of a slab are unrolled: the tap shifts are immediates. A variant with a runtime tap loop and the weights of step
+    // s+2 prefetched into a second register set was measured slower (250 vs 221 us bf16 / 449 vs 420 us bf16x3 on FPN-P2); with
+    // unrolled taps AND two weight sets the kernel needs > 256 registers. PMC on FPN-P2 with one tap per step in bf16: MFMA pipe
+    // 31 % busy, LDS 25 %, 0 bank-conflict cycles.)
+    constexpr int NST = 9 / TPS;                 // steps per slab
     for (int cs = 0; cs < cslabs; ++cs) {
         const int pbuf = cs & 1;
         const bool more_slabs = cs + 1 < cslabs;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const bool last = !more_slabs && tap == 8;
-            // loads of the next step's weights; the next slab's patch is fetched at tap 0 and stashed at tap 5
-            if (!last) { if (tap < 8) H3_FETCH_B(cs, tap + 1) else H3_FETCH_B(cs + 1, 0) }
-            if (tap == 0 && more_slabs) H3_FETCH_PATCH(cs + 1)
-            const int sh = (tap / 3) * H3_PW + (tap % 3);
+        for (int st = 0; st < NST; ++st) {
+            const bool last = !more_slabs && st == NST - 1;
+            // loads of the next step's weights; the next slab's patch is fetched at the first step and stashed at tap 5 / row 1
+            if (!last) { if (st < NST - 1) H3_FETCH_B(cs, (st + 1) * TPS) else H3_FETCH_B(cs + 1, 0) }
+            if (st == 0 && more_slabs) H3_FETCH_PATCH(cs + 1)
 #pragma unroll
-            for (int t = 0; t < CB_BK / 16; ++t) {
-                const int ko = 2 * t + akr;
-                bf16x8 ah[2], bh[2];
+            for (int u = 0; u < TPS; ++u) {
+                const int tap = st * TPS + u;
+                const int sh = (tap / 3) * H3_PW + (tap % 3);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ah[i] = *reinterpret_cast<const bf16x8 *>(&Ph[pbuf][H3_SW(pb[i] + sh, ko)]);
+                for (int t = 0; t < CB_BK / 16; ++t) {
+                    const int ko = 2 * t + akr;
+                    bf16x8 ah[2], bh[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[bb][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
-                if (SPLIT == 3) {
-                    bf16x8 al[2], bl[2];
+                    for (int i = 0; i < 2; ++i) ah[i] = *reinterpret_cast<const bf16x8 *>(&Ph[pbuf][H3_SW(pb[i] + sh, ko)]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const bf16x8 *>(&Pl[pbuf][H3_SW(pb[i] + sh, ko)]);
+                    for (int j = 0; j < 2; ++j) bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[bb][u][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
+                    if (SPLIT == 3) {
+                        bf16x8 al[2], bl[2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[bb][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
+                        for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const bf16x8 *>(&Pl[pbuf][H3_SW(pb[i] + sh, ko)]);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[bb][u][wn * 64 + 32 * j + aij][CB_SW(wn * 64 + 32 * j + aij, ko)]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            }
+                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        }
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
             if (!last) H3_STASH_B(bb ^ 1)
-            if (tap == 5 && more_slabs) H3_STASH_PATCH(pbuf ^ 1)
+            if (st == (TPS == 1 ? 5 : 1) && more_slabs) H3_STASH_PATCH(pbuf ^ 1)
             __syncthreads();
             bb ^= 1;
         }
@@ -482,8 +494,8 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
         p.m_tiles = t3;
         p.n_tiles = ldw / CB_BN;
         const int g3 = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-        if (lo) hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<3>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
-        else hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+        if (lo) hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<3, 1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+        else hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
         UPS_CHECK_LAUNCH("conv3x3_bf16_halo_kernel");
         return 0;
     }
