@@ -15,6 +15,8 @@
 //                         resolved in registers with ctz/readlane on the diagonal tile, then every lane
 //                         ORs its own suppression words for the kept rows (coalesced row reads).
 // Decisions use the reference's fp32 expression order without FMA -> keep lists are bit-exact.
+#include <stdlib.h>
+
 #include "common.h"
 #include "sort.h"
 #include "upsnet_hip.h"
@@ -238,7 +240,14 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     UPS_CHECK_LAUNCH("nms_sort_kernel");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, P), dim3(64), 0, st, w.sorted_boxes, counts, nmax, CB, thresh, ge, w.mask, w.diagT);
     UPS_CHECK_LAUNCH("nms_mask_kernel");
-    const int use_lds = nmax <= NMS_LDS_ROWS;
+    // LDS staging of the mask (128 KiB for 1000 boxes) makes the scan ~20 % faster in isolation, but a workgroup that needs 128 KiB
+    // cannot start on a CU that still hosts workgroups of the concurrently running semantic head (34 KiB each): inside the forward
+    // the RPN scan took 383 us instead of 50 (profiles/r06_timeline_serial.txt). Default: read the kept rows from L2 (no LDS):
+    // 215 us there, 139.5 -> 141.2 img/s, serial 8.09 -> 7.89 ms; UPSNET_NMS_LDS=1 restores the staging. (What remains is the wait
+    // for a wave slot: the deformable kernel's workgroups hold 504 of the 512 VGPRs of a SIMD. s_setprio 3 on the chain kernels was
+    // measured too: no effect -- they are not short of issue slots, they are waiting to be placed.)
+    static const bool want_lds = getenv("UPSNET_NMS_LDS") != nullptr && getenv("UPSNET_NMS_LDS")[0] == '1';
+    const int use_lds = want_lds && nmax <= NMS_LDS_ROWS;
     int cbp = 1;
     while (cbp < CB) cbp <<= 1;
     const size_t scan_smem = use_lds ? (size_t)nmax * cbp * sizeof(u64) : 0;
