@@ -283,6 +283,9 @@ int upsnet_nms_batched(void *stream, const float *boxes, const float *scores, co
                        const uint8_t *pre_removed, int num_problems, int nmax, float thresh, int *keep_idx,
                        int *keep_cnt, void *workspace);
 
+/* Development knob: 1 = the scan stages the suppression mask in LDS (<= 1024 boxes per problem), 0 = reads it from L2 (default). */
+void upsnet_nms_tuning(int lds_staging);
+
 /* cpu_nms (upsnet/nms/cpu_nms.pyx:29-80, behind cpu_nms_wrapper, upsnet/nms/nms.py:37-40) on the device: same layout, visiting
  * order and IoU expression as upsnet_nms_batched, but suppression at `overlap >= thresh` (:77) with `thresh` a double (a Python
  * float in the reference's compiled module; the fp32 overlap is compared in double). */

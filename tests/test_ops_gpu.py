@@ -236,6 +236,22 @@ def test_nms_batched_with_counts_and_preremoved(U):
         assert np.array_equal(keep[p, :cnt[p]], refs[p])
 
 
+@pytest.mark.parametrize("lds", [0, 1])
+def test_nms_scan_both_mask_sources(U, lds):
+    """The greedy scan reads the suppression words of the kept rows from L2 (default) or from an LDS copy of the mask (knob): same
+    keep lists, for 1 .. 2000 boxes (the LDS form covers <= 1024)."""
+    from upsnet_amd._lib import lib
+    rng = np.random.default_rng(5)
+    try:
+        lib().upsnet_nms_tuning(lds)
+        for n in (1, 63, 64, 65, 500, 1000, 1024, 2000):
+            d = gen_dets(rng, n)
+            got = U.gpu_nms(cu(d), 0.5).cpu().numpy()
+            assert np.array_equal(got, oops.gpu_nms(d, 0.5)), (lds, n)
+    finally:
+        lib().upsnet_nms_tuning(0)
+
+
 @pytest.mark.parametrize("method", [0, 1, 2])
 @pytest.mark.parametrize("n", [1, 5, 200, 1300])
 def test_soft_nms_bitexact(U, method, n):

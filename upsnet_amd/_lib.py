@@ -42,6 +42,7 @@ _SIGNATURES = {
     "upsnet_nms_host": (c_int, [P, P, P, c_int, c_int, c_float, c_int]),
     "upsnet_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
     "upsnet_nms_batched": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P, P, P]),
+    "upsnet_nms_tuning": (None, [c_int]),
     "upsnet_cpu_nms_batched": (c_int, [P, P, P, P, c_int, c_int, c_double, P, P, P]),
     "upsnet_soft_nms_batched_workspace_bytes": (c_size_t, [c_int, c_int]),
     "upsnet_soft_nms_batched": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_int, P, P]),

@@ -224,6 +224,10 @@ extern "C" size_t upsnet_nms_workspace_bytes(int P, int nmax)
            align256((size_t)P * nmax * sizeof(u64)) + align256((size_t)P * nmax * CB * sizeof(u64)) + 256;
 }
 
+// development knob: 1 = stage the suppression mask in LDS (problems of <= 1024 boxes), 0 (default, or UPSNET_NMS_LDS unset) = read it from L2
+static int g_nms_lds = (getenv("UPSNET_NMS_LDS") != nullptr && getenv("UPSNET_NMS_LDS")[0] == '1') ? 1 : 0;
+extern "C" void upsnet_nms_tuning(int lds_staging) { g_nms_lds = lds_staging ? 1 : 0; }
+
 // internal: tie_mode-selectable version used by the proposal / detection pipelines
 int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
                          const uint8_t *pre_removed, int P, int nmax, float thresh, int tie_mode, int *keep_idx,
@@ -246,8 +250,7 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     // 215 us there, 139.5 -> 141.2 img/s, serial 8.09 -> 7.89 ms; UPSNET_NMS_LDS=1 restores the staging. (What remains is the wait
     // for a wave slot: the deformable kernel's workgroups hold 504 of the 512 VGPRs of a SIMD. s_setprio 3 on the chain kernels was
     // measured too: no effect -- they are not short of issue slots, they are waiting to be placed.)
-    static const bool want_lds = getenv("UPSNET_NMS_LDS") != nullptr && getenv("UPSNET_NMS_LDS")[0] == '1';
-    const int use_lds = want_lds && nmax <= NMS_LDS_ROWS;
+    const int use_lds = g_nms_lds && nmax <= NMS_LDS_ROWS;
     int cbp = 1;
     while (cbp < CB) cbp <<= 1;
     const size_t scan_smem = use_lds ? (size_t)nmax * cbp * sizeof(u64) : 0;
