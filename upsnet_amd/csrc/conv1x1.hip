@@ -15,7 +15,8 @@
 //   * a K step (32 channels) costs a thread 2 global loads + 2 LDS writes; the loads of step s+2 are issued while step s is
 //     contracted (8 registers), pixels beyond the map read as 0 through the buffer bounds check.
 // Tile: 64 pixels x 128 channels (4 waves = 4 column blocks x both row blocks) or 64 x 64 (2 x 2 waves) for Cout <= 64 and for
-// maps with few tiles. Epilogue fused: + bias (folded frozen-BN shift), + residual (optionally read through the FPN's nearest x2
+// maps with few tiles. (Measured and rejected: different s_setprio levels for the four workgroups of a CU, to stagger their
+// completion so that the stores of one overlap the K walk of the others: 0-4 %, within noise.) Epilogue fused: + bias (folded frozen-BN shift), + residual (optionally read through the FPN's nearest x2
 // upsampling), ReLU, one NHWC store. Fixed accumulation order (bit-repeatable).
 #include "conv_params.h"
 #include "upsnet_hip.h"
