@@ -7,6 +7,7 @@ decisions bit-for-bit, hence -ffp-contract=off (no FMA contraction).
 """
 import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -19,16 +20,20 @@ SOURCES = ["capi.cpp", "fill.hip", "roi_align.hip", "nms.hip", "deform_conv.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+_COMMENT = re.compile(rb"//[^\n]*|/\*.*?\*/", re.S)
+
+
 def _source_hash():
-    """sha1 over the compile flags and every source / header the library is built from (mtimes are not trusted: a shipped
-    .so and a checked-out source can carry the same timestamp)."""
+    """sha1 over the compile flags and every source / header the library is built from, comments and whitespace runs removed (mtimes
+    are not trusted: a shipped .so and a checked-out source can carry the same timestamp; and a comment edit must neither rebuild the
+    library nor orphan the PMC profile that is stamped with this hash, tools/make_pmc_json.py)."""
     h = hashlib.sha1(" ".join(FLAGS + SOURCES).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
     deps.append(os.path.join(INCLUDE, "upsnet_hip.h"))
     for d in deps:
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
-            h.update(f.read())
+            h.update(b" ".join(_COMMENT.sub(b" ", f.read()).split()))
     return h.hexdigest()
 
 
