@@ -32,7 +32,6 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 template <int NW, bool RESUP>
 __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvParams p)
 {
-    constexpr int BN = 32 * NW;
     constexpr int NR = NW == 4 ? 2 : 1;          // 32-row blocks per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *As = reinterpret_cast<float4 *>(smem_raw);   // [2][8 q][64 px ^ 2q]
