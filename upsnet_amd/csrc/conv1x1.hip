@@ -24,15 +24,22 @@
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 #define C1_BM 64
-#define C1_ABUF (8 * C1_BM)   // float4 units of one A buffer: 8 channel quarters x 64 pixels
-#define C1_RING 4
 
 // NW: waves along N (4: BN = 128, every wave owns both 32-row blocks of one column block; 2: BN = 64, waves 2 x 2).
 // RESUP: the residual lives at half resolution and is read through a nearest x2 upsampling (fpn.py:34,90-96).
+// A K step (32 channels, one barrier) is 4 sub-steps of 8 channels (one A fragment, one B fragment, 4 NR MFMAs each). The
+// activations of step t+2 are fetched in sub-step 2 of step t and stashed in sub-step 1 of step t+1. Every load in the loop is
+// unconditional (steps beyond the end read through an out-of-range offset = 0, no memory access) and the prologue issues its loads
+// in the order of a steady-state step, so the vmcnt values the compiler derives for the loop are exact: with a conditional fetch
+// it fell back to vmcnt(3) everywhere, which -- vmcnt retires in order -- made every B wait also a wait for the activations
+// fetched two sub-steps earlier (5-15 % per layer). (Measured and rejected: two slabs per step with a B ring of 8, i.e. 7
+// sub-steps of latency cover and half the barriers: 2-10 % slower on every layer -- latency is not what bounds the loop.)
 template <int NW, bool RESUP>
 __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvParams p)
 {
     constexpr int NR = NW == 4 ? 2 : 1;          // 32-row blocks per wave
+    constexpr int NU = 4;                        // sub-steps per step = B fragments in flight
+    constexpr int C1_ABUF = 8 * C1_BM;           // float4 units of one A buffer: 8 channel quarters x 64 pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *As = reinterpret_cast<float4 *>(smem_raw);   // [2][8 q][64 px ^ 2q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,7 +59,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     }
     const ConvSeg sg = p.seg[0];
     const long p0 = (long)m_t * C1_BM;
-    const int nsl = p.Cin >> 5;
+    const int nsl = p.Cin >> 5;                  // K steps (32-channel slabs)
     const long HoWo = (long)sg.Ho * sg.Wo;
 
     // ---- loader geometry: thread = (pixel prow [+32], channel quarter q); byte offset of the pixel's channel vector, bit 31 set
@@ -91,14 +98,16 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float4 xa0, xa1;          // staged pixels of the K step in flight
-    float4 breg[C1_RING];
+    float4 breg[NU];
 
 #define C1_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
-#define C1_FETCH(S) { const unsigned c_ = (unsigned)(S) * 128u; C1_LDX(xa0, po0 + c_) C1_LDX(xa1, po1 + c_) }
-#define C1_STASH(BUF) { As[(BUF) * C1_ABUF + st0] = xa0; As[(BUF) * C1_ABUF + st1] = xa1; }
+    // step S: channels 32 S ... of the two pixels; a step beyond the end reads nothing (offset out of range -> 0)
+#define C1_FETCH(S, D0, D1) { const unsigned c_ = (S) < nsl ? (unsigned)(S) * 128u : 0x80000000u; C1_LDX(D0, po0 + c_) C1_LDX(D1, po1 + c_) }
+#define C1_STASH(BUF, D0, D1) { As[(BUF) * C1_ABUF + st0] = D0; As[(BUF) * C1_ABUF + st1] = D1; }
 #define C1_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 1024u, 0); \
         breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+    // fragment of sub-step H: channel quarter 2 H + lhalf of the step
 #define C1_FRAG(BUF, H, A0, A1)                                                                                        \
     {                                                                                                                  \
         const int q_ = 2 * (H) + lhalf;                                                                                \
@@ -106,25 +115,32 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
         if (NR == 2) A1 = As[(BUF) * C1_ABUF + q_ * C1_BM + ((32 + l32) ^ (2 * q_))];                                  \
     }
 
-    // ---- prologue: step 0 -> buffer 0, step 1 in flight, first ring of B fragments
-    C1_FETCH(0)
-#pragma unroll
-    for (int u = 0; u < C1_RING; ++u) C1_BLOAD(u, u)
-    C1_STASH(0)
-    if (nsl > 1) C1_FETCH(1)
+    // ---- prologue: step 0 -> buffer 0, step 1 in flight, first ring of B fragments. The loads are issued in the order of a
+    // steady-state step (B of sub-steps 0 and 1, the activations, the remaining B), so that the wait counts the compiler derives
+    // for the loop -- the merge of this entry state and the back edge -- are the steady-state ones, not more conservative.
+    {
+        float4 xp0, xp1;
+        C1_FETCH(0, xp0, xp1)
+        C1_BLOAD(0, 0)
+        C1_BLOAD(1, 1)
+        C1_FETCH(1, xa0, xa1)
+        C1_BLOAD(2, 2)
+        C1_BLOAD(3, 3)
+        C1_STASH(0, xp0, xp1)
+    }
     __syncthreads();
     float4 a0, a1;
     C1_FRAG(0, 0, a0, a1)
     int g = 0;
-    for (int s = 0; s < nsl; ++s) {
-        const int cur = s & 1;
+    for (int t = 0; t < nsl; ++t) {
+        const int cur = t & 1;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             float4 n0_, n1_;
-            if (u < 3) C1_FRAG(cur, u + 1, n0_, n1_)
-            if (u == 1 && s + 1 < nsl) C1_STASH(cur ^ 1)                 // step s+1 (fetched during step s-1)
-            if (u == 2 && s + 2 < nsl) C1_FETCH(s + 2)
-            if (u == 3) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
+            if (u < NU - 1) C1_FRAG(cur, u + 1, n0_, n1_)
+            if (u == 1) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
+            if (u == 2) C1_FETCH(t + 2, xa0, xa1)
+            if (u == NU - 1) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
             const float4 bf_ = breg[u];
             __builtin_amdgcn_sched_barrier(0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
@@ -135,12 +151,12 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);
-            C1_BLOAD(u, g + 4 + u)
+            C1_BLOAD(u, g + NU + u)
             a0 = n0_;
             if (NR == 2) a1 = n1_;
             __builtin_amdgcn_sched_barrier(0);
         }
-        g += 4;
+        g += NU;
     }
 #undef C1_LDX
 #undef C1_FETCH
@@ -163,28 +179,28 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
         if (has_res) {
             long ridx[16];
             if (RESUP) {
-                const long pb = pbase < sg.M ? pbase : sg.M - 1;
-                const int n_b = (int)(pb / HoWo);
-                const int rem_b = (int)(pb - (long)n_b * HoWo);
-                const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
-                const bool fast = sg.Wo >= 32;
+                // the 32 rows of this block are consecutive output pixels starting at a multiple of 32. Wo % 32 == 0 (every FPN
+                // level of the workloads): they lie in one image row, so the half-resolution source is one base + (column >> 1)
+                // -- no division per row. Other widths: the general decomposition, one row at a time.
+                const long pb0 = p0 + 32 * (NR == 2 ? i : wm);
+                if ((sg.Wo & 31) == 0) {
+                    const long pb = pb0 < sg.M ? pb0 : 0;
+                    const int n_b = (int)(pb / HoWo);
+                    const int rem_b = (int)(pb - (long)n_b * HoWo);
+                    const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;      // w_b: multiple of 32
+                    const long rb = ((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1) + 2 * lhalf;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    int n = n_b, h = h_b, w = w_b;
-                    if (pbase + off < sg.M) {
-                        if (fast) {
-                            w += off;
-                            if (w >= sg.Wo) { w -= sg.Wo; ++h; }
-                            if (h >= sg.Ho) { h -= sg.Ho; ++n; }
-                        } else {
-                            const long pp = pbase + off;
-                            n = (int)(pp / HoWo);
-                            const int rem = (int)(pp - (long)n * HoWo);
-                            h = rem / sg.Wo; w = rem - h * sg.Wo;
-                        }
+                    for (int r = 0; r < 16; ++r) ridx[r] = rb + (((r & 3) + 8 * (r >> 2)) >> 1);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        long pp = pbase + (r & 3) + 8 * (r >> 2);
+                        pp = pp < sg.M ? pp : sg.M - 1;
+                        const int n = (int)(pp / HoWo);
+                        const int rem = (int)(pp - (long)n * HoWo);
+                        const int h = rem / sg.Wo, w = rem - h * sg.Wo;
+                        ridx[r] = ((long)n * Hr + (h >> 1)) * Wr + (w >> 1);
                     }
-                    ridx[r] = ((long)n * Hr + (h >> 1)) * Wr + (w >> 1);
                 }
             }
 #pragma unroll
@@ -237,7 +253,7 @@ extern "C" int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const 
     if (!bn) bn = (Cout > 64 && (long)p.m_tiles * ((Cout + 127) / 128) >= 512) ? 128 : 64;
     if (Cout <= 64) bn = 64;
     p.n_tiles = (Cout + bn - 1) / bn;
-    const size_t smem = (size_t)2 * C1_ABUF * 16;
+    const size_t smem = (size_t)2 * 8 * C1_BM * 16;
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
 #define C1_LAUNCH(NW, RU) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<NW, RU>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p)
     if (bn == 128) { if (residual_up) C1_LAUNCH(4, true); else C1_LAUNCH(4, false); }

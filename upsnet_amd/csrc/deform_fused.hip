@@ -69,8 +69,8 @@ extern "C" int upsnet_dcn_pack_weight(void *stream, const float *weight, int cou
     return 0;
 }
 
-// SETS: corner register sets in flight (2: the gather of step s+2 overlaps the blend of step s+1; 1: one step of lookahead);
-// WPE: waves per SIMD the register budget is set for.
+// SETS: corner register sets in flight (2: the gather of step s+2 overlaps the blend of step s+1; 1: one step of lookahead;
+// 3: one set, "early" schedule -- see DF_STEP_EARLY); WPE: waves per SIMD the register budget is set for.
 template <bool MOD, int SETS, int WPE>
 __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParams p)
 {
@@ -187,12 +187,14 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     float4 yc00, yc01, yc02, yc03, yc10, yc11, yc12, yc13;   // register set Y
     float4 breg[DF_RING];
     int f_cs = s_begin / ntap, f_tap = s_begin - (s_begin / ntap) * ntap;   // (channel slab, tap) of the NEXT step to fetch
+    unsigned f_kill = 0u;     // early schedule: 0x80000000 once every step of this workgroup is fetched (the gather then reads nothing)
+    int f_left = nsl;
 
 #define DF_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
 #define DF_FETCH_PX(P, R, O)                                                                                           \
     {                                                                                                                  \
-        const unsigned c_ = (unsigned)(f_cs * 128 + q * 16);                                                           \
+        const unsigned c_ = ((unsigned)(f_cs * 128) | f_kill) + (unsigned)(q * 16);                                    \
         DF_LDX(P##c##R##0, (O).x + c_) DF_LDX(P##c##R##1, (O).y + c_) DF_LDX(P##c##R##2, (O).z + c_) DF_LDX(P##c##R##3, (O).w + c_) \
     }
     // gather of the step whose corner offsets were pre-read into no0 / no1; then pre-read the offsets of the step after it
@@ -253,24 +255,92 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
         g += 4;                                                                                                        \
     }
 
+    // Early schedule (SETS == 3, one register set), per pixel of the thread: blend + stash of step s+1 (pixel 0 at u = 0, pixel 1
+    // at u = 1), then -- one sub-step later, into the registers just freed -- its gather of step s+2 (u = 1, u = 2): a gather has
+    // three sub-steps (24 MFMAs of its wave) to arrive instead of one or two. Everything in the loop is unconditional: past the end
+    // the gather runs with out-of-range offsets (f_kill: no memory access) and the stash fills the buffer nobody reads. (With the
+    // conditional form the compiler placed register copies, and with them the wait for the gather, directly behind the loads.)
+#define DF_STEP_EARLY(BUF, STAP)                                                                                       \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                \
+            float4 n0_, n1_;                                                                                           \
+            if (u < 3) DF_FRAG(BUF, u + 1, n0_, n1_)                                                                   \
+            if (u == 0) DF_STASH_PX(x, 0, prow, st0, STAP, (BUF) ^ 1)                                                  \
+            if (u == 1) {                                                                                              \
+                f_kill = f_left > 0 ? 0u : 0x80000000u; --f_left;                                                      \
+                DF_FETCH_PX(x, 0, no0)                                                                                 \
+                DF_STASH_PX(x, 1, prow + 32, st1, STAP, (BUF) ^ 1)                                                     \
+            }                                                                                                          \
+            if (u == 2) {                                                                                              \
+                DF_FETCH_PX(x, 1, no1)                                                                                 \
+                if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                            \
+                DF_NEXT_OFFSETS                                                                                        \
+            }                                                                                                          \
+            if (u == 3) { __syncthreads(); DF_FRAG((BUF) ^ 1, 0, n0_, n1_) }                                           \
+            const float4 bf_ = breg[u];                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf_.y, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);                                   \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);                                   \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);                                   \
+            DF_BLOAD(u, g + 4 + u)                                                                                     \
+            a0 = n0_; a1 = n1_;                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                              \
+        g += 4;                                                                                                        \
+    }
+
     __syncthreads();   // descriptor table complete
     // ---- prologue: step 0 -> buffer 0 (set X), gather of step 1 in flight (set Y), first ring of B fragments
     uintx4 no0, no1;                                           // corner offsets of the next step to fetch (pre-read from the table)
     DF_NEXT_OFFSETS
+    --f_left;
     DF_FETCH(x)
     const int tap0 = s_begin - (s_begin / ntap) * ntap;       // tap of this workgroup's first step
+    if (SETS != 3) {
 #pragma unroll
-    for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, 4 * s_begin + u)
+        for (int u = 0; u < DF_RING; ++u) DF_BLOAD(u, 4 * s_begin + u)
+    }
     DF_NEXT_OFFSETS
     if (SETS == 2 && nsl > 1) { DF_FETCH(y) DF_NEXT_OFFSETS }
     DF_STASH_PX(x, 0, prow, st0, tap0, 0)
     DF_STASH_PX(x, 1, prow + 32, st1, tap0, 0)
+    if (SETS == 3) {
+        // step 1 in flight across the barrier, and the first B ring, issued in the order of a steady-state step (B, gather of pixel
+        // 0, B, gather of pixel 1, B, B) so that the loop's wait counts -- the merge of this entry state and the back edge -- are
+        // the steady-state ones
+        f_kill = f_left > 0 ? 0u : 0x80000000u; --f_left;
+        __builtin_amdgcn_sched_barrier(0);
+        DF_BLOAD(0, 4 * s_begin)
+        __builtin_amdgcn_sched_barrier(0);
+        DF_FETCH_PX(x, 0, no0)
+        __builtin_amdgcn_sched_barrier(0);
+        DF_BLOAD(1, 4 * s_begin + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        DF_FETCH_PX(x, 1, no1)
+        if (++f_tap == ntap) { f_tap = 0; ++f_cs; }
+        DF_NEXT_OFFSETS
+        __builtin_amdgcn_sched_barrier(0);
+        DF_BLOAD(2, 4 * s_begin + 2)
+        DF_BLOAD(3, 4 * s_begin + 3)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
     float4 a0, a1;
     DF_FRAG(0, 0, a0, a1)
     int g = 4 * s_begin;
     int s_tap = tap0 + 1 == ntap ? 0 : tap0 + 1;   // tap of step s+1
-    if (SETS == 2) {
+    if (SETS == 3) {
+        for (int s = 0; s < nsl; ++s) {      // one step per iteration (buffer parity at run time): nothing but the back edge
+            const int cur = s & 1;             // carries the in-flight gather, so it stays in the registers it was loaded into
+            DF_STEP_EARLY(cur, s_tap)
+            if (++s_tap == ntap) s_tap = 0;
+        }
+    } else if (SETS == 2) {
         for (int s = 0; s < nsl; s += 2) {
             DF_STEP(0, x, y, s + 2 < nsl, s + 1 < nsl, s_tap)
             if (++s_tap == ntap) s_tap = 0;
@@ -294,6 +364,7 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 #undef DF_BLOAD
 #undef DF_FRAG
 #undef DF_STEP
+#undef DF_STEP_EARLY
 
     // ---- epilogue: + bias, ReLU, NHWC store. Accumulator element r of lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3),
     // column l32 of the 32x32 block
@@ -319,8 +390,9 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     }
 }
 
-// development knob for A/B runs: 0 = auto (default), 1 = one corner set at 3 waves / SIMD, 2 = two sets at 2 waves / SIMD,
-// 3 = one set at 4, 4 = two sets at 3 (the last two spill: kept for measurements only)
+// development knob for A/B runs: 0 = auto (default: 5), 1 = one corner set at 3 waves / SIMD, 2 = two sets at 2 waves / SIMD,
+// 5 = one set, early schedule, at 3 (r07: 859 vs 938 us on the 256 -> 128 layer over four levels, 443 vs 459 on the 128 -> 128
+// one). (One set at 4 waves and two sets at 3 need more than their register budget: both spilled inside the loop, 2x slower.)
 static int g_dcn_variant = 0;
 extern "C" void upsnet_dcn_tuning(int variant) { g_dcn_variant = variant; }
 
@@ -355,14 +427,15 @@ static int dcn_fused_launch(void *stream, int nlev, const float *const x[], cons
     }
     const size_t smem = (size_t)2 * DF_ABUF * 16 + (size_t)kh * kw * DF_BM * (16 + 16 + 4);
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * p.ksplit;
-    // auto = one corner set at 3 waves per SIMD everywhere. (Two sets -- deeper gather lookahead -- for grids below
+    // auto = one corner set, early schedule, at 3 waves per SIMD everywhere. (Two sets -- deeper gather lookahead -- for grids below
     // UPSNET_DCN_SMALL_GRID workgroups was measured on the R101-DCN backbone: 106.6 vs 107.7 img/s, so the default threshold is 0.)
     const int dcn_small = atoi(getenv("UPSNET_DCN_SMALL_GRID") ? getenv("UPSNET_DCN_SMALL_GRID") : "0");
-    const int v = g_dcn_variant ? g_dcn_variant : (grid < dcn_small ? 2 : 1);
+    static const int dcn_auto = atoi(getenv("UPSNET_DCN_VARIANT") ? getenv("UPSNET_DCN_VARIANT") : "5");   // A/B runs of whole models
+    const int v = g_dcn_variant ? g_dcn_variant : (grid < dcn_small ? 2 : dcn_auto);
 #define DF_LAUNCH(SETS, WPE)                                                                                           \
     if (mask) hipLaunchKernelGGL((dcn_fused_f32_kernel<true, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p); \
     else hipLaunchKernelGGL((dcn_fused_f32_kernel<false, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
-    if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else if (v == 3) { DF_LAUNCH(1, 4) } else { DF_LAUNCH(2, 3) }
+    if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else { DF_LAUNCH(3, 3) }
 #undef DF_LAUNCH
     UPS_CHECK_LAUNCH("dcn_fused_f32_kernel");
     if (p.ksplit > 1)
