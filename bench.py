@@ -140,6 +140,23 @@ def main():
         ev = [e for e in ops.PROFILE['events'] if e[0] == kind and (prefix is None or (len(e) > 5 and e[5].startswith(prefix)))]
         ms = sum(e[1].elapsed_time(e[2]) for e in ev)
         return len(ev), ms / 1000.0, sum(e[3] for e in ev), sum(e[4] for e in ev)
+    def bound_frac(kind, want_wino=None):
+        """Time-weighted per-launch roofline: sum over launches of max(executed flops / MFMA peak, algorithmic bytes / HBM peak)
+        divided by the measured time -- unlike `frac` it does not charge an HBM-bound launch (res2's 1x1 layers, the narrow heads)
+        for the MFMA rate it cannot reach. Returns (fraction, launches whose bound is HBM)."""
+        tb, tt, nh = 0.0, 0.0, 0
+        for e in ops.PROFILE['events']:
+            if e[0] != kind:
+                continue
+            wino = len(e) > 5 and e[5].startswith('winograd')
+            if want_wino is not None and wino != want_wino:
+                continue
+            t_m = e[3] * (16.0 / 36.0 if wino else 1.0) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            t_h = e[4] / (PEAK_HBM_GBS * 1e9)
+            tb += max(t_m, t_h)
+            nh += t_h > t_m
+            tt += e[1].elapsed_time(e[2]) / 1000.0
+        return (round(tb / tt, 4) if tt > 0 else None), nh
     roofline = None
     n_c, t_c, f_c, b_c = agg('conv')
     n_d, t_d, f_d, b_d = agg('dcn_fused')
@@ -168,9 +185,11 @@ def main():
                               'conv_wino16_f32_kernel (Winograd F(2x2,3x3), csrc/conv_wino.hip)', 'bound': 'mfma',
                     'achieved': round(ex, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'frac_of_launch_bounds': bound_frac('conv')[0], 'hbm_bound_launches': bound_frac('conv')[1],
                     'achieved_algorithmic': round(alg, 3), 'frac_algorithmic': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     'note': 'achieved/frac = MFMA flops actually issued (Winograd launches at 16/36 of their direct-form flops) / time; '
-                            '*_algorithmic = direct-form flops of SURVEY 8d / time',
+                            '*_algorithmic = direct-form flops of SURVEY 8d / time; frac_of_launch_bounds = sum over launches of '
+                            'max(executed flops / 157.3 TFLOP/s, algorithmic bytes / 8 TB/s) / time (per-launch roofline, time-weighted)',
                     'traffic': traffic, 'traffic_source': traffic_src or 'none for this build (rocprofv3 --pmc passes: tools/profile_round.sh)',
                     'launches_timed': n_c, 'images_sampled': n_sampled, 'launches_per_image': n_c // n_sampled,
                     'avg_launch_ms': round(1000.0 * t_c / n_c, 4), 'ms_per_image': round(1000.0 * t_c / n_sampled, 3),
@@ -180,10 +199,12 @@ def main():
                     'winograd': {'launches_timed': n_w, 'ms_per_image': round(1000.0 * t_w / n_sampled, 3),
                                  'achieved_algorithmic': round(f_w / max(t_w, 1e-9) / 1e12, 3),
                                  'achieved': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12, 3),
-                                 'frac': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                                 'frac': round(f_w * 16.0 / 36.0 / max(t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'frac_of_launch_bounds': bound_frac('conv', True)[0]},
                     'direct': {'launches_timed': n_c - n_w, 'ms_per_image': round(1000.0 * (t_c - t_w) / n_sampled, 3),
                                'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3),
-                               'frac': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
+                               'frac': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                               'frac_of_launch_bounds': bound_frac('conv', False)[0], 'hbm_bound_launches': bound_frac('conv', False)[1]}}
         n_b, t_b, f_b, b_b = agg('conv_bf16')
         if n_b and t_b > 0:   # --conv-precision bf16 / bf16x3 (BASELINE configs[2]): the layers that ran on the bf16 matrix cores
             mult = 3.0 if args.conv_precision == 'bf16x3' else 1.0

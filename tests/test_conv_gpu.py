@@ -88,6 +88,61 @@ def test_conv1x1_gemm_kernel_vs_torch(N, Cin, Cout, H, W, stride, relu, res, bia
     assert torch.equal(out2, outs[-1] if not bn else out2)
 
 
+@pytest.mark.parametrize("N,H,W,C1", [(1, 64, 96, 256), (2, 37, 41, 256), (1, 9, 7, 128), (1, 40, 40, 384)])
+def test_conv1x1_pair_kernel(N, H, W, C1):
+    """csrc/conv1x1_pair.hip: relu(conv3(x) + b3 + shortcut) and relu(conv1(that) + b1) in one launch -- bit-identical to two launches
+    of csrc/conv1x1.hip (same K order), within 1e-4 of torch float64; tail tiles and maps smaller than a tile included."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + H + W + C1)
+    x = torch.randn(N, 64, H, W, device='cuda').relu()
+    sc = torch.randn(N, C1, H, W, device='cuda')
+    w3 = torch.randn(C1, 64, 1, 1, device='cuda') / 8
+    b3 = torch.randn(C1, device='cuda')
+    w1 = torch.randn(64, C1, 1, 1, device='cuda') / C1 ** 0.5
+    b1 = torch.randn(64, device='cuda')
+    p3, p1 = ops.pack_conv1x1_weight(w3), ops.pack_conv1x1_weight(w1)
+    o1, o2 = ops.conv1x1_pair(x, sc, p3, b3, C1, p1, b1, 64)
+    s1 = ops.conv1x1_frag(x, p3, b3, C1, 1, relu=True, residual=sc)
+    s2 = ops.conv1x1_frag(s1, p1, b1, 64, 1, relu=True)
+    assert torch.equal(o1, s1) and torch.equal(o2, s2)
+    r1 = (F.conv2d(x.double(), w3.double(), b3.double()) + sc.double()).clamp_min(0)
+    r2 = F.conv2d(r1, w1.double(), b1.double()).clamp_min(0)
+    np.testing.assert_allclose(o1.cpu().numpy(), r1.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o2.cpu().numpy(), r2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_pair(x, sc[:, :64], p3, b3, C1, p1, b1, 64)
+
+
+def test_res2_stage_with_paired_boundaries_is_bit_identical():
+    """models/resnet.py res_block: with the block-boundary pairs (hipconv.use_pair) the res2 stage returns the very same bits as
+    with one launch per layer, and takes two launches fewer."""
+    from upsnet_amd import ops
+    from upsnet_amd.models import hipconv, resnet
+    torch.manual_seed(3)
+    stage = resnet.res_block(64, 3).cuda().eval()
+    for m in stage.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.normal_(m.weight, std=(2.0 / (m.in_channels * m.kernel_size[0] ** 2)) ** 0.5)
+    resnet.fold_frozen_bn(stage)
+    stage = stage.to(memory_format=torch.channels_last)
+    x = torch.randn(1, 64, 256, 512, device='cuda').relu().contiguous(memory_format=torch.channels_last)
+    outs, launches = [], []
+    old = hipconv.PAIR
+    try:
+        for pair in (True, False):
+            hipconv.PAIR = pair
+            ops.PROFILE['events'], ops.PROFILE['enabled'] = [], True
+            with torch.no_grad():
+                outs.append(stage(x))
+            launches.append([e[5] if len(e) > 5 else '' for e in ops.PROFILE['events']])
+    finally:
+        hipconv.PAIR = old
+        ops.PROFILE['enabled'] = False
+        ops.PROFILE['events'] = []
+    assert torch.equal(outs[0], outs[1])
+    assert len(launches[0]) == len(launches[1]) - 2 and sum('pair' in l for l in launches[0]) == 2
+
+
 def test_hipconv_routes_1x1_layers_to_the_gemm_kernel():
     from upsnet_amd import ops
     from upsnet_amd.models import hipconv

@@ -77,3 +77,17 @@ if not only or 'dcn' in only:
                           lambda: ops.deform_conv_fused(xs, offs, wp, None, cin, cout, (3, 3), (1, 1), (1, 1), (1, 1), relu=True),
                           2.0 * cout * cin * 9 * hw, 4.0 * hw * (cin + 18 + cout))
             lib().upsnet_dcn_tuning(0)
+
+if not only or 'pair' in only:   # block boundary of res2: conv3 + shortcut + ReLU, then the next conv1 + ReLU -- two launches vs one
+    for H, W, c1 in ((256, 512, 256),):
+        x = torch.randn(1, 64, H, W, device='cuda').relu().contiguous(memory_format=torch.channels_last)
+        sc = torch.randn(1, c1, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+        p3 = ops.pack_conv1x1_weight(torch.randn(c1, 64, 1, 1, device='cuda') / 8)
+        p1 = ops.pack_conv1x1_weight(torch.randn(64, c1, 1, 1, device='cuda') / c1 ** 0.5)
+        b3, b1 = torch.randn(c1, device='cuda'), torch.randn(64, device='cuda')
+        fl = 2.0 * H * W * (64 * c1 + c1 * 64)
+        def two():
+            o1 = ops.conv1x1_frag(x, p3, b3, c1, 1, relu=True, residual=sc)
+            return ops.conv1x1_frag(o1, p1, b1, 64, 1, relu=True)
+        bench("res2 conv3 + next conv1, two launches", two, fl, 4.0 * H * W * (64 + 3 * c1 + 64))
+        bench("res2 conv3 + next conv1, pair kernel", lambda: ops.conv1x1_pair(x, sc, p3, b3, c1, p1, b1, 64), fl, 4.0 * H * W * (64 + 2 * c1 + 64))

@@ -1,0 +1,235 @@
+// conv1x1_pair.hip -- two chained 1x1 convolutions of consecutive ResNet bottlenecks in one launch:
+//     out1 = relu(x . W3^T + b3 + residual)        (conv3 + frozen BN + shortcut + ReLU of block b,   C0 -> C1 = 4 C0)
+//     out2 = relu(out1 . W1^T + b1)                (conv1 + frozen BN + ReLU of block b+1,            C1 -> C2)
+//
+// Reference: Bottleneck.forward (upsnet/models/resnet.py:53-100), the tail of one block and the head of the next.
+//
+// Why: on the 256 x 512 map of res2 these layers are HBM-bound -- conv3 reads 33 MB + 134 MB of shortcut and writes 134 MB
+// (61-76 us), the next conv1 reads those 134 MB back and writes 33 MB (50 us). The block output has to be written (it is the next
+// shortcut), but it does not have to be read again: a workgroup owns 64 pixels x ALL C1 channels, produces them in chunks of 128
+// channels (the 64 x 128 tile of conv1x1.hip: 4 waves x both row blocks), stores each chunk to HBM and drops it into LDS in the
+// A-fragment layout, and contracts it right away with the matching K chunk of W1. One launch, 134 MB less traffic per block
+// boundary; the MFMA time of the second GEMM hides under the HBM time of the first.
+//   * x tile (64 px x C0, 16 KiB for C0 = 64) staged once, reused by every chunk; chunk buffer 64 px x 128 ch = 32 KiB
+//     (50 KiB with the pitch: three workgroups per CU).
+//   * both weight matrices in the fragment order of conv1x1.hip (upsnet_dcn_pack_weight, kh = kw = 1), read from L2 through
+//     register rings; same fragment / MFMA scheme (v_mfma_f32_32x32x2_f32, lane = (row, k half), float4 = 4 channels of a pixel).
+//   * accumulation order of both GEMMs = that of conv1x1_frag_f32_kernel (K ascending through one accumulator chain per output
+//     element), so out1 and out2 are bit-identical to the two separate launches.
+#include "conv_params.h"
+#include "upsnet_hip.h"
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define CP_PITCH 65
+
+struct PairParams {
+    const float *x, *res, *w3, *b3, *w1, *b1;
+    float *out1, *out2;
+    long M;
+    int C0, C1, C2;
+};
+
+// NSL0 = C0 / 32 (K steps of the first GEMM). N2 = C2: 64 (waves 2 x 2, one 32 x 32 block each) or 128 (wave = column block, both
+// row blocks).
+template <int NSL0, int N2>
+__global__ void __launch_bounds__(256, 3) conv1x1_pair_f32_kernel(const PairParams p)
+{
+    constexpr int XQ = 8 * NSL0;                 // 16-byte channel quarters of the x tile
+    constexpr int G1 = 4 * NSL0;                 // sub-steps (8 channels) of the first GEMM per chunk
+    constexpr int NR2 = N2 == 128 ? 2 : 1;       // 32-row blocks per wave in the second GEMM
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // LDS tiles in 16-byte units [channel quarter][pixel], pitch CP_PITCH = 65 units per quarter: the loader's ds_write_b128
+    // (8 lanes = 8 quarters of one pixel) and the epilogue's ds_write_b32 (8 quarters per wave half) spread over the banks through
+    // the odd pitch, the fragment ds_read_b128 (consecutive pixels) is conflict-free anyway -- and, unlike the XOR swizzle of
+    // conv1x1.hip, every address is one lane base plus an immediate (24 sub-steps x 2 fragments would otherwise hold 48 registers)
+    float4 *Xs = reinterpret_cast<float4 *>(smem_raw);     // [XQ][65]
+    float4 *Ys = Xs + XQ * CP_PITCH;                        // [32 quarters of the chunk][65]
+    float *Ysf = reinterpret_cast<float *>(Ys);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: it enters the scalar offsets of the B loads
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    const long p0 = (long)blockIdx.x * 64;
+    const int nsl1 = p.C1 >> 5, npass = p.C1 >> 7;
+
+    // ---- buffer resources: x (bounds = the map, so pixels beyond it read 0), the two packed weight matrices
+    const size_t xaddr = reinterpret_cast<size_t>(p.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C0) * 4u);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    const size_t w3addr = reinterpret_cast<size_t>(p.w3);
+    const unsigned w3lo = __builtin_amdgcn_readfirstlane((unsigned)w3addr), w3hi = __builtin_amdgcn_readfirstlane((unsigned)(w3addr >> 32));
+    const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w3hi << 32) | w3lo), 0, p.C1 * p.C0 * 4, 0x00020000);
+    const int wm2 = N2 == 128 ? 0 : (wave & 1), wn2 = N2 == 128 ? wave : (wave >> 1);
+    const size_t w1addr = reinterpret_cast<size_t>(p.w1) + (size_t)wn2 * (size_t)nsl1 * 4096u;
+    const unsigned w1lo = __builtin_amdgcn_readfirstlane((unsigned)w1addr), w1hi = __builtin_amdgcn_readfirstlane((unsigned)(w1addr >> 32));
+    const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w1hi << 32) | w1lo), 0, nsl1 * 4096, 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
+    const int g2max = nsl1 * 4 - 1;
+    // shortcut / out1 / out2 through buffer descriptors too: one 32-bit lane offset (row 4 lhalf of the tile, this lane's channel)
+    // plus a scalar offset per accumulator row and chunk; rows beyond the map read 0 and their stores are dropped by the bounds
+    // check -- no clamps, no predicates, no 64-bit address per row
+#define CP_RSRC(NAME, PTR, BYTES)                                                                                      \
+    const size_t NAME##_a = reinterpret_cast<size_t>(PTR);                                                             \
+    const __amdgpu_buffer_rsrc_t NAME = __builtin_amdgcn_make_buffer_rsrc(                                             \
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(NAME##_a >> 32)) << 32) |  \
+                                 (size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)NAME##_a)), 0, (int)(BYTES), 0x00020000);
+    const unsigned bytes1 = __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C1) * 4u);
+    CP_RSRC(rrsrc, p.res, bytes1)
+    CP_RSRC(o1rsrc, p.out1, bytes1)
+    CP_RSRC(o2rsrc, p.out2, __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C2) * 4u))
+#undef CP_RSRC
+    const unsigned row1 = 4u * (unsigned)p.C1;                       // bytes of one pixel of out1
+    const unsigned vo1 = ((unsigned)(p0 + 4 * lhalf) * (unsigned)p.C1 + (unsigned)(32 * wave + l32)) * 4u;
+
+#define CP_LD(D, RS, VO, SO) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(RS, (VO), (SO), 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+    // B fragment of the first GEMM: chunk J (column block 4 J + wave), sub-step G; beyond the last chunk: clamped (unused)
+#define CP_B1(SLOT, J, G) CP_LD(b1r[SLOT], w3rsrc, b_lane, (unsigned)((min((J), npass - 1) * 4 + wave) * G1 + (G)) * 1024u)
+    // B fragment of the second GEMM: global sub-step G of this wave's column block
+#define CP_B2(SLOT, G) CP_LD(b2r[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u)
+
+    float4 b1r[4], b2r[4];
+    // ---- stage the x tile: thread = (pixel prow [+32], channel quarter q of each 32-channel slab)
+    {
+        const int q = tid & 7, prow = tid >> 3;
+        float4 xa[2 * NSL0];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long pp = p0 + prow + 32 * r;
+            const unsigned po = pp < p.M ? (unsigned)pp * 4u * (unsigned)p.C0 + 16u * (unsigned)q : 0x80000000u;
+#pragma unroll
+            for (int s = 0; s < NSL0; ++s) CP_LD(xa[2 * s + r], xrsrc, po + 128u * (unsigned)s, 0)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) CP_B1(u, 0, u)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) CP_B2(u, u)
+#pragma unroll
+        for (int s = 0; s < NSL0; ++s) {
+            Xs[(8 * s + q) * CP_PITCH + prow] = xa[2 * s];
+            Xs[(8 * s + q) * CP_PITCH + prow + 32] = xa[2 * s + 1];
+        }
+    }
+    __syncthreads();
+
+    const float4 *xfrag = Xs + lhalf * CP_PITCH + l32;                       // this lane's fragment bases (+ immediates per sub-step)
+    const float4 *yfrag = Ys + lhalf * CP_PITCH + 32 * wm2 + l32;
+    float *ydst = Ysf + (((32 * wave + l32) >> 2) * CP_PITCH + 4 * lhalf) * 4 + (l32 & 3);   // this lane's channel, pixel 4 lhalf
+    floatx16 acc2a, acc2b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2a[r] = 0.f; acc2b[r] = 0.f; }
+    int g2 = 0;
+    for (int j = 0; j < npass; ++j) {
+        // ---- first GEMM: this wave's 64 x 32 block of chunk j (rows l32 and 32 + l32 of both row blocks, column 32 (4 j + wave) + l32)
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const int co = 128 * j + 32 * wave + l32;
+        // shortcut of both row blocks, in flight during the GEMM (the B fragments it needs were issued before: vmcnt retires in order)
+        float rr[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, vo1, (unsigned)(32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2)) * row1 + 512u * (unsigned)j, 0));
+        {
+            float4 a0 = xfrag[0], a1 = xfrag[32];                 // quarter 2 g + lhalf, rows l32 / 32 + l32
+#pragma unroll
+            for (int g = 0; g < G1; ++g) {
+                float4 n0, n1;
+                if (g + 1 < G1) { n0 = xfrag[2 * (g + 1) * CP_PITCH]; n1 = xfrag[2 * (g + 1) * CP_PITCH + 32]; }
+                const float4 bf = b1r[g & 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf.w, acc1, 0, 0, 0);
+                // refill: sub-step g + 4 of this chunk, or the first fragments of the next chunk
+                if (g + 4 < G1) CP_B1(g & 3, j, g + 4) else CP_B1(g & 3, j + 1, g + 4 - G1)
+                if (g + 1 < G1) { a0 = n0; a1 = n1; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue of the chunk: + bias, + shortcut, ReLU; store to HBM; drop into LDS as A fragments of the second GEMM
+        // (element (pixel, channel c of the chunk) -> unit [c / 4][pixel], word c % 4)
+        const float bv = p.b3 != nullptr ? p.b3[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (i == 0 ? acc0[r] : acc1[r]) + bv;
+                v = v + rr[16 * i + r];
+                v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o1rsrc, vo1, (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * row1 + 512u * (unsigned)j, 0);
+                ydst[(32 * i + (r & 3) + 8 * (r >> 2)) * 4] = v;
+            }
+        }
+        __syncthreads();   // chunk complete in LDS
+        // ---- second GEMM: K chunk j (channels 128 j ... of out1) into this wave's block(s) of out2
+        {
+            float4 a0 = yfrag[0], a1;                             // quarter 2 t + lhalf of the chunk
+            if (NR2 == 2) a1 = yfrag[32];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float4 n0, n1;
+                if (t + 1 < 16) { n0 = yfrag[2 * (t + 1) * CP_PITCH]; if (NR2 == 2) n1 = yfrag[2 * (t + 1) * CP_PITCH + 32]; }
+                const float4 bf = b2r[t & 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf.x, acc2a, 0, 0, 0);
+                if (NR2 == 2) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf.x, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf.y, acc2a, 0, 0, 0);
+                if (NR2 == 2) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf.y, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf.z, acc2a, 0, 0, 0);
+                if (NR2 == 2) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf.z, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf.w, acc2a, 0, 0, 0);
+                if (NR2 == 2) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf.w, acc2b, 0, 0, 0);
+                CP_B2(t & 3, g2 + 4 + t)
+                if (t + 1 < 16) { a0 = n0; if (NR2 == 2) a1 = n1; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        g2 += 16;
+        __syncthreads();   // every read of the chunk is done before the next one overwrites it
+    }
+#undef CP_LD
+#undef CP_B1
+#undef CP_B2
+
+    // ---- epilogue of the second GEMM: + bias, ReLU, store
+    const int co2 = 32 * wn2 + l32;
+    const float bv2 = p.b1 != nullptr ? p.b1[co2] : 0.f;
+    const unsigned vo2 = ((unsigned)(p0 + 32 * wm2 + 4 * lhalf) * (unsigned)p.C2 + (unsigned)co2) * 4u;
+    const unsigned row2 = 4u * (unsigned)p.C2;
+#pragma unroll
+    for (int i = 0; i < NR2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = (i == 0 ? acc2a[r] : acc2b[r]) + bv2;
+            v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o2rsrc, vo2, (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * row2, 0);
+        }
+    }
+}
+
+/* out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1) in one launch (see the header of this
+ * file). x [pixels, C0], residual / out1 [pixels, C1], out2 [pixels, C2], all NHWC with pixels = N*H*W.
+ * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: C0 = 64, C1 % 128 == 0, C2 = 64 (the res2 stage). */
+extern "C" int upsnet_conv1x1_pair_nhwc_f32(void *stream, const float *x, const float *residual, float *out1, float *out2, long pixels,
+                                            int C0, const float *w3pack, const float *bias3, int C1, const float *w1pack,
+                                            const float *bias1, int C2)
+{
+    UPS_REQUIRE(x && residual && out1 && out2 && w3pack && w1pack && pixels > 0, "conv1x1_pair_nhwc_f32: null pointer / empty map");
+    UPS_REQUIRE(C0 == 64 && C2 == 64 && C1 > 0 && C1 % 128 == 0, "conv1x1_pair_nhwc_f32: supported shapes are C0 = 64, C1 %% 128 == 0, C2 = 64 (got %d, %d, %d)", C0, C1, C2);
+    UPS_REQUIRE(pixels * C1 < (1L << 29), "conv1x1_pair_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    PairParams p;
+    p.x = x; p.res = residual; p.w3 = w3pack; p.b3 = bias3; p.w1 = w1pack; p.b1 = bias1; p.out1 = out1; p.out2 = out2;
+    p.M = pixels; p.C0 = C0; p.C1 = C1; p.C2 = C2;
+    const int grid = (int)((pixels + 63) / 64);
+    const size_t smem = (size_t)(8 * (C0 / 32) + 32) * CP_PITCH * 16;
+    hipLaunchKernelGGL((conv1x1_pair_f32_kernel<2, 64>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    UPS_CHECK_LAUNCH("conv1x1_pair_f32_kernel");
+    return 0;
+}

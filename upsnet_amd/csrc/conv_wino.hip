@@ -23,6 +23,7 @@
 // 2h+1). The B operand (U) does not go through LDS: it is packed as [n-tile][slab][xi][q][64 channels][4] so that a lane's
 // fragment is one 16-byte load, contiguous across the wave (1 KiB), prefetched in a register ring.
 // LDS: 2 buffers x 64 KiB (double-buffered V), one workgroup per CU; the 32-tile forms: 2 x 32 KiB, two workgroups per CU.
+#include <cstdlib>
 #include "conv_params.h"
 #include "upsnet_hip.h"
 
@@ -367,7 +368,8 @@ static int conv_wino16_launch(hipStream_t st, ConvParams &p)
     long wgs64 = 0;
     for (int i = 0; i < p.nseg; ++i) wgs64 += (p.seg[i].M + 63) / 64;
     wgs64 *= p.ldw / 64;
-    const int tm = g_wino_tm ? g_wino_tm : (wgs64 > 768 ? 64 : 32);
+    static const long tm64_min = getenv("UPSNET_WINO_TM64_MIN") ? atol(getenv("UPSNET_WINO_TM64_MIN")) : 768;   // (models/hipconv.py reads the same)
+    const int tm = g_wino_tm ? g_wino_tm : (wgs64 > tm64_min ? 64 : 32);
     return tm == 32 ? conv_wino16_launch_tm<32, 64>(st, p) : conv_wino16_launch_tm<64, 64>(st, p);
 }
 

@@ -20,6 +20,7 @@ ENABLED = True
 # Smaller layers stay on the direct form.
 WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_WORKGROUPS = int(os.environ.get('UPSNET_WINOGRAD_MIN_WG', '128'))
+WINO_TM64_MIN = int(os.environ.get('UPSNET_WINO_TM64_MIN', '768'))   # 64-tile Winograd workgroups above this many (csrc/conv_wino.hip reads the same)
 SPLITK = os.environ.get('UPSNET_SPLITK', '1') != '0'
 # 1x1 convolutions (stride 1 / 2) with >= CONV1X1_MIN_WG workgroups of 64 pixels x 64 channels go through the lean GEMM kernel
 # (csrc/conv1x1.hip); smaller ones (res5's 2048-pixel maps: split-K) and Cout < 32 heads stay on the general kernel.
@@ -71,6 +72,28 @@ def _use_conv1x1(m, x):
     st = m.stride[0]
     pix = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
     return -(-pix // 64) * -(-m.out_channels // 64) >= CONV1X1_MIN_WG
+
+
+PAIR = os.environ.get('UPSNET_CONV1X1_PAIR', '1') != '0'
+PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
+
+
+def use_pair(m3, m1, x, residual):
+    """conv3 of one bottleneck (m3, + residual + ReLU) and conv1 of the next (m1, + ReLU) in one launch (csrc/conv1x1_pair.hip)?
+    Only where the pair is HBM-bound and the map has enough 64-pixel tiles: the res2 stage (64 -> 256 -> 64 on the stride-4 map).
+    Not in the bf16 modes (there the layers follow hipconv._use_bf16)."""
+    if not (PAIR and CONV1X1 and PRECISION == 'fp32' and supported(m3, x) and residual is not None and isinstance(m1, nn.Conv2d)):
+        return False
+    ok = lambda m: (tuple(m.kernel_size) == (1, 1) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (0, 0) and m.groups == 1)
+    if not (ok(m3) and ok(m1) and m3.in_channels == 64 and m3.out_channels % 128 == 0 and m1.in_channels == m3.out_channels and
+            m1.out_channels == 64):
+        return False
+    return x.shape[0] * x.shape[2] * x.shape[3] >= 64 * PAIR_MIN_TILES
+
+
+def conv_pair(m3, m1, x, residual):
+    """(relu(conv3(x) + residual), relu(conv1(that))) -- see use_pair."""
+    return ops.conv1x1_pair(x, residual, _conv1x1_plan(m3), m3.bias, m3.out_channels, _conv1x1_plan(m1), m1.bias, m1.out_channels)
 
 
 def supported(m, x):
@@ -134,7 +157,7 @@ def _wino_workgroups(m, xs, tm=64):
 def _wino_tm(m, xs):
     """2x2 tiles per workgroup the launcher will pick (csrc/conv_wino.hip, conv_wino16_launch): 64 (one workgroup per CU) above
     768 such workgroups, else 32 (two per CU); always 32 for the 32-channel form (Cout <= 32)."""
-    return 64 if m.out_channels > 32 and _wino_workgroups(m, xs, 64) > 768 else 32
+    return 64 if m.out_channels > 32 and _wino_workgroups(m, xs, 64) > WINO_TM64_MIN else 32
 
 
 def _wino_ksplit(m, xs):

@@ -54,19 +54,29 @@ class _Block(nn.Module):
 
     def forward(self, x):
         if isinstance(self.bn1, nn.Identity):  # BN folded: conv + bias (+ residual) + ReLU in one kernel each
-            y = hipconv.conv(self.conv1, x, relu=True)
-            if self.deformable:
-                y = torch.relu_(self.conv2(y, hipconv.conv(self.conv2_offset, y)))
-            else:
-                y = hipconv.conv(self.conv2, y, relu=True)
-            shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x)
-            return hipconv.conv(self.conv3, y, relu=True, residual=shortcut)
+            return self.forward_chain(x)[0]
         y = torch.relu_(self.bn1(self.conv1(x)))
         y = self.conv2(y, self.conv2_offset(y)) if self.deformable else self.conv2(y)
         y = torch.relu_(self.bn2(y))
         y = self.bn3(self.conv3(y))
         y += x if self.downsample is None else self.downsample(x)
         return torch.relu_(y)
+
+
+    def forward_chain(self, x, y1=None, nxt=None):
+        """Folded-BN forward as a link of a stage: y1 = this block's conv1 output if the previous block already produced it,
+        nxt = the next block of the stage. Returns (block output, the next block's conv1 output or None): where the two 1x1 layers
+        at a block boundary are HBM-bound (res2), conv3 + shortcut + ReLU of this block and conv1 + ReLU of the next run as one
+        launch that never reads the block output back (hipconv.use_pair, csrc/conv1x1_pair.hip; bit-identical results)."""
+        y = hipconv.conv(self.conv1, x, relu=True) if y1 is None else y1
+        if self.deformable:
+            y = torch.relu_(self.conv2(y, hipconv.conv(self.conv2_offset, y)))
+        else:
+            y = hipconv.conv(self.conv2, y, relu=True)
+        shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x)
+        if nxt is not None and isinstance(nxt.bn1, nn.Identity) and hipconv.use_pair(self.conv3, nxt.conv1, y, shortcut):
+            return hipconv.conv_pair(self.conv3, nxt.conv1, y, shortcut)
+        return hipconv.conv(self.conv3, y, relu=True, residual=shortcut), None
 
 
 class Bottleneck(_Block):
@@ -114,7 +124,13 @@ class res_block(nn.Module):
         self.layers = nn.Sequential(*mods)
 
     def forward(self, x):
-        return self.layers(x)
+        blocks = list(self.layers)
+        if not all(isinstance(b.bn1, nn.Identity) for b in blocks):
+            return self.layers(x)
+        y1 = None
+        for i, blk in enumerate(blocks):
+            x, y1 = blk.forward_chain(x, y1, blocks[i + 1] if i + 1 < len(blocks) else None)
+        return x
 
 
 class ResNetBackbone(nn.Module):

@@ -643,6 +643,31 @@ def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, resi
     return out
 
 
+def conv1x1_pair(x, residual, w3pack, bias3, c1, w1pack, bias1, c2):
+    """Tail of one bottleneck and head of the next in one launch (csrc/conv1x1_pair.hip):
+    out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1); both bit-identical to two
+    conv1x1_frag calls. x: logical NCHW; returns two channels_last tensors."""
+    require_cuda(w3pack, w1pack, x, residual)
+    x, res = nhwc(x.float()), nhwc(residual.float())
+    N, c0, H, W = x.shape
+    if tuple(res.shape) != (N, c1, H, W):
+        raise RuntimeError("conv1x1_pair: residual shape %s != %s" % (tuple(res.shape), (N, c1, H, W)))
+    out1, out2 = _nhwc_out(N, c1, H, W, x.device), _nhwc_out(N, c2, H, W, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv1x1_pair_nhwc_f32(stream(), ptr(x), ptr(res), ptr(out1), ptr(out2), N * H * W, int(c0), ptr(w3pack),
+                                             ptr(None if bias3 is None else f32c(bias3)), int(c1), ptr(w1pack),
+                                             ptr(None if bias1 is None else f32c(bias1)), int(c2)), "conv1x1_pair_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * H * W
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * (c1 * c0 + c2 * c1) * npix,
+                                  4.0 * (c0 * npix + 2 * c1 * npix + c2 * npix + c1 * c0 + c2 * c1),
+                                  "direct 1x1 pair %d->%d->%d [%s] +res (gemm)" % (c0, c1, c2, (N, H, W))))
+    return out1, out2
+
+
 def fcn_score_combine(parts, bias=None):
     """score = bias + parts[0] + sum_l bilinear_up_{2^l}(parts[l]); parts[l]: logical NCHW [1,S,H>>l,W>>l] (channels_last
     memory). Returns a channels_last [1,S,H,W] tensor (fcn.py:94-100 with the 1x1 conv commuted below the upsampling)."""
