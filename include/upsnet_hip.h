@@ -391,6 +391,13 @@ int upsnet_mask_removal(void *stream, const float *mask_rois, const float *cls_p
                         double fraction_threshold, int64_t *keep_inds, int *num_keep, int *real_keep,
                         void *workspace);
 
+/* Tail of the fixed-capacity forward (models/resnet_upsnet.py): kept_cls[i] = cls[keep[i]], kept_scores[i] = scores[keep[i]] for the
+ * kept panoptic detections (panoptic_cls_inds / panoptic_cls_probs of upsnet/models/resnet_upsnet.py:242-247; rows past *num_keep read
+ * row 0) and counters = {*det_num, *pan_num, *extra_num, *num_keep}: one launch instead of clamp + 2 index_select + 2 cat. */
+int upsnet_panoptic_tail_pack(void *stream, const int64_t *keep, const int *num_keep, int K, const int64_t *cls, const float *scores,
+                              const int *det_num, const int *pan_num, const int *extra_num, int64_t *kept_cls, float *kept_scores,
+                              int *counters);
+
 /* Materialise MaskRemoval's mask_energy [k,H,W] (mask_removal.py:86) for the kept instances. */
 int upsnet_mask_paste(void *stream, const float *mask_rois, const float *mask_logit, const int64_t *keep_inds,
                       const int *num_keep, const int *real_keep, int kmax, int mask_size, int height, int width,

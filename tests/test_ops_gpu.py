@@ -449,3 +449,34 @@ def test_panoptic_fuse_with_fused_upsample_bitexact(U, m, S, C, Hs, Ws, nhwc):
     pan2, _ = U.panoptic_fuse(up, S - (C - 1), cu(rois), cu(logit), cu(cls), keep, num, real, cmap, True)
     assert float((pan2 != pan).float().mean()) < 1e-4
     config.dataset.num_classes, config.dataset.num_seg_classes = 9, 19
+
+
+def test_panoptic_tail_pack_and_keep_zero_fill(U):
+    """ops.panoptic_tail_pack == clamp + index_select + cat (the ATen sequence it replaces), rows past num_keep read row 0;
+    mask_removal leaves the rows of keep_inds past the count at 0 without the caller clearing the buffer."""
+    torch.manual_seed(5)
+    K = 37
+    keep = torch.randint(0, K, (K,), device='cuda', dtype=torch.int64)
+    keep[3] = K + 5           # out of range on purpose: clamped like keep.clamp(0, K - 1)
+    cls = torch.randint(1, 9, (K,), device='cuda', dtype=torch.int64)
+    sc = torch.rand(K, device='cuda')
+    nums = [torch.tensor([v], dtype=torch.int32, device='cuda') for v in (11, 7, 0)]
+    for nk in (1, 9, K):
+        num_keep = torch.tensor([nk], dtype=torch.int32, device='cuda')
+        kc, ks, cnt = U.panoptic_tail_pack(keep, num_keep, cls, sc, *nums)
+        kz = keep.clone()
+        kz[nk:] = 0
+        kk = kz.clamp(0, K - 1)
+        assert torch.equal(kc, cls.index_select(0, kk)) and torch.equal(ks, sc.index_select(0, kk))
+        assert cnt.tolist() == [11, 7, 0, nk]
+    # keep_inds of the removal: garbage in the caching allocator's block must not survive past the count
+    junk = torch.full((64,), 12345, dtype=torch.int64, device='cuda')
+    del junk
+    m, ms = 6, 28
+    rois = torch.tensor([[10., 10., 60., 60.]] * m, device='cuda') + torch.arange(m, device='cuda').view(-1, 1) * 3
+    prob = torch.linspace(0.9, 0.4, m, device='cuda')
+    logit = torch.full((m, 1, ms, ms), 4.0, device='cuda')
+    cidx = torch.ones(m, dtype=torch.int64, device='cuda')
+    keep2, num2, _ = U.mask_removal(rois, prob, logit, cidx, 8, (128, 128))
+    n = int(num2.item())
+    assert 1 <= n < m and bool((keep2[n:] == 0).all())

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "upsnet_mask_logit_gather": (c_int, [P, P, c_int, c_int, c_int, c_long, c_long, c_long, P, P, c_int, P]),
     "upsnet_mask_removal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "upsnet_mask_removal": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_double, P, P, P, P]),
+    "upsnet_panoptic_tail_pack": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P]),
     "upsnet_mask_paste": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_seg_term": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_int, P]),
     "upsnet_panoptic_fuse": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, P, P]),

@@ -167,14 +167,52 @@ mask_removal_finalize_kernel(const int64_t *__restrict__ cls_idx, const int m_ca
                              const int *__restrict__ sorted_idx, const uint8_t *__restrict__ kept_flag, int64_t *__restrict__ keep_inds,
                              int *__restrict__ num_keep, int *__restrict__ real_keep)
 {
-    if (threadIdx.x != 0) return;
-    const int m = m_dev ? min(m_cap, *m_dev) : m_cap;
-    int k = 0;
-    const bool dummy = (m == 1 && cls_idx[0] == 0);  // mask_removal.py:55-57
-    if (!dummy)
-        for (int si = 0; si < m; ++si) if (kept_flag[si]) keep_inds[k++] = sorted_idx[si];
-    if (k == 0) { keep_inds[0] = 0; *num_keep = 1; *real_keep = 0; }  // :90-92
-    else { *num_keep = k; *real_keep = 1; }
+    __shared__ int k_sh;
+    if (threadIdx.x == 0) {
+        const int m = m_dev ? min(m_cap, *m_dev) : m_cap;
+        int k = 0;
+        const bool dummy = (m == 1 && cls_idx[0] == 0);  // mask_removal.py:55-57
+        if (!dummy)
+            for (int si = 0; si < m; ++si) if (kept_flag[si]) keep_inds[k++] = sorted_idx[si];
+        if (k == 0) { keep_inds[0] = 0; *num_keep = 1; *real_keep = 0; k = 1; }  // :90-92
+        else { *num_keep = k; *real_keep = 1; }
+        k_sh = k;
+    }
+    __syncthreads();
+    // rows past the count are defined (0), so the caller need not clear the buffer
+    for (int i = k_sh + (int)threadIdx.x; i < m_cap; i += (int)blockDim.x) keep_inds[i] = 0;
+}
+
+// Tail of the fixed-capacity forward: the kept detections' classes / scores (rows past num_keep: as if keep were 0, like the
+// index_select of a zero-filled index buffer) and the four device counters the host reads after the replay, in one launch
+// (instead of clamp + 2 x index_select + 2 x cat).
+__global__ void __launch_bounds__(256)
+pan_tail_pack_kernel(const int64_t *__restrict__ keep, const int *__restrict__ num_keep, const int K, const int64_t *__restrict__ cls,
+                     const float *__restrict__ scores, const int *__restrict__ det_num, const int *__restrict__ pan_num,
+                     const int *__restrict__ extra_num, int64_t *__restrict__ kept_cls, float *__restrict__ kept_scores,
+                     int *__restrict__ counters)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int nk = *num_keep;
+    if (i < K) {
+        long kk = i < nk ? (long)keep[i] : 0;
+        kk = kk < 0 ? 0 : (kk > K - 1 ? K - 1 : kk);
+        kept_cls[i] = cls[kk];
+        kept_scores[i] = scores[kk];
+    }
+    if (i == 0) { counters[0] = *det_num; counters[1] = *pan_num; counters[2] = *extra_num; counters[3] = nk; }
+}
+
+extern "C" int upsnet_panoptic_tail_pack(void *stream, const int64_t *keep, const int *num_keep, int K, const int64_t *cls,
+                                         const float *scores, const int *det_num, const int *pan_num, const int *extra_num,
+                                         int64_t *kept_cls, float *kept_scores, int *counters)
+{
+    UPS_REQUIRE(keep && num_keep && cls && scores && det_num && pan_num && extra_num && kept_cls && kept_scores && counters && K >= 1,
+                "panoptic_tail_pack: null pointer / K < 1");
+    hipLaunchKernelGGL(pan_tail_pack_kernel, dim3(ups_divup(K, 256)), dim3(256), 0, (hipStream_t)stream, keep, num_keep, K, cls, scores,
+                       det_num, pan_num, extra_num, kept_cls, kept_scores, counters);
+    UPS_CHECK_LAUNCH("pan_tail_pack_kernel");
+    return 0;
 }
 
 struct MrPlan { size_t occ, bits, sums, sorted, kept, total; int WW; };

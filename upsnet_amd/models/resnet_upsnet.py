@@ -263,7 +263,7 @@ class resnet_upsnet(resnet_rcnn):
         # The two selections overlap heavily (same (ROI, class) -> box table): panoptic detections that are also per-class
         # detections reuse the mask logits computed for those (bit-identical, every ROI goes through the head independently)
         pan_row, extra_boxes, extra_num = ops.mask_roi_dedup(det_src, det_cls, det_num, pan_src, pan_cls, pan_boxes, pan_num)
-        nums = torch.cat([det_num, pan_num, extra_num])
+        nums = None   # (the three counters as one tensor: only the eager continuation needs it; the fixed-capacity tail packs its own)
         if side is not main:
             main.wait_event(ev_join)
         tail_out = None
@@ -278,9 +278,11 @@ class resnet_upsnet(resnet_rcnn):
             keep, num_keep, real_keep = self.mask_removal.select(pb[:, 1:], ps, pan_logit, pc, (H, W), num_dev=pan_num)
             num_stuff = self.num_seg_classes - (self.num_classes - 1)
             panoptic, sem = ops.panoptic_fuse_up(fcn, 4, num_stuff, pb, pan_logit, pc, keep, num_keep, real_keep, self._class_map_dev(pb.device))
-            kk = keep[:K].clamp(0, K - 1)
-            tail_out = dict(keep=keep, panoptic=panoptic, sem=sem, counters=torch.cat([nums, num_keep]),
-                            mask_prob=torch.sigmoid(mask_det), kept_cls=pc.index_select(0, kk), kept_scores=ps.index_select(0, kk))
+            kept_cls, kept_scores, counters = ops.panoptic_tail_pack(keep, num_keep, pc, ps, det_num, pan_num, extra_num)
+            tail_out = dict(keep=keep, panoptic=panoptic, sem=sem, counters=counters, mask_prob=torch.sigmoid(mask_det),
+                            kept_cls=kept_cls, kept_scores=kept_scores)
+        if tail_out is None:
+            nums = torch.cat([det_num, pan_num, extra_num])
         return dict(feats=feats, fcn=fcn, fuse_up=fuse_up, tail=tail_out, det_boxes=det_boxes, det_scores=det_scores, det_cls=det_cls,
                     pan_boxes=pan_boxes, pan_scores=pan_scores, pan_cls=pan_cls, pan_row=pan_row, extra_boxes=extra_boxes, nums=nums,
                     mask_det=mask_det, max_det=max_det, _events=(ev_fork, ev_join))

@@ -466,7 +466,7 @@ def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, i
     cls_idx = cls_idx.to(torch.int64).contiguous().reshape(-1)
     H, W = int(im_shape[0]), int(im_shape[1])
     dev = mask_rois4.device
-    keep = torch.zeros((m,), dtype=torch.int64, device=dev)
+    keep = torch.empty((m,), dtype=torch.int64, device=dev)   # (the finalize kernel zero-fills the rows past the count)
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     real = torch.empty((1,), dtype=torch.int32, device=dev)
     ws = _ws(lib().upsnet_mask_removal_workspace_bytes(m, num_thing_classes, H, W), dev)
@@ -474,6 +474,20 @@ def mask_removal(mask_rois4, cls_prob, mask_logit, cls_idx, num_thing_classes, i
                                     int(num_thing_classes), H, W, float(fraction_threshold), ptr(keep), ptr(num), ptr(real),
                                     ptr(ws)), "mask_removal")
     return keep, num, real
+
+
+def panoptic_tail_pack(keep, num_keep, cls, scores, det_num, pan_num, extra_num):
+    """(kept_cls, kept_scores, counters[4] int32) of the fixed-capacity tail in one launch: cls / scores gathered at the kept rows
+    (rows past num_keep read row 0) and {det_num, pan_num, extra_num, num_keep} packed for the single host read."""
+    require_cuda(keep, cls, scores)
+    K = int(cls.shape[0])
+    cls, scores = cls.to(torch.int64).contiguous().reshape(-1), f32c(scores).reshape(-1)
+    kept_cls = torch.empty((K,), dtype=torch.int64, device=cls.device)
+    kept_scores = torch.empty((K,), dtype=torch.float32, device=cls.device)
+    counters = torch.empty((4,), dtype=torch.int32, device=cls.device)
+    check(lib().upsnet_panoptic_tail_pack(stream(), ptr(keep), ptr(num_keep), K, ptr(cls), ptr(scores), ptr(det_num), ptr(pan_num),
+                                          ptr(extra_num), ptr(kept_cls), ptr(kept_scores), ptr(counters)), "panoptic_tail_pack")
+    return kept_cls, kept_scores, counters
 
 
 def mask_paste(mask_rois4, mask_logit, keep, num, real, k, im_shape):
