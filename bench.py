@@ -77,6 +77,8 @@ def main():
                     help="images launched per rank before the oldest one is read back (2: the next graph launch overlaps the read-back; "
                          "1: strictly one image after the other)")
     ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
+    ap.add_argument('--no-configs2', action='store_true',
+                    help='skip the short second leg (same workload with --conv-precision bf16 = BASELINE.json configs[2], reported as "configs2")')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048: 1 warm-up + 3 timed passes, ~35 s)')
     args = ap.parse_args()
@@ -277,6 +279,24 @@ def main():
             if k >= 4:
                 serial.append(time.perf_counter() - t0)
     serial_ms = 1000.0 * sorted(serial)[len(serial) // 2]
+    # BASELINE.json configs[2] (dense convolutions on the bf16 matrix cores) on the same workload, after and outside the timed
+    # region of the headline: a short second leg on a fresh model, reported beside the fp32 value, never as it
+    configs2 = None
+    if world == 1 and args.conv_precision == 'fp32' and not args.no_configs2:
+        hipconv.PRECISION = 'bf16'
+        try:
+            r2 = upsnet_test(args.workload, steps=30, warmup=6, input_mode=args.input, post=args.post, in_flight=args.in_flight)
+            torch.cuda.synchronize()
+            net2 = sorted(r2['net_times'])
+            configs2 = {'what': 'BASELINE.json configs[2]: same workload, dense convolutions with >= %d 128x128 tiles on the bf16 matrix cores '
+                                '(bf16 products, fp32 accumulation; csrc/conv_bf16.hip), everything else as in the headline run; '
+                                'own run: python bench.py --conv-precision bf16' % hipconv.BF16_MIN_WG,
+                        'conv_precision': 'bf16', 'value': round(30 / r2['elapsed'], 4), 'unit': 'images/sec', 'steps': 30, 'warmup': 6,
+                        'ms_per_img_p50': round(1000.0 * net2[len(net2) // 2], 3),
+                        'n_det': int(r2['last_out']['cls_inds'].numel()), 'n_inst': int(r2['last_out']['panoptic_cls_inds'].numel())}
+            del r2
+        finally:
+            hipconv.PRECISION = 'fp32'
     agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
     if agree < 0.99 or chk['pred_boxes'].shape != last['pred_boxes'].shape:   # (bit-identical in practice; the FC GEMMs are a library)
         raise RuntimeError("bench: the timed run's outputs differ from an eager re-run of the same image (label agreement %.4f)" % agree)
@@ -293,7 +313,7 @@ def main():
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
                    'dense_convs': 'hand-written fp32 MFMA kernels for every convolution, NHWC, frozen BN folded, bias/residual/ReLU fused: 1x1 layers on the '
-                                  'lean GEMM kernel (csrc/conv1x1.hip), 3x3 / stride-1 layers with >= 128 workgroups of tiles (FPN, RPN, res2-res5 conv2, '
+                                  'lean GEMM kernel (csrc/conv1x1.hip; the conv3 / next conv1 pairs of res2 in one launch, csrc/conv1x1_pair.hip), 3x3 / stride-1 layers with >= 128 workgroups of tiles (FPN, RPN, res2-res5 conv2, '
                                   'DCN offset convs, mask head) on the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip, split-K below 160 workgroups), '
                                   'the rest (7x7 stem, strided 3x3, 2x2 deconvolution, narrow heads) on the implicit-GEMM kernel (csrc/conv.hip); '
                                   'max-pool + FC GEMMs on PyTorch-ROCm',
@@ -307,7 +327,7 @@ def main():
                               % (args.in_flight, n_sampled),
                    'hip_graph': bool(g), 'verified_vs_eager_rerun': same,
                    'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
-        'roofline': roofline, 'cpu_baseline': cpu_baseline,
+        'roofline': roofline, 'cpu_baseline': cpu_baseline, 'configs2': configs2,
     }
     print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

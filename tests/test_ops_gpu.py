@@ -163,7 +163,7 @@ def test_deform_conv_fused_geometries(U, k, pad, stride, dil):
     from upsnet_amd._lib import lib
     outs = []
     try:
-        for variant in (1, 2, 5):
+        for variant in (1, 2, 5, 6):
             lib().upsnet_dcn_tuning(variant)
             outs.append(U.deform_conv_fused([cu(x)], [cu(off)], wp, None, cin, cout, (k, k), (stride, stride), (pad, pad), (dil, dil))[0].cpu().numpy()[0])
     finally:

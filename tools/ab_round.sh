@@ -9,7 +9,7 @@ echo "pytest exit $?" >> gpurun_out/${TAG}_pytest.log
 tail -5 gpurun_out/${TAG}_pytest.log
 (ONLY=1x1 NOTORCH=1 REPS=20 timeout 300 python tools/microbench_conv.py; ONLY=dcn NOTORCH=1 REPS=10 timeout 300 python tools/microbench_conv.py) > gpurun_out/${TAG}_micro.txt 2>&1
 timeout 300 python tools/bench_winograd.py > gpurun_out/${TAG}_wino.txt 2>&1
-B="timeout 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+B="timeout 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-configs2"
 UPSNET_C1_KS=1 UPSNET_WINO_PF=0 UPSNET_DCN_VARIANT=1 $B > gpurun_out/${TAG}_bench_old.log 2>&1
 UPSNET_C1_KS=2 UPSNET_WINO_PF=0 UPSNET_DCN_VARIANT=1 $B > gpurun_out/${TAG}_bench_c1.log 2>&1
 UPSNET_C1_KS=1 UPSNET_WINO_PF=1 UPSNET_DCN_VARIANT=1 $B > gpurun_out/${TAG}_bench_pf.log 2>&1

@@ -9,11 +9,11 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 EAGER="env UPSNET_OVERLAP=0 UPSNET_GRAPH=0"
-$EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_trace_bench.log 2>&1
+$EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-configs2 > $OUT/${TAG}_trace_bench.log 2>&1
 python $REPO/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) 70 > $OUT/${TAG}_kernel_stats.txt 2>&1
 python $REPO/tools/rocpd_calls.py $(find /tmp/p_trace -name "*.db" | head -1) fpn_roi_align nms_sort nms_mask nms_scan dcn_fused panoptic_fuse > $OUT/${TAG}_per_call.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  $EAGER rocprofv3 --kernel-trace --pmc $C -d /tmp/p_$C -o t -- python $REPO/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_pmc_$C.log 2>&1
+  $EAGER rocprofv3 --kernel-trace --pmc $C -d /tmp/p_$C -o t -- python $REPO/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-configs2 > $OUT/${TAG}_pmc_$C.log 2>&1
   python $REPO/tools/rocpd_pmc.py $(find /tmp/p_$C -name "*.db" | head -1) > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
 cd $REPO

@@ -32,7 +32,10 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 #define DF_BM 64
 #define DF_BN 128
-#define DF_ABUF (8 * DF_BM)        // float4 units of one A buffer: 8 channel quarters x 64 pixels
+#define DF_PITCH 65                // 16-byte units per channel quarter of an A buffer: 64 pixels + 1 (odd pitch: the loader's ds_write_b128
+                                   // -- 8 lanes = 8 quarters of a pixel -- spreads over the banks, the fragment ds_read_b128 reads consecutive
+                                   // pixels anyway, and every fragment address is one lane base + an immediate)
+#define DF_ABUF (8 * DF_PITCH)     // float4 units of one A buffer: 8 channel quarters
 #define DF_RING 4
 
 // Weights [Cout, Cin, kh, kw] -> fragment order [cb = co/32][cs = c/32][tap][h = (c%32)/8][half = (c%8)/4][co%32][c%4]; the column
@@ -75,7 +78,7 @@ template <bool MOD, int SETS, int WPE>
 __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float4 *As = reinterpret_cast<float4 *>(smem_raw);                       // [2][8 q][64 px ^ 2q]
+    float4 *As = reinterpret_cast<float4 *>(smem_raw);                       // [2][8 q][DF_PITCH]
     // sampling table [tap][64 px]: byte offsets of the 4 corners' channel vectors (bit 31 set = outside the image: the buffer load
     // then returns 0, the value the reference substitutes), the 4 bilinear weights, v2: the modulation
     uintx4 *dsc_o = reinterpret_cast<uintx4 *>(smem_raw + 2 * DF_ABUF * 16);
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
     const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
-    const unsigned st0 = (unsigned)(q * DF_BM + (prow ^ (2 * q))), st1 = (unsigned)(q * DF_BM + ((prow + 32) ^ (2 * q)));
+    const unsigned st0 = (unsigned)(q * DF_PITCH + prow), st1 = st0 + 32u;
     // fragment units of step h: quarter 2h + lhalf, rows l32 (block 0) and 32 + l32 (block 1)
     // B: lane's float4 of global step g = 4 s + h sits at wbase + g * 1024 + lhalf * 512 + l32 * 16
     const int cb = 4 * n_t + wave;
@@ -221,8 +224,8 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
 #define DF_FRAG(BUF, H, A0, A1)                                                                                        \
     {                                                                                                                  \
         const int q_ = 2 * (H) + lhalf;                                                                                \
-        A0 = As[(BUF) * DF_ABUF + q_ * DF_BM + (l32 ^ (2 * q_))];                                                      \
-        A1 = As[(BUF) * DF_ABUF + q_ * DF_BM + ((32 + l32) ^ (2 * q_))];                                               \
+        A0 = As[(BUF) * DF_ABUF + q_ * DF_PITCH + l32];                                                                \
+        A1 = As[(BUF) * DF_ABUF + q_ * DF_PITCH + 32 + l32];                                                           \
     }
     // One K step s (buffer BUF holds its blended A tile). Tap index of step s+1 (the one being stashed) is passed as STAP.
     //   u = 0: gather of step s+2 into FSET;  u = 1, 2: blend + stash of step s+1 (SSET) into the other buffer;
@@ -435,7 +438,7 @@ static int dcn_fused_launch(void *stream, int nlev, const float *const x[], cons
 #define DF_LAUNCH(SETS, WPE)                                                                                           \
     if (mask) hipLaunchKernelGGL((dcn_fused_f32_kernel<true, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p); \
     else hipLaunchKernelGGL((dcn_fused_f32_kernel<false, SETS, WPE>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
-    if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else { DF_LAUNCH(3, 3) }
+    if (v == 1) { DF_LAUNCH(1, 3) } else if (v == 2) { DF_LAUNCH(2, 2) } else if (v == 6) { DF_LAUNCH(3, 4) } else { DF_LAUNCH(3, 3) }
 #undef DF_LAUNCH
     UPS_CHECK_LAUNCH("dcn_fused_f32_kernel");
     if (p.ksplit > 1)
