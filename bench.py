@@ -282,7 +282,19 @@ def main():
     # BASELINE.json configs[2] (dense convolutions on the bf16 matrix cores) on the same workload, after and outside the timed
     # region of the headline: a short second leg on a fresh model, reported beside the fp32 value, never as it
     configs2 = None
+    n_det, n_inst = int(last['cls_inds'].numel()), int(last['panoptic_cls_inds'].numel())
+    agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
+    boxes_same_shape = chk['pred_boxes'].shape == last['pred_boxes'].shape
     if world == 1 and args.conv_precision == 'fp32' and not args.no_configs2:
+        # the headline's model goes first: with its graph pools still resident the second model runs ~12 % slower (measured:
+        # 168 vs 190 img/s; freeing them restores it)
+        import gc
+        model._graphs.clear()
+        res['model'] = None
+        del model, chk, last
+        res.pop('last_out', None)
+        gc.collect()
+        torch.cuda.empty_cache()
         hipconv.PRECISION = 'bf16'
         try:
             r2 = upsnet_test(args.workload, steps=30, warmup=6, input_mode=args.input, post=args.post, in_flight=args.in_flight)
@@ -297,8 +309,7 @@ def main():
             del r2
         finally:
             hipconv.PRECISION = 'fp32'
-    agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
-    if agree < 0.99 or chk['pred_boxes'].shape != last['pred_boxes'].shape:   # (bit-identical in practice; the FC GEMMs are a library)
+    if agree < 0.99 or not boxes_same_shape:   # (bit-identical in practice; the FC GEMMs are a library)
         raise RuntimeError("bench: the timed run's outputs differ from an eager re-run of the same image (label agreement %.4f)" % agree)
     line = {
         'metric': 'images/sec (whole node), %s' % {'upsnet50_cityscapes_1024x2048': 'UPSNet-50 1024x2048',
@@ -326,7 +337,7 @@ def main():
                               'latency_ms_p50 = launch -> outputs); the %d roofline-sampled image(s) run eagerly and serially'
                               % (args.in_flight, n_sampled),
                    'hip_graph': bool(g), 'verified_vs_eager_rerun': same,
-                   'n_det': int(last['cls_inds'].numel()), 'n_inst': int(last['panoptic_cls_inds'].numel())},
+                   'n_det': n_det, 'n_inst': n_inst},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'configs2': configs2,
     }
     print(json.dumps(line), flush=True)

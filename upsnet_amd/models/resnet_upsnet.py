@@ -36,6 +36,7 @@ from .rpn import RPN, rpn_forward_levels
 
 
 _SIDE = {}  # device index -> (side stream, fork event, join event)
+_SLOT_STREAMS = {}  # (device index, graph instance number) -> the stream that instance is captured and replayed on
 
 
 class _Pending(object):
@@ -306,7 +307,15 @@ class resnet_upsnet(resnet_rcnn):
             static_im = torch.from_numpy(np.asarray(im_info_host, dtype=np.float32).reshape(-1)[:3].copy()).to(x.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            sk = torch.cuda.Stream(device=x.device) if self.graph_slots >= 2 or os.environ.get('UPSNET_GRAPH_OWN_STREAM') == '1' else None
+            sk = None
+            if self.graph_slots >= 2 or os.environ.get('UPSNET_GRAPH_OWN_STREAM') == '1':
+                # one stream per instance NUMBER, shared by every model / input shape of the process: a stream is bound to one of the
+                # few hardware queues when it is created, and a second model with fresh streams can land both of its instances on
+                # one queue (bench.py's configs[2] leg: 161 instead of 188 img/s before this)
+                sk_key = (x.device.index, slots['slots'].index(ent))
+                if sk_key not in _SLOT_STREAMS:
+                    _SLOT_STREAMS[sk_key] = torch.cuda.Stream(device=x.device)
+                sk = _SLOT_STREAMS[sk_key]
             gc_was_on = gc.isenabled()
             gc.disable()   # a collection in the middle of the capture could release device objects (illegal while capturing)
             try:
