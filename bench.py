@@ -217,7 +217,8 @@ def main():
                 'achieved': round(mult * f_b / t_b / 1e12, 3), 'frac': round(mult * f_b / t_b / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 'achieved_algorithmic': round(f_b / t_b / 1e12, 3), 'launches_timed': n_b, 'ms_per_image': round(1000.0 * t_b / n_sampled, 3),
                 'note': 'layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem, the deconvolution, the FPN laterals with the '
-                        'upsampled add and the deformable convolutions stay on the fp32 kernels (they are in the fp32 family above)'}
+                        'upsampled add stay on the fp32 kernels (they are in the fp32 family above); in the bf16 mode the deformable '
+                        'convolutions run on csrc/deform_fused_bf16.hip (deformable_bf16 below), in the bf16x3 mode on the fp32 kernel'}
         if n_d and t_d > 0:
             roofline['deformable'] = {'kernel': 'dcn_fused_f32_kernel (csrc/deform_fused.hip: fused deformable convolution v1, fp32 MFMA)', 'bound': 'mfma',
                                       'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -225,6 +226,15 @@ def main():
                                       'algorithmic_flops_per_launch': f_d / n_d, 'algorithmic_bytes_per_launch': b_d / n_d,
                                       'hbm_equiv_GBs': round(b_d / t_d / 1e9, 1),
                                       'hbm_equiv_frac': round(b_d / t_d / 1e9 / PEAK_HBM_GBS, 4)}
+
+        n_db, t_db, f_db, b_db = agg('dcn_fused_bf16')
+        if n_db and t_db > 0:   # --conv-precision bf16: the deformable layers on the bf16 matrix cores (csrc/deform_fused_bf16.hip)
+            roofline['deformable_bf16'] = {'kernel': 'dcn_fused_bf16_kernel (csrc/deform_fused_bf16.hip: fused deformable convolution, bf16 MFMA, fp32 '
+                                                     'accumulate; bound by the corner gather and the blend, priced here against the bf16 MFMA peak)',
+                                           'bound': 'mfma', 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                           'achieved': round(f_db / t_db / 1e12, 3), 'frac': round(f_db / t_db / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                           'launches_timed': n_db, 'avg_launch_ms': round(1000.0 * t_db / n_db, 4),
+                                           'algorithmic_bytes_per_launch': b_db / n_db, 'hbm_equiv_GBs': round(b_db / t_db / 1e9, 1)}
 
     # ---- CPU baseline: the oracle's composite forward on the host cores (bounded sample)
     cpu_baseline = None

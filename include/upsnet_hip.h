@@ -156,6 +156,16 @@ int upsnet_deform_conv_fused_nhwc_splitk(void *stream, const float *x, const flo
                                          const float *wpack, const float *bias, int relu, int ksplit, void *workspace);
 void upsnet_dcn_tuning(int variant);
 
+/* The same fused deformable convolution on the bf16 matrix cores (csrc/deform_fused_bf16.hip; BASELINE.json configs[2], opt-in with
+ * the other bf16 kernels): blended samples and weights rounded to bf16 (nearest even), exact products, fp32 accumulation. Arguments
+ * as upsnet_deform_conv_fused_nhwc; wpack: upsnet_dcn_pack_weight_bf16 into upsnet_dcn_packed_weight_bf16_elems 2-byte elements. */
+size_t upsnet_dcn_packed_weight_bf16_elems(int cout, int cin, int kh, int kw);
+int upsnet_dcn_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, void *wpack);
+int upsnet_deform_conv_fused_nhwc_bf16(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                       const float *const mask[], float *const out[], const int height[], const int width[], int cin,
+                                       int cout, int kh, int kw, int pad, int stride, int dil, const void *wpack, const float *bias,
+                                       int relu);
+
 /* ============================== Input blob (the step before the path) ============================== */
 
 /* BaseDataset.prep_im_for_blob + im_list_to_blob (upsnet/dataset/base_dataset.py:143-173,898-923) in one kernel:

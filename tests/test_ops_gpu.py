@@ -123,6 +123,33 @@ def test_deform_conv_fused_vs_oracle(U, cin, cout, sizes, mod, relu, kind):
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)  # fp32 logits within 1e-4 (BASELINE.json)
 
 
+@pytest.mark.parametrize("cin,cout,sizes,mod,relu,k,pad,dil", [
+    (64, 128, [(16, 24), (8, 12), (4, 6), (2, 3)], False, True, 3, 1, 1), (32, 64, [(10, 10)], True, False, 3, 1, 1),
+    (256, 128, [(40, 64), (20, 32)], False, True, 3, 1, 1), (64, 19, [(11, 13)], True, False, 3, 2, 2),
+    (96, 160, [(33, 17)], False, False, 1, 0, 1), (32, 32, [(9, 9)], False, False, 5, 2, 1)])
+def test_deform_conv_fused_bf16_matrix_cores(U, cin, cout, sizes, mod, relu, k, pad, dil):
+    """csrc/deform_fused_bf16.hip (BASELINE configs[2]: blended samples and weights rounded to bf16, exact products, fp32 sums) vs
+    the oracle evaluated on bf16-rounded weights: what remains is the rounding of the samples -- a few 1e-3 of the output scale."""
+    rng = np.random.default_rng(7)
+    w = (rng.normal(size=(cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    xs = [rng.normal(size=(1, cin, h, ww)).astype(np.float32) for h, ww in sizes]
+    offs = [(rng.normal(size=(1, 2 * k * k, h, ww)) * 2).astype(np.float32) for h, ww in sizes]
+    masks = [rng.uniform(0, 2, size=(1, k * k, h, ww)).astype(np.float32) for h, ww in sizes] if mod else None
+    wp = U.pack_dcn_weight(cu(w), 'frag_bf16')
+    assert wp[0] == 'frag_bf16' and wp[1].dtype == torch.bfloat16 and wp[1].numel() == (cout + 127) // 128 * 128 * cin * k * k
+    outs = U.deform_conv_fused([cu(x) for x in xs], [cu(o) for o in offs], wp, cu(b), cin, cout, (k, k), (1, 1), (pad, pad), (dil, dil),
+                               masks=[cu(m) for m in masks] if mod else None, relu=relu)
+    wr = torch.from_numpy(w).to(torch.bfloat16).float().numpy()
+    for i, o in enumerate(outs):
+        ref = _dcn_ref(xs[i][0], offs[i][0], wr, b, k, pad, 1, dil, masks[i][0] if mod else None, relu)
+        got = o.cpu().numpy()[0]
+        assert got.shape == ref.shape
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= 1.5e-2 * scale
+        assert float(np.sqrt(np.mean((got - ref) ** 2))) <= 3e-3 * scale
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(256, 256, 25, 42), (128, 128, 50, 84), (512, 512, 13, 21)])
 def test_deform_conv_fused_splitk_small_maps(U, cin, cout, H, W):
     """The DCN bottlenecks of the R101-DCN backbone (configs[3]) are single small maps: the fused kernel splits K over up to 8

@@ -68,7 +68,7 @@ if not only or 'dcn' in only:
         hw = sum(h * w for h, w in sizes)
         for std in (2.0, 0.3):   # offset spread in pixels (the synthetic benchmark weights give ~0.3-3 px)
             offs = [(torch.randn(1, 18, h, w, device='cuda') * std).contiguous(memory_format=torch.channels_last) for h, w in sizes]
-            for kind, variants in (('igemm', (None,)), ('frag', (5, 6))):
+            for kind, variants in (('frag_bf16', (None,)), ('frag', (5, 6))):
                 wp = ops.pack_dcn_weight(wgt, kind)
                 for v in variants:
                     if v is not None:

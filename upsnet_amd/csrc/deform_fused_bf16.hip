@@ -1,0 +1,287 @@
+// deform_fused_bf16.hip -- fused deformable convolution (v1 / v2) on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation): BASELINE.json configs[2] for the deformable layers of the FCN head / the DCN backbone. Opt-in with the other bf16
+// kernels (hipconv.PRECISION == 'bf16'); the fp32 kernel of deform_fused.hip stays the default and the one the headline runs on.
+//
+// Reference: DeformConvFunction / ModDeformConvFunction.forward (upsnet/operators/functions/deform_conv.py:27-60,
+// src/deform_conv_kernel.cu:88-118, 227-240): sampling positions, corner validity and bilinear weights are the reference's fp32
+// expressions (the table of deform_fused.hip); the blended sample is rounded to bf16 (round to nearest even) when it is written to
+// LDS, the weights are rounded once when they are packed; products are exact, sums fp32.
+//
+// Same decomposition as deform_fused.hip -- 8 x 8 pixel tiles x 128 output channels, K walk = (32-channel slab outer, tap inner),
+// sampling table in LDS, B fragments straight from L2 -- but a K step is 4 MFMAs of 32 cycles per wave instead of 32 of 64, so
+// the kernel is bound by the gather and the blend, not by the matrix cores. It is therefore built for occupancy: one corner
+// register set, <= 128 registers = four waves per SIMD, 29 KiB of LDS; a step is [blend + stash of step s+1] [gather of step
+// s+2 into the registers just freed] [4 MFMAs of step s] [barrier], the loop body unconditional (beyond the end the gather runs
+// with out-of-range offsets = no memory access).
+// LDS A tile: [4 k octets][DFB_PITCH pixels] 16-byte units (8 bf16 = the MFMA operand of one lane); thread (pixel, channel
+// quarter q) writes 4 bf16 = the half (q & 1) of unit [q >> 1][pixel].
+#include <stdlib.h>
+
+#include "conv_params.h"
+#include "upsnet_hip.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define DFB_BM 64
+#define DFB_BN 128
+#define DFB_PITCH 65
+#define DFB_ABUF (4 * DFB_PITCH)   // 16-byte units of one A buffer
+
+// Weights [Cout, Cin, kh, kw] fp32 -> bf16 in fragment order [cb = co/32][cs = c/32][tap][k half = (c%32)/16][octet = (c%16)/8]
+// [co%32][c%8]; column blocks padded to a multiple of 4 with zeros.
+__global__ void dcn_pack_weight_bf16_kernel(const float *__restrict__ w, int cout, int cin, int taps, int nblk, __bf16 *__restrict__ wp)
+{
+    const long total = (long)nblk * 32 * cin * taps;
+    const int cslabs = cin >> 5;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int e = idx & 7, col = (idx >> 3) & 31, oct = (idx >> 8) & 1, kh2 = (idx >> 9) & 1;
+        long r = idx >> 10;
+        const int tap = r % taps; r /= taps;
+        const int cs = r % cslabs; const int cb = r / cslabs;
+        const int co = 32 * cb + col, c = 32 * cs + 16 * kh2 + 8 * oct + e;
+        wp[idx] = (__bf16)(co < cout ? w[((long)co * cin + c) * taps + tap] : 0.f);
+    }
+}
+
+extern "C" size_t upsnet_dcn_packed_weight_bf16_elems(int cout, int cin, int kh, int kw)
+{
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)((cout + DFB_BN - 1) / DFB_BN) * DFB_BN * (size_t)cin * kh * kw;
+}
+
+extern "C" int upsnet_dcn_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, void *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && cin % 32 == 0 && kh > 0 && kw > 0, "dcn_pack_weight_bf16: bad args (Cin %% 32 must be 0)");
+    const int nblk = (cout + DFB_BN - 1) / DFB_BN * 4;
+    const long total = (long)nblk * 32 * cin * kh * kw;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, kh * kw, nblk,
+                       reinterpret_cast<__bf16 *>(wpack));
+    UPS_CHECK_LAUNCH("dcn_pack_weight_bf16_kernel");
+    return 0;
+}
+
+template <bool MOD>
+__global__ void __launch_bounds__(256, 4) dcn_fused_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ wpk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uintx4 *As = reinterpret_cast<uintx4 *>(smem_raw);                       // [2][4 octets][DFB_PITCH], 8 bf16 per unit
+    uintx4 *dsc_o = reinterpret_cast<uintx4 *>(smem_raw + 2 * DFB_ABUF * 16);  // sampling table, as in deform_fused.hip
+    float4 *dsc_w = reinterpret_cast<float4 *>(dsc_o + p.KH * p.KW * DFB_BM);
+    float *dsc_m = reinterpret_cast<float *>(dsc_w + p.KH * p.KW * DFB_BM);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    int m_t, n_t;
+    {   // XCD-aware tile order (workgroup b runs on XCD b % 8), as in deform_fused.hip
+        const int nt = p.n_tiles;
+        const int per = (p.m_tiles + 7) >> 3;
+        const int bid = (int)blockIdx.x;
+        const int q = bid >> 3;
+        n_t = q % nt;
+        const int local = q / nt;
+        m_t = (bid & 7) * per + local;
+        if (local >= per || m_t >= p.m_tiles) return;
+    }
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
+    const ConvSeg sg = p.seg[si];
+    const int tiles_x = (sg.Wo + 7) >> 3, tiles_y = (sg.Ho + 7) >> 3;
+    const int t_loc = m_t - sg.tile_start;
+    const int t_n = t_loc / (tiles_x * tiles_y), t_rem = t_loc - t_n * (tiles_x * tiles_y);
+    const int t_y = t_rem / tiles_x, t_x = t_rem - t_y * tiles_x;
+    const int ntap = p.KH * p.KW;
+    const int nsl = (p.Cin >> 5) * ntap;           // (channel slab, tap) steps, tap innermost
+
+    // ---- sampling table of this tile (deform_conv_kernel.cu:227-240 positions, :88-118 corners and weights; same fp32 expressions)
+    {
+        const unsigned cin4_ = 4u * (unsigned)p.Cin;
+        for (int idx = tid; idx < ntap * DFB_BM; idx += 256) {
+            const int tap = idx >> 6, px = idx & 63;
+            const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
+            const bool inside = ho < sg.Ho && wo < sg.Wo;
+            const long pp = ((long)t_n * sg.Ho + ho) * sg.Wo + wo;
+            uintx4 o;
+            o.x = o.y = o.z = o.w = 0x80000000u;
+            float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+            float m = 1.0f;
+            if (inside) {
+                const int ki = tap / p.KW, kj = tap - ki * p.KW;
+                const int h_base = ho * p.stride - p.pad + ki * p.dil, w_base = wo * p.stride - p.pad + kj * p.dil;
+                const float off_h = sg.off[pp * (2 * ntap) + 2 * tap];
+                const float off_w = sg.off[pp * (2 * ntap) + 2 * tap + 1];
+                const float h_im = (float)h_base + off_h;
+                const float w_im = (float)w_base + off_w;
+                const int H = sg.H, W = sg.W;
+                if (h_im > -1 && w_im > -1 && h_im < (float)H && w_im < (float)W) {
+                    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                    const float hh = 1.0f - lh, hw = 1.0f - lw;
+                    wt = make_float4(hh * hw, hh * lw, lh * hw, lh * lw);
+                    const bool a = h_low >= 0, b = h_high <= H - 1, c = w_low >= 0, e = w_high <= W - 1;
+                    const unsigned base = (unsigned)(t_n * H * W) * cin4_;
+                    if (a && c) o.x = base + (unsigned)(h_low * W + w_low) * cin4_;
+                    if (a && e) o.y = base + (unsigned)(h_low * W + w_high) * cin4_;
+                    if (b && c) o.z = base + (unsigned)(h_high * W + w_low) * cin4_;
+                    if (b && e) o.w = base + (unsigned)(h_high * W + w_high) * cin4_;
+                }
+                if (MOD) m = sg.mask[pp * ntap + tap];
+            }
+            dsc_o[idx] = o;
+            dsc_w[idx] = wt;
+            if (MOD) dsc_m[idx] = m;
+        }
+    }
+
+    // ---- loader geometry: thread = (pixel prow [+32], channel quarter q of the slab)
+    const int q = tid & 7, prow = tid >> 3;
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    // stash: 8 bytes = channels 4 q .. 4 q + 3 of the slab -> half (q & 1) of unit [q >> 1][pixel]
+    unsigned char *st0 = smem_raw + ((q >> 1) * DFB_PITCH + prow) * 16 + (q & 1) * 8;
+    // B: lane's operand of (step s, k half kh) of column block cb sits at wbase(cb) + (2 s + kh) * 1024 + lhalf * 512 + l32 * 16
+    const int cb = 4 * n_t + wave;
+    const size_t waddr = reinterpret_cast<size_t>(wpk) + (size_t)cb * (size_t)nsl * 2048u;
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 2048, 0x00020000);
+    const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
+    // fragments: unit [2 kh + lhalf][row], rows l32 and 32 + l32
+    const uintx4 *afrag = As + lhalf * DFB_PITCH + l32;
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float4 xc00, xc01, xc02, xc03, xc10, xc11, xc12, xc13;   // gathered corners: [pixel][corner]
+    uintx4 b0, b1;                                            // B operands of the two k halves of the step in flight
+    int f_cs = 0, f_tap = 0;                                  // (channel slab, tap) of the next step to fetch
+    unsigned f_kill = 0u;
+    int f_left = nsl;
+    uintx4 no0, no1;
+
+#define DB_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define DB_FETCH_PX(R, O)                                                                                              \
+    {                                                                                                                  \
+        const unsigned c_ = ((unsigned)(f_cs * 128) | f_kill) + (unsigned)(q * 16);                                    \
+        DB_LDX(xc##R##0, (O).x + c_) DB_LDX(xc##R##1, (O).y + c_) DB_LDX(xc##R##2, (O).z + c_) DB_LDX(xc##R##3, (O).w + c_) \
+    }
+    // gather of the next step (both pixels), then advance and pre-read the corner offsets of the one after it
+#define DB_FETCH                                                                                                       \
+    {                                                                                                                  \
+        f_kill = f_left > 0 ? 0u : 0x80000000u; --f_left;                                                              \
+        DB_FETCH_PX(0, no0) DB_FETCH_PX(1, no1)                                                                        \
+        if (++f_tap == ntap) { f_tap = 0; ++f_cs; }                                                                    \
+        no0 = dsc_o[f_tap * DFB_BM + prow]; no1 = dsc_o[f_tap * DFB_BM + prow + 32];                                   \
+    }
+    // blend pixel R (sampled for tap TAP), round to bf16, write its 4-channel half unit into A buffer BUF
+#define DB_STASH_PX(R, PX, TAP, BUF)                                                                                   \
+    {                                                                                                                  \
+        const float4 w_ = dsc_w[(TAP) * DFB_BM + (PX)];                                                                \
+        float4 v_;                                                                                                     \
+        v_.x = ((w_.x * (xc##R##0).x + w_.y * (xc##R##1).x) + w_.z * (xc##R##2).x) + w_.w * (xc##R##3).x;              \
+        v_.y = ((w_.x * (xc##R##0).y + w_.y * (xc##R##1).y) + w_.z * (xc##R##2).y) + w_.w * (xc##R##3).y;              \
+        v_.z = ((w_.x * (xc##R##0).z + w_.y * (xc##R##1).z) + w_.z * (xc##R##2).z) + w_.w * (xc##R##3).z;              \
+        v_.w = ((w_.x * (xc##R##0).w + w_.y * (xc##R##1).w) + w_.z * (xc##R##2).w) + w_.w * (xc##R##3).w;              \
+        if (MOD) { const float m_ = dsc_m[(TAP) * DFB_BM + (PX)]; v_.x = v_.x * m_; v_.y = v_.y * m_; v_.z = v_.z * m_; v_.w = v_.w * m_; } \
+        bf16x4 h_;                                                                                                     \
+        h_[0] = (__bf16)v_.x; h_[1] = (__bf16)v_.y; h_[2] = (__bf16)v_.z; h_[3] = (__bf16)v_.w;                        \
+        *reinterpret_cast<bf16x4 *>(st0 + (BUF) * (DFB_ABUF * 16) + 32 * 16 * (R)) = h_;                               \
+    }
+#define DB_BLOAD(S) { b0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((S), nsl - 1) * 2048u, 0);          \
+                      b1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((S), nsl - 1) * 2048u + 1024u, 0); }
+
+    __syncthreads();   // sampling table complete
+    // ---- prologue: step 0 -> buffer 0, gather of step 1 in flight, B of step 0
+    no0 = dsc_o[prow]; no1 = dsc_o[prow + 32];
+    DB_FETCH
+    DB_BLOAD(0)
+    DB_STASH_PX(0, prow, 0, 0)
+    DB_STASH_PX(1, prow + 32, 0, 0)
+    DB_FETCH
+    __syncthreads();
+    int s_tap = ntap == 1 ? 0 : 1;   // tap of step s+1
+    for (int s = 0; s < nsl; ++s) {
+        const int cur = s & 1;
+        // fragments and B operands of step s (buffer cur), then the MFMAs; meanwhile: blend + stash of step s+1 (gathered during
+        // step s-1) into the other buffer, and the gather of step s+2 into the registers that frees
+        const uintx4 a00 = afrag[cur * DFB_ABUF], a01 = afrag[cur * DFB_ABUF + 32];
+        const uintx4 a10 = afrag[cur * DFB_ABUF + 2 * DFB_PITCH], a11 = afrag[cur * DFB_ABUF + 2 * DFB_PITCH + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        DB_STASH_PX(0, prow, s_tap, cur ^ 1)
+        DB_STASH_PX(1, prow + 32, s_tap, cur ^ 1)
+        __builtin_amdgcn_sched_barrier(0);
+        DB_FETCH
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a00), __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a01), __builtin_bit_cast(bf16x8, b0), acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a10), __builtin_bit_cast(bf16x8, b1), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a11), __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DB_BLOAD(s + 1)
+        if (++s_tap == ntap) s_tap = 0;
+        __syncthreads();   // step s+1 is complete in the other buffer; every read of this one is done
+    }
+#undef DB_LDX
+#undef DB_FETCH_PX
+#undef DB_FETCH
+#undef DB_STASH_PX
+#undef DB_BLOAD
+
+    // ---- epilogue: + bias, ReLU, NHWC store (accumulator element r of lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3), column l32)
+    const int co = 32 * cb + l32;
+    const bool co_ok = co < p.Cout;
+    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = 32 * i + 4 * lhalf + (r & 3) + 8 * (r >> 2);
+            const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
+            float v = (i == 0 ? acc0[r] : acc1[r]) + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const long pp = ((long)t_n * sg.Ho + ho) * sg.Wo + wo;
+            if (co_ok && ho < sg.Ho && wo < sg.Wo) sg.out[pp * p.Cout + co] = v;
+        }
+    }
+}
+
+/* Fused deformable convolution on the bf16 matrix cores: same arguments and geometry as upsnet_deform_conv_fused_nhwc; wpack from
+ * upsnet_dcn_pack_weight_bf16. Results differ from the fp32 kernel by the bf16 rounding of the blended samples and of the weights
+ * (~3 significant digits per product, fp32 accumulation). */
+extern "C" int upsnet_deform_conv_fused_nhwc_bf16(void *stream, int nlev, const float *const x[], const float *const offset[],
+                                                  const float *const mask[], float *const out[], const int height[], const int width[],
+                                                  int cin, int cout, int kh, int kw, int pad, int stride, int dil, const void *wpack,
+                                                  const float *bias, int relu)
+{
+    UPS_REQUIRE(nlev >= 1 && nlev <= 4 && offset && wpack, "deform_conv_fused_nhwc_bf16: nlev must be 1..4 and offsets / weights given");
+    for (int l = 0; l < nlev; ++l) UPS_REQUIRE(offset[l] && (!mask || mask[l]), "deform_conv_fused_nhwc_bf16: null offset/mask at level %d", l);
+    UPS_REQUIRE(kh * kw >= 1 && kh * kw <= 25, "deform_conv_fused_nhwc_bf16: at most 25 taps (got %dx%d)", kh, kw);
+    ConvParams p;
+    const int ldw = (cout + 31) / 32 * 32;
+    int rc = conv_fill(p, "deform_conv_fused_nhwc_bf16", nlev, x, nullptr, offset, mask, out, nullptr, height, width, cin, cout,
+                       reinterpret_cast<const float *>(wpack), ldw, bias, kh, kw, stride, pad, dil, relu);
+    if (rc) return rc;
+    for (int i = 0; i < p.nseg; ++i)
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * cin < (1L << 29), "deform_conv_fused_nhwc_bf16: feature map %d exceeds 2 GiB; split the batch", i);
+    int tiles = 0;
+    for (int i = 0; i < p.nseg; ++i) {   // 8 x 8 pixel tiles
+        p.seg[i].tile_start = tiles;
+        tiles += p.seg[i].N * ((p.seg[i].Ho + 7) / 8) * ((p.seg[i].Wo + 7) / 8);
+    }
+    p.m_tiles = tiles;
+    p.n_tiles = (cout + DFB_BN - 1) / DFB_BN;
+    const size_t smem = (size_t)2 * DFB_ABUF * 16 + (size_t)kh * kw * DFB_BM * (16 + 16 + 4);
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    const __bf16 *wp = reinterpret_cast<const __bf16 *>(wpack);
+    if (mask) hipLaunchKernelGGL((dcn_fused_bf16_kernel<true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p, wp);
+    else hipLaunchKernelGGL((dcn_fused_bf16_kernel<false>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p, wp);
+    UPS_CHECK_LAUNCH("dcn_fused_bf16_kernel");
+    return 0;
+}

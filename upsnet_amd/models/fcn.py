@@ -53,7 +53,7 @@ class FCNSubNet(nn.Module):
         return x
 
     def _wpack(self, i, dc):
-        key = (dc.weight.data_ptr(), dc.weight._version)
+        key = (dc.weight.data_ptr(), dc.weight._version, ops.dcn_precision())
         if i not in self._packed or self._packed[i][0] != key:
             self._packed[i] = (key, ops.pack_dcn_weight(dc.weight.detach()))
         return self._packed[i][1]

@@ -175,11 +175,26 @@ def roi_align_backward(pooled_h, pooled_w, sampling_ratio, spatial_scale, top_gr
 DCN_KERNEL = os.environ.get('UPSNET_DCN_KERNEL', 'frag')
 
 
+def dcn_precision():
+    """'bf16' when the dense convolutions run on the bf16 matrix cores (hipconv.PRECISION == 'bf16', BASELINE configs[2]): the fused
+    deformable convolutions then do too (csrc/deform_fused_bf16.hip). 'bf16x3' and 'fp32' keep the exact fp32 kernel."""
+    from .models import hipconv
+    return 'bf16' if hipconv.PRECISION == 'bf16' and os.environ.get('UPSNET_DCN_BF16', '1') != '0' else 'fp32'
+
+
 def pack_dcn_weight(weight, kind=None):
-    """[Cout,Cin,kh,kw] -> packed weight for deform_conv_fused: ('frag', wp) in MFMA fragment order for csrc/deform_fused.hip, or
+    """[Cout,Cin,kh,kw] -> packed weight for deform_conv_fused: ('frag', wp) in MFMA fragment order for csrc/deform_fused.hip
+    (('frag_bf16', wp) for csrc/deform_fused_bf16.hip: kind 'frag_bf16', or 'frag' while dcn_precision() is 'bf16'), or
     (wpack [kh*kw*Cin, ldw], ldw) -- the dense convolution's packing -- for the first-generation kernel."""
     kind = kind or DCN_KERNEL
     cout, cin, kh, kw = weight.shape
+    if kind == 'frag' and dcn_precision() == 'bf16':
+        kind = 'frag_bf16'
+    if kind == 'frag_bf16' and cin % 32 == 0 and kh * kw <= 25:
+        w = f32c(weight)
+        wp = torch.empty((lib().upsnet_dcn_packed_weight_bf16_elems(cout, cin, kh, kw),), dtype=torch.bfloat16, device=w.device)
+        check(lib().upsnet_dcn_pack_weight_bf16(stream(), ptr(w), cout, cin, kh, kw, ptr(wp)), "dcn_pack_weight_bf16")
+        return ('frag_bf16', wp)
     if kind == 'frag' and cin % 32 == 0 and kh * kw <= 25:
         w = f32c(weight)
         wp = torch.empty((lib().upsnet_dcn_packed_weight_floats(cout, cin, kh, kw),), dtype=torch.float32, device=w.device)
@@ -190,7 +205,7 @@ def pack_dcn_weight(weight, kind=None):
 
 def cached_dcn_pack(weight):
     """Packed deformable-convolution weight cached ON the weight tensor (re-packed when it changes or moves)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL)
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL, dcn_precision())
     ent = weight.__dict__.get('_ups_dcn_pack')
     if ent is None or ent[0] != key:
         ent = (key, pack_dcn_weight(weight.detach()))
@@ -225,12 +240,12 @@ def dcn_ksplit(outs, cin, cout, taps):
     return ks
 
 
-def _dcn_event(ev0, xs, outs, cin, cout, ksize):
+def _dcn_event(ev0, xs, outs, cin, cout, ksize, kind='dcn_fused'):
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record()
     npix = sum(o.shape[2] * o.shape[3] for o in outs)
     taps = ksize[0] * ksize[1]
-    PROFILE['events'].append(('dcn_fused', ev0, ev1, 2.0 * cout * cin * taps * npix,
+    PROFILE['events'].append((kind, ev0, ev1, 2.0 * cout * cin * taps * npix,
                               4.0 * (sum(x.shape[2] * x.shape[3] for x in xs) * cin + npix * (2 * taps + cout) + cout * cin * taps),
                               "dcn %d->%d %s" % (cin, cout, [tuple(x.shape[2:]) for x in xs])))
 
@@ -258,6 +273,17 @@ def deform_conv_fused(xs, offsets, wpack, bias, cin, cout, ksize, stride, pad, d
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    if wp == 'frag_bf16':   # bf16 matrix cores (BASELINE configs[2])
+        if not (pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]):
+            raise RuntimeError("deform_conv_fused: square pad / stride / dilation only")
+        check(lib().upsnet_deform_conv_fused_nhwc_bf16(stream(), n, ptr_array(xs), ptr_array(offsets),
+                                                       ptr_array(masks) if masks is not None else None, ptr_array(outs),
+                                                       int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]),
+                                                       int(cin), int(cout), ksize[0], ksize[1], pad[0], stride[0], dil[0], ptr(ldw), ptr(b),
+                                                       int(bool(relu))), "deform_conv_fused_nhwc_bf16")
+        if PROFILE['enabled']:
+            _dcn_event(ev0, xs, outs, cin, cout, ksize, 'dcn_fused_bf16')
+        return outs
     if wp == 'frag':   # (kind, packed) from pack_dcn_weight: second-generation kernel
         if not (pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]):
             raise RuntimeError("deform_conv_fused: square pad / stride / dilation only")
