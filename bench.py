@@ -216,8 +216,8 @@ def main():
                 'bound': 'mfma', 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'achieved': round(mult * f_b / t_b / 1e12, 3), 'frac': round(mult * f_b / t_b / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 'achieved_algorithmic': round(f_b / t_b / 1e12, 3), 'launches_timed': n_b, 'ms_per_image': round(1000.0 * t_b / n_sampled, 3),
-                'note': 'layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem, the deconvolution, the FPN laterals with the '
-                        'upsampled add stay on the fp32 kernels (they are in the fp32 family above); in the bf16 mode the deformable '
+                'note': 'layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem and the deconvolution '
+                        'stay on the fp32 kernels (they are in the fp32 family above); in the bf16 mode the deformable '
                         'convolutions run on csrc/deform_fused_bf16.hip (deformable_bf16 below), in the bf16x3 mode on the fp32 kernel'}
         if n_d and t_d > 0:
             roofline['deformable'] = {'kernel': 'dcn_fused_f32_kernel (csrc/deform_fused.hip: fused deformable convolution v1, fp32 MFMA)', 'bound': 'mfma',

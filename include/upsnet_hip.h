@@ -231,7 +231,8 @@ int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout
  *   wpack_lo != NULL : "bf16x3" -- a = a_hi + a_lo, b = b_hi + b_lo; a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi (error ~2^-16
  *                      relative per product, fp32 accumulation): inside the 1e-4 fp32-logit tolerance
  * wpack_hi / wpack_lo: bf16 [KH*KW*Cin/32][ldw][32] from upsnet_conv_pack_weight_bf16, ldw = Cout rounded up to 64.
- * Same calling convention as upsnet_conv2d_nhwc_f32 (without residual_up). */
+ * Same calling convention as upsnet_conv2d_nhwc_f32 (without residual_up). relu: bit 0 = ReLU; bit 1 = `residual` is at half
+ * resolution and is added through a nearest x2 upsampling (1x1 kernels only: the FPN top-down add). */
 int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], const float *const residual[], float *const out[],
                             const int batch[], const int height[], const int width[], int Cin, const void *wpack_hi,
                             const void *wpack_lo, int ldw, const float *bias, int Cout, int KH, int KW, int stride, int pad,

@@ -354,6 +354,25 @@ def test_conv_bf16_matrix_cores_vs_torch(N, Cin, Cout, H, W, k, stride, pad, rel
     assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,split", [(1, 256, 256, 32, 64, True), (2, 512, 256, 18, 22, True), (1, 64, 96, 6, 10, False)])
+def test_conv_bf16_lateral_with_upsampled_residual(N, Cin, Cout, H, W, split):
+    """FPN top-down add on the bf16 kernel: conv1x1(x) + nearest_up2(residual) with the upsampling folded into the residual read
+    (fpn.py:34,90-96); widths that are / are not a multiple of 32 (both index paths)."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + W)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    r = torch.randn(N, Cout, H // 2, W // 2, device='cuda')
+    ref = F.conv2d(x.double(), w.double(), b.double()) + F.interpolate(r.double(), scale_factor=2, mode='nearest')
+    hi, lo, ldw = ops.pack_conv_weight_bf16(w, split=split)
+    out = ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, b, Cout, 1, 1, 0, residuals=[r], residual_up=True)[0]
+    tol = 1e-4 if split else 3e-2
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=tol, atol=tol)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, b, Cout, 1, 1, 0, residuals=[r[:, :, :-1]], residual_up=True)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,ksplit,relu,res", [
     (1, 256, 256, 64, 128, 3, 1, 2, True, False), (1, 512, 512, 32, 64, 3, 1, 4, True, False), (1, 2048, 512, 32, 64, 1, 1, 4, True, False),
     (1, 1024, 256, 17, 23, 1, 1, 3, False, True), (2, 64, 128, 9, 9, 3, 2, 2, True, True),

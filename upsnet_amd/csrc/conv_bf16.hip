@@ -210,7 +210,32 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
         for (int i = 0; i < 2; ++i) {
             const long pbase = p0 + wm * 64 + 32 * i + 4 * akr;
             float rr[16];
-            if (has_res) {
+            if (has_res && p.res_up) {
+                // residual at half resolution, read through a nearest x2 upsampling (FPN top-down add, fpn.py:34,90-96). The 32 rows
+                // of the block are consecutive output pixels from a multiple of 32: with Wo % 32 == 0 they lie in one image row
+                const long HoWo_ = (long)sg.Ho * sg.Wo;
+                const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
+                if ((sg.Wo & 31) == 0) {
+                    const long pb0 = p0 + wm * 64 + 32 * i;
+                    const long pb = pb0 < sg.M ? pb0 : 0;
+                    const int n_b = (int)(pb / HoWo_);
+                    const int rem_b = (int)(pb - (long)n_b * HoWo_);
+                    const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
+                    const long rb = ((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1) + 2 * akr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = sg.res[(rb + (((r & 3) + 8 * (r >> 2)) >> 1)) * p.Cout + coc];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        long pp = pbase + (r & 3) + 8 * (r >> 2);
+                        pp = pp < sg.M ? pp : sg.M - 1;
+                        const int n = (int)(pp / HoWo_);
+                        const int rem = (int)(pp - (long)n * HoWo_);
+                        const int h = rem / sg.Wo, w = rem - h * sg.Wo;
+                        rr[r] = sg.res[(((long)n * Hr + (h >> 1)) * Wr + (w >> 1)) * p.Cout + coc];
+                    }
+                }
+            } else if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     long pp = pbase + (r & 3) + 8 * (r >> 2);
@@ -476,9 +501,17 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
                                        int relu)
 {
     ConvParams p;
+    const int res_up = (relu >> 1) & 1;   // relu: bit 0 = ReLU, bit 1 = the residual is at half resolution (nearest x2 upsampled add)
+    relu &= 1;
     int rc = conv_fill(p, "conv2d_nhwc_bf16", nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout,
                        reinterpret_cast<const float *>(wpack_hi), ldw, bias, KH, KW, stride, pad, 1, relu);
     if (rc) return rc;
+    if (res_up) {
+        UPS_REQUIRE(residual && KH == 1 && KW == 1, "conv2d_nhwc_bf16: the upsampled residual needs a residual and a 1x1 kernel");
+        for (int i = 0; i < p.nseg; ++i)
+            UPS_REQUIRE(p.seg[i].Ho % 2 == 0 && p.seg[i].Wo % 2 == 0, "conv2d_nhwc_bf16: the upsampled residual needs even output dims");
+        p.res_up = 1;
+    }
     UPS_REQUIRE(ldw % CB_BN == 0, "conv2d_nhwc_bf16: ldw must be a multiple of %d (got %d)", CB_BN, ldw);
     UPS_REQUIRE(KH * KW <= 9, "conv2d_nhwc_bf16: at most 9 taps");
     for (int i = 0; i < p.nseg; ++i)   // bit 31 of a pixel offset flags the zero padding

@@ -196,10 +196,11 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
     winograd=False / 'always' pins the direct / the Winograd form (layers whose batch size varies at run time: the choice,
     hence the rounding, must not depend on it)."""
     if supported(m, x):
-        if not residual_up and _use_bf16(m, [x], always=(winograd == 'always')):
+        if (not residual_up or tuple(m.kernel_size) == (1, 1)) and _use_bf16(m, [x], always=(winograd == 'always')):
             hi, lo, ldw = _bf16_plan(m)
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
-                                              relu=relu, residuals=None if residual is None else [residual])[0]
+                                              relu=relu, residuals=None if residual is None else [residual],
+                                              residual_up=residual_up)[0]
         if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
             ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])

@@ -959,8 +959,9 @@ def pack_conv_weight_bf16(weight, split=True):
     return hi, lo, ldw
 
 
-def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None):
-    """conv2d_nhwc_multi on the bf16 matrix cores: wlo None -> plain bf16 products, else the 3-term split (fp32-equivalent)."""
+def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None, residual_up=False):
+    """conv2d_nhwc_multi on the bf16 matrix cores: wlo None -> plain bf16 products, else the 3-term split (fp32-equivalent).
+    residual_up (1x1 kernels): the residuals are at half resolution, added through a nearest x2 upsampling."""
     require_cuda(whi, *xs)
     assert 1 <= len(xs) <= 5
     xs = [nhwc(x.float()) for x in xs]
@@ -974,8 +975,9 @@ def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, re
     if residuals is not None:
         ress = [nhwc(r.float()) for r in residuals]
         for r, o in zip(ress, outs):
-            if tuple(r.shape) != tuple(o.shape):
-                raise RuntimeError("conv2d_nhwc_bf16: residual shape %s != %s" % (tuple(r.shape), tuple(o.shape)))
+            want = (o.shape[0], o.shape[1], o.shape[2] // 2, o.shape[3] // 2) if residual_up else tuple(o.shape)
+            if tuple(r.shape) != want:
+                raise RuntimeError("conv2d_nhwc_bf16: residual shape %s != %s" % (tuple(r.shape), want))
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -983,7 +985,7 @@ def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, re
                                         int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
                                         int_array([x.shape[3] for x in xs]), int(cin), ptr(whi), ptr(wlo), int(ldw),
                                         ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride), int(pad),
-                                        int(bool(relu))), "conv2d_nhwc_bf16")
+                                        int(bool(relu)) | (2 if (residual_up and ress is not None) else 0)), "conv2d_nhwc_bf16")
     if PROFILE['enabled']:
         ev1.record()
         npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
