@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libupsnet_hip.so")
+LIB_PATH = os.environ.get("UPSNET_LIB_PATH") or os.path.join(_HERE, "csrc", "libupsnet_hip.so")   # (the override: same-box A/B of two builds)
 
 c_int, c_float, c_double, c_void_p, c_size_t, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long
 P = c_void_p
