@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import deform_im2col, roi_align_forward
+from . import deform_im2col
 from . import ops as oops
 
 

@@ -6,13 +6,11 @@ returns the run-length encoding as the list of column-major pixel indices where 
 that into pycocotools' `counts` (differences) and its compressed string (rleToString of pycocotools' maskApi.c -- a third-party
 format, restated from the published algorithm).
 """
-import ctypes
 
 import numpy as np
 import torch
 
 from .._lib import check, lib, ptr, stream
-from ..config.config import config
 
 
 def counts_from_transitions(positions, num_pixels):

@@ -1,7 +1,6 @@
 """FPN (upsnet/models/fpn.py:25-104): 1x1 laterals, nearest x2 top-down adds, 3x3 outputs,
 P6 = stride-2 subsample of P5, optional GAP branch (COCO configs). with_norm='none' only (every
 shipped config)."""
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 

@@ -4,14 +4,12 @@ MI355X notes: FPNRoIAlign delivers channels-last pooled features straight from t
 consumes them without a transpose by using fc6's weight re-laid-out once to the (ph, pw, c) flatten
 order (same dot products, different summation order); the mask head's convolutions take channels-last.
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..config.config import config
 from . import hipconv
 from ..operators.modules.fpn_roi_align import FPNRoIAlign
-from ..operators.modules.roialign import RoIAlign
 
 
 class MaskBranch(nn.Module):

@@ -18,7 +18,6 @@ import os
 
 import numpy as np
 import torch
-import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops

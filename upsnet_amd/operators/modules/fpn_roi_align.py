@@ -8,7 +8,6 @@ device inside ONE launch over all four levels and the output is written directly
 returns, so ``pool_feat.view(N, -1)`` works for a drop-in caller); ``channels_last=True`` keeps the
 kernel's native NHWC output (no transpose), which is what the model's heads consume.
 """
-import torch
 from torch.nn.modules.module import Module
 
 from ... import ops

@@ -4,7 +4,6 @@ forward(mask_rois [m,4], cls_prob [m], mask_prob [m,1,28,28], cls_idx [m], im_sh
 (keep_inds int64 [k], mask_energy [1,k,H,W]). `select` is the variant used by the fused panoptic head:
 it returns the selection only (no [k,H,W] planes are materialised).
 """
-import torch
 import torch.nn as nn
 
 from ... import ops
