@@ -95,11 +95,16 @@ def deform_conv(x, offset, dc, bn=None, relu=False, chunk=64):
 
 
 # ----------------------------------------------------------------------------- backbone / FPN / RPN
-def bottleneck(x, blk):
-    """resnet.py:84-100 (Bottleneck.forward) / :133-153 (DCNBottleneck.forward)."""
+def bottleneck(x, blk, given=None, own=None):
+    """resnet.py:84-100 (Bottleneck.forward) / :133-153 (DCNBottleneck.forward). given: iterator over recorded sampling offsets
+    (one per deformable block, in graph order) to sample at instead of the ones predicted here; own: list receiving the latter."""
     y = conv_bn(x, blk.conv1, blk.bn1, relu=True)
     if hasattr(blk, 'conv2_offset'):
         off = conv_bn(y, blk.conv2_offset)
+        if own is not None:
+            own.append(off)
+        if given is not None:
+            off = next(given).to(device=y.device, dtype=y.dtype)
         y = deform_conv(y, off, blk.conv2, blk.bn2, relu=True)
     else:
         y = conv_bn(y, blk.conv2, blk.bn2, relu=True)
@@ -108,14 +113,17 @@ def bottleneck(x, blk):
     return F.relu(y + sc)
 
 
-def backbone(x, bb):
-    """resnet.py:347-356: conv1 (7x7/2 + BN + ReLU + 3x3/2 max-pool, :169-175) then res2..res5."""
+def backbone(x, bb, given_offsets=None, own_offsets=None):
+    """resnet.py:347-356: conv1 (7x7/2 + BN + ReLU + 3x3/2 max-pool, :169-175) then res2..res5. given_offsets: recorded sampling
+    offsets of the deformable bottlenecks in graph order (a chaotic chain of 30 data-dependent samplers cannot be compared
+    free-running: the strict check is made at identical sampling positions, and the offset predictions on their own)."""
+    given = iter(given_offsets) if given_offsets is not None else None
     y = conv_bn(x, bb.conv1.conv1, bb.conv1.bn1, relu=True)
     y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
     feats = []
     for name in ('res2', 'res3', 'res4', 'res5'):
         for blk in getattr(bb, name).layers:
-            y = bottleneck(y, blk)
+            y = bottleneck(y, blk, given, own_offsets)
         feats.append(y)
     return feats
 
@@ -241,7 +249,7 @@ def mask_head(feats, boxes, m, size):
 
 
 # ----------------------------------------------------------------------------- driver
-def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, dtype=torch.float64, fcn_offsets=None):
+def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, dtype=torch.float64, fcn_offsets=None, backbone_offsets=None):
     """The dense stages of resnet_upsnet.forward (resnet_upsnet.py:88-248, test branch) in float64, with the SELECTION results
     (rois, detections) taken from the caller (the product's recorded ones: selection is integer work with its own bit-exact
     tests, and tiny logit differences must not be allowed to change which boxes the two executions look at).
@@ -250,21 +258,22 @@ def dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, dtype=to
     global D
     saved, D = D, dtype
     try:
-        return _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets)
+        return _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets, backbone_offsets)
     finally:
         D = saved
 
 
-def _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets):
+def _dense_reference(model, data, rois, det_boxes, pan_boxes, mask_size, fcn_offsets, backbone_offsets=None):
     with torch.no_grad():
         dev = next(model.parameters()).device
         x = data['data'].to(dev).to(D)
         if x.shape[1] == 4:
             x = x[:, :3]
-        res = backbone(x.contiguous(), model.resnet_backbone)
+        own_bb = []
+        res = backbone(x.contiguous(), model.resnet_backbone, backbone_offsets, own_bb)
         pyr = fpn(*res, model.fpn)
         r = [rpn(f, model.rpn) for f in pyr]
-        out = dict(res=res, pyramid=pyr, rpn_cls_prob=[t[2] for t in r], rpn_bbox_pred=[t[1] for t in r])
+        out = dict(res=res, pyramid=pyr, rpn_cls_prob=[t[2] for t in r], rpn_bbox_pred=[t[1] for t in r], backbone_offsets=own_bb)
         out['fcn_score'] = fcn_score(pyr, model.fcn_head)
         if fcn_offsets is not None:
             own = []

@@ -18,7 +18,7 @@ def setup():
     from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
     update_config_dict(CITYSCAPES_R50)
     from upsnet_amd.synthetic import build_model, make_image
-    model = build_model(cls_gain=0.3)
+    model = build_model()
     data = make_image(256, 512, seed=0, device='cuda')
     return model, data
 
@@ -49,7 +49,7 @@ def test_full_size_stagewise_parity():
     from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
     update_config_dict(CITYSCAPES_R50)
     from upsnet_amd.synthetic import build_model, make_image
-    model = build_model(cls_gain=0.3)
+    model = build_model()
     data = make_image(1024, 2048, seed=1, device='cuda')
     model.taps = {}
     with torch.no_grad():
@@ -89,7 +89,7 @@ def test_coco_r101_dcn_config_stagewise_parity():
     update_config_dict(COCO_R101_DCN)
     try:
         from upsnet_amd.synthetic import build_model, make_image
-        model = build_model(cls_gain=0.3)
+        model = build_model()
         assert sum(1 for n, _ in model.named_modules() if n.endswith('conv2_offset')) == 4 + 23 + 3
         data = make_image(200, 333, seed=2, device='cuda')   # padded to 224 x 352
         model.taps = {}
@@ -111,7 +111,7 @@ def test_coco_r101_dcn_full_size_stagewise_parity():
     update_config_dict(COCO_R101_DCN)
     try:
         from upsnet_amd.synthetic import build_model, make_image
-        model = build_model(cls_gain=0.3)
+        model = build_model()
         data = make_image(800, 1333, seed=5, device='cuda')
         model.taps = {}
         with torch.no_grad():
@@ -166,7 +166,7 @@ def test_mixed_resolution_stream_r101_dcn():
     update_config_dict(COCO_R101_DCN)
     try:
         from upsnet_amd.synthetic import build_model, make_image
-        model = build_model(cls_gain=0.3)
+        model = build_model()
         imgs = [make_image(128, 256, seed=3, device='cuda'), make_image(100, 167, seed=4, device='cuda')]   # second pads to 128 x 192
         first = {}
         with torch.no_grad():

@@ -212,7 +212,7 @@ def test_dense_fp64_reference_agrees_with_the_modules_on_cpu():
     from upsnet_amd.synthetic import build_model, make_image
     from conftest import gen_rois
     torch.set_num_threads(8)
-    m = build_model(cls_gain=0.3, device='cpu', channels_last=False)
+    m = build_model(device='cpu', channels_last=False)
     data = make_image(64, 128, seed=0)
     with torch.no_grad():
         res = m.resnet_backbone(data['data'])
@@ -248,7 +248,7 @@ def test_forward_cpu_covers_the_dcn_backbone():
         from upsnet_amd.synthetic import build_model, make_image
         from oracle.forward import forward_cpu
         torch.set_num_threads(8)
-        m = build_model(cls_gain=0.3, device='cpu', channels_last=False)
+        m = build_model(device='cpu', channels_last=False)
         out = forward_cpu(m, make_image(64, 96, seed=0))
         assert out['panoptic_outputs'].shape == (64, 96) and out['n_rois'] <= 300 and out['mask_probs'].shape[1:] == (81, 28, 28)
     finally:

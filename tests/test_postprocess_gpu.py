@@ -57,7 +57,7 @@ def test_unified_pan_on_model_output():
     update_config_dict(CITYSCAPES_R50)
     from upsnet_amd.dataset.base_dataset import BaseDataset
     from upsnet_amd.synthetic import build_model, make_image
-    model = build_model(cls_gain=0.3)
+    model = build_model()
     with torch.no_grad():
         out = model(make_image(256, 512, seed=0, device='cuda'))
     res = BaseDataset().get_unified_pan_result([out['fcn_outputs']], [out['panoptic_outputs']], [out['panoptic_cls_inds']], stuff_area_limit=500)[0]

@@ -78,7 +78,7 @@ def test_model_from_uint8_image_equals_model_from_fp32_blob():
     update_config_dict(CITYSCAPES_R50)
     from upsnet_amd.dataset.blob import get_image_blob
     from upsnet_amd.synthetic import build_model
-    model = build_model(cls_gain=0.3)
+    model = build_model()
     rng = np.random.default_rng(5)
     im = rng.integers(0, 256, size=(250, 500, 3), dtype=np.uint8)   # padded to 256 x 512
     with torch.no_grad():

@@ -23,32 +23,44 @@ def _err(got, ref):
     return worst, (float(err.max()) if err.numel() else 0.0), (float(ref.abs().max()) if err.numel() else 0.0)
 
 
-def _run(preset, h, w, seed, strict, offsets_chain=True):
-    """strict: names that must be within rtol = atol = 1e-4 (elementwise) of the float64 value. The others must be within 1e-4 OR
-    at most 3x as far from the float64 value as a plain fp32 library execution of the same graph (torch / MIOpen convolutions,
-    oracle.dense_ref in float32), i.e. as accurate as the reference's own fp32 path. Two things make the elementwise 1e-4
-    unattainable for ANY fp32 execution on these synthetic weights (frozen identity BN: activations of magnitude 50-140):
-    tensors behind deformable layers (an offset difference of 1e-5 px moves a sample of magnitude-100 features by 1e-3), and, at
-    1024x2048, near-zero elements of tensors whose scale is ~50 (the library execution itself is 2.4x over the bound there)."""
+def _run(preset, h, w, seed, strict, report_only=()):
+    """strict: names that must be within rtol = atol = 1e-4 (elementwise) of the float64 value; report_only: names that are compared
+    and printed but not asserted. Every other name must be within 1e-4 OR at most 3x as far from the float64 value as a plain fp32
+    library execution of the same graph (torch / MIOpen convolutions, oracle.dense_ref in float32) -- since r08 (calibrated synthetic
+    statistics, activations O(1-10) as in a trained network) no tensor of either model needs that escape.
+
+    Data-dependent samplers are compared AT IDENTICAL SAMPLING POSITIONS: the float64 execution samples every deformable layer
+    (the 2-3 of the semantic head; the 30 bottlenecks of the R101-DCN backbone) at the offsets the product recorded, and the offset
+    predictions themselves are compared layer by layer along that same chain, strictly. (Free-running, a deformable layer multiplies
+    an offset difference by the local feature gradient, which on the spatially white feature maps of a random-noise image is ~1 per
+    pixel: ~3x per layer, so 30 layers in sequence are chaotic for ANY fp32 execution. 'fcn_score' free-running is report_only.)"""
     from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50, config
+    from upsnet_amd.models import hipconv
     from oracle import dense_ref
     update_config_dict(preset)
     try:
         from upsnet_amd.synthetic import build_model, make_image
-        model = build_model(cls_gain=0.3)
+        model = build_model()
         data = make_image(h, w, seed=seed, device='cuda')
         model.taps = {}
         sub = model.fcn_head.fcn_subnet
         sub.taps = {}
-        with torch.no_grad():
-            out = model(data)
+        hipconv.TRACE = []
+        try:
+            with torch.no_grad():
+                out = model(data)
+            trace = hipconv.TRACE
+        finally:
+            hipconv.TRACE = None
         t, model.taps = model.taps, None
         offs, sub.taps = sub.taps['offsets'], None
+        bb_offs = [r['offsets'][0] for r in trace if r['kind'] == 'dcn' and r['form'] == 'dcn_fused']   # backbone bottlenecks, graph order
+        del trace
         n = int(t['n_rois'].item())
         ms = config.network.mask_size
         args = (model, data, t['rois'][:n], t['det_boxes'], t['pan_boxes'], ms)
-        ref = dense_ref.dense_reference(*args, fcn_offsets=offs)
-        lib = dense_ref.dense_reference(*args, dtype=torch.float32, fcn_offsets=offs)
+        ref = dense_ref.dense_reference(*args, fcn_offsets=offs, backbone_offsets=bb_offs or None)
+        lib = dense_ref.dense_reference(*args, dtype=torch.float32, fcn_offsets=offs, backbone_offsets=bb_offs or None)
 
         def pan_logit(r):
             return r['mask_logit_pan'].gather(1, t['pan_cls'].view(-1, 1, 1, 1).expand(-1, -1, ms, ms).to(r['mask_logit_pan'].device))
@@ -61,52 +73,59 @@ def _run(preset, h, w, seed, strict, offsets_chain=True):
         pairs['mask_probs'] = (out['mask_probs'], torch.sigmoid(ref['mask_logit_det']), torch.sigmoid(lib['mask_logit_det']))
         pairs['pan_mask_logit'] = (t['pan_logit'], pan_logit(ref), pan_logit(lib))
         pairs['fcn_score'] = (t['fcn_score'], ref['fcn_score'], lib['fcn_score'])
-        # the semantic head at IDENTICAL sampling positions (the product's recorded offsets): strict; and the offset predictions
-        # themselves, layer by layer, against the float64 prediction along that same chain: strict
-        # (only meaningful when the features in front of the head are themselves strictly equal: not behind a DCN backbone)
-        if offsets_chain:
-            pairs['fcn_score_at_recorded_offsets'] = (t['fcn_score'], ref['fcn_score_given'], lib['fcn_score_given'])
-            for i, per_level in enumerate(offs):
-                for l, o in enumerate(per_level):
-                    pairs['fcn_offset_layer%d_p%d' % (i, l + 2)] = (o, ref['fcn_offsets'][i][l], lib['fcn_offsets'][i][l])
+        pairs['fcn_score_at_recorded_offsets'] = (t['fcn_score'], ref['fcn_score_given'], lib['fcn_score_given'])
+        for i, per_level in enumerate(offs):
+            for l, o in enumerate(per_level):
+                pairs['fcn_offset_layer%d_p%d' % (i, l + 2)] = (o, ref['fcn_offsets'][i][l], lib['fcn_offsets'][i][l])
+        for i, o in enumerate(bb_offs):
+            pairs['backbone_offset_%02d' % i] = (o, ref['backbone_offsets'][i], lib['backbone_offsets'][i])
         rep, bad = {}, {}
         for name, (got, r64, r32) in pairs.items():
             worst, max_abs, max_ref = _err(got, r64)
             ent = dict(worst_over_bound=round(worst, 3), max_abs=max_abs, max_ref=max_ref)
             ok = worst <= 1.0
-            if r32 is not None:
-                lib_worst, lib_abs, _ = _err(r32, r64)
-                ent.update(fp32_library_worst_over_bound=round(lib_worst, 3), fp32_library_max_abs=lib_abs)
-                if not ok and name not in strict:
-                    ok = max_abs <= 3.0 * lib_abs
-                    ent['criterion'] = '<= 3x the fp32 library execution'
+            lib_worst, lib_abs, _ = _err(r32, r64)
+            ent.update(fp32_library_worst_over_bound=round(lib_worst, 3), fp32_library_max_abs=lib_abs)
+            if not ok and name not in strict and name not in report_only:
+                ok = max_abs <= 3.0 * lib_abs
+                ent['criterion'] = '<= 3x the fp32 library execution'
             rep[name] = ent
-            if not ok:
+            if not ok and name not in report_only:
                 bad[name] = ent
         assert not bad, bad
         assert n > 50 and t['det_boxes'].shape[0] >= 1 and t['pan_boxes'].shape[0] >= 1
+        assert not any('criterion' in v for v in rep.values()), {k: v for k, v in rep.items() if 'criterion' in v}
         return rep
     finally:
         update_config_dict(CITYSCAPES_R50)
 
 
 _RPN = ['rpn_cls_prob_p%d' % l for l in range(2, 7)] + ['rpn_bbox_pred_p%d' % l for l in range(2, 7)]
+_STRICT = _RPN + ['cls_prob', 'bbox_pred', 'mask_probs', 'pan_mask_logit', 'fcn_score_at_recorded_offsets']
+
+
+def _summary(rep):
+    keep = {k: v for k, v in rep.items() if not k.startswith(('backbone_offset_', 'fcn_offset_'))}
+    offs = [v['worst_over_bound'] for k, v in rep.items() if k.startswith(('backbone_offset_', 'fcn_offset_'))]
+    print({k: (v['worst_over_bound'], v.get('fp32_library_worst_over_bound')) for k, v in keep.items()}, 'offset predictions: worst', max(offs))
 
 
 @pytest.mark.parametrize("h,w", [(256, 512), (1024, 2048)])
 def test_trunk_logits_vs_fp64_reference_upsnet50(h, w):
-    """UPSNet-50 has no deformable layer in front of the RPN / box / mask heads: all of them strictly within 1e-4; the semantic
-    head strictly at the recorded offsets."""
+    """UPSNet-50: RPN / box / mask heads, the panoptic mask logits and the semantic head (at the recorded offsets) strictly within 1e-4
+    at both sizes, 1024x2048 = the benchmark configuration included; every offset prediction strictly."""
     from upsnet_amd.config.config import CITYSCAPES_R50
-    strict = _RPN + ['cls_prob', 'bbox_pred', 'mask_probs'] + (['pan_mask_logit', 'fcn_score_at_recorded_offsets'] if h * w < 1 << 20 else [])
-    rep = _run(CITYSCAPES_R50, h, w, seed=3, strict=strict)
-    print({k: (v['worst_over_bound'], v.get('fp32_library_worst_over_bound')) for k, v in rep.items()})
+    rep = _run(CITYSCAPES_R50, h, w, seed=3, strict=_STRICT + ['fcn_offset_layer%d_p%d' % (i, l) for i in range(2) for l in range(2, 6)],
+               report_only=['fcn_score'])
+    _summary(rep)
 
 
 @pytest.mark.parametrize("h,w", [(200, 333), (800, 1333)])
 def test_trunk_logits_vs_fp64_reference_upsnet101_dcn(h, w):
     """BASELINE configs[3]: R101 with DCN v1 in res3-res5 (30 deformable layers in front of everything), GAP in the FPN, 3 FCN
-    layers, 81 / 133 classes, 300 proposals."""
+    layers, 81 / 133 classes, 300 proposals: the same strict list, every deformable layer sampled at the product's recorded offsets
+    and every offset prediction (30 backbone + 3 x 4 head) strictly within 1e-4 of the float64 prediction along that chain."""
     from upsnet_amd.config.config import COCO_R101_DCN
-    rep = _run(COCO_R101_DCN, h, w, seed=4, strict=[], offsets_chain=False)
-    print({k: (v['worst_over_bound'], v.get('fp32_library_worst_over_bound')) for k, v in rep.items()})
+    rep = _run(COCO_R101_DCN, h, w, seed=4, strict=_STRICT + ['backbone_offset_%02d' % i for i in range(30)] +
+               ['fcn_offset_layer%d_p%d' % (i, l) for i in range(3) for l in range(2, 6)], report_only=['fcn_score'])
+    _summary(rep)

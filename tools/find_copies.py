@@ -6,7 +6,7 @@ from torch.profiler import profile, ProfilerActivity
 from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
 update_config_dict(CITYSCAPES_R50)
 from upsnet_amd.synthetic import build_model, make_image
-model = build_model(cls_gain=0.3)
+model = build_model()
 data = make_image(1024, 2048, seed=0, device='cuda')
 with torch.no_grad():
     for _ in range(4): model(data)

@@ -11,7 +11,7 @@ update_config_dict(CITYSCAPES_R50)
 from upsnet_amd.synthetic import build_model, make_image
 
 data = make_image(1024, 2048, seed=0, device='cuda')
-model = build_model(cls_gain=0.3)
+model = build_model()
 with torch.no_grad():
     for _ in range(3):
         model(data)

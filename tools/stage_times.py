@@ -11,7 +11,7 @@ H, W = 1024, 2048
 data = make_image(H, W, seed=0, device='cuda')
 print("torch", torch.__version__, torch.cuda.get_device_name(0), "cpus", os.cpu_count(), "ref exists", os.path.isdir('/root/reference'), flush=True)
 # stage timing with events
-model = build_model(cls_gain=0.3)
+model = build_model()
 with torch.no_grad():
     for _ in range(3):
         model(data)

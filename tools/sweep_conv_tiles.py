@@ -15,7 +15,7 @@ def rec(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=No
     shapes[key] = shapes.get(key, 0) + 1
     return orig(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu, residuals)
 ops.conv2d_nhwc_multi = rec
-model = build_model(cls_gain=0.3)
+model = build_model()
 data = make_image(1024, 2048, seed=0, device='cuda')
 with torch.no_grad():
     model(data)

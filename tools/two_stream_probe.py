@@ -4,7 +4,7 @@ import torch
 from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
 update_config_dict(CITYSCAPES_R50)
 from upsnet_amd.synthetic import build_model, make_image
-model = build_model(cls_gain=0.3)
+model = build_model()
 imgs = [make_image(1024, 2048, seed=j, device='cuda') for j in range(2)]
 with torch.no_grad():
     for _ in range(8):

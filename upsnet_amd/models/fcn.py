@@ -70,8 +70,10 @@ class FCNSubNet(nn.Module):
             offsets = hipconv.conv_multi(layer.conv_offset, xs)
             if self.taps is not None:
                 self.taps.setdefault('offsets', []).append([o.detach().clone() for o in offsets])
-            xs = ops.deform_conv_fused(xs, offsets, self._wpack(i, dc), dc.bias, dc.in_channels, dc.out_channels,
+            ys = ops.deform_conv_fused(xs, offsets, self._wpack(i, dc), dc.bias, dc.in_channels, dc.out_channels,
                                        dc.kernel_size, dc.stride, dc.padding, dc.dilation, relu=True)
+            hipconv._trace('dcn', module=dc, xs=xs, offsets=offsets, outs=ys, relu=True, form='dcn_fused multi')
+            xs = ys
         return xs
 
 

@@ -1,20 +1,47 @@
-"""Route nn.Conv2d layers of the inference graph through the hand-written fp32 MFMA convolution
-(csrc/conv.hip) with fused bias / residual / ReLU epilogues.
+"""Route the nn.Conv2d / nn.ConvTranspose2d layers of the inference graph through the hand-written MFMA convolution kernels
+(csrc/conv1x1.hip, conv1x1_pair.hip, conv_wino.hip, conv.hip, conv_bf16.hip) with fused bias / residual / ReLU epilogues.
 
 `conv(module, x, relu=False, residual=None)` computes relu?(module(x) + residual). Weights are packed once per
-module (cached; re-packed if the parameter changes). Layers the kernel does not cover (the 7x7 stem with
-Cin=3, dilated or grouped convs) and CPU tensors go through the module itself (library convolution) followed
-by the same epilogue in torch -- same math, unfused.
+module (cached; re-packed if the parameter changes).
+
+No silent library fallback: a CUDA tensor that reaches a layer the kernels do not cover (dilated or grouped convolutions,
+Cin not a multiple of 32, ...) RAISES, unless UPSNET_ALLOW_LIBRARY_CONV=1, in which case the layer runs on the library
+convolution (MIOpen) and is recorded in FALLBACKS. CPU tensors always go through the module itself (torch-CPU convolution +
+the same epilogue in torch): that is the host execution used by oracle.forward.forward_cpu and by synthetic.calibrate_statistics,
+never a product path on a GPU box.
+
+TRACE (parity tests): set to a list and every convolution launch appends a record of its module(s), inputs, fused epilogue
+operands and output -- tests/test_layerwise_gpu.py replays each record in float64 ("per op, on identical inputs").
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
 
-import os
-
 ENABLED = True
+ALLOW_LIBRARY = os.environ.get('UPSNET_ALLOW_LIBRARY_CONV', '0') == '1'
+FALLBACKS = []   # (layer description, reason) of every CUDA-tensor call that left the hand-written path
+TRACE = None
+
+
+def _library(m, x, why):
+    """Called on the way to the module's own (library) forward."""
+    if x.is_cuda:
+        FALLBACKS.append((repr(m), why))
+        if not ALLOW_LIBRARY:
+            raise RuntimeError('upsnet_amd.hipconv: %r on a CUDA tensor %s is not covered by the hand-written kernels (%s); set '
+                               'UPSNET_ALLOW_LIBRARY_CONV=1 to run it on the library convolution' % (m, tuple(x.shape), why))
+
+
+def _trace(kind, **kw):
+    if TRACE is not None:
+        kw['kind'] = kind
+        TRACE.append(kw)
+
+
 # 3x3 / stride-1 layers with enough 2x2 output tiles to occupy half the chip go through the Winograd F(2x2,3x3) kernel
 # (csrc/conv_wino.hip; 1.2-2.2x faster there, tools/bench_winograd.py; same fp32 arithmetic class, ~1e-5 absolute difference).
 # Smaller layers stay on the direct form.
@@ -65,10 +92,12 @@ def _conv1x1_plan(m):
     return ent[1]
 
 
-def _use_conv1x1(m, x):
+def _use_conv1x1(m, x, always=False):
     if not (CONV1X1 and tuple(m.kernel_size) == (1, 1) and tuple(m.padding) == (0, 0) and m.stride[0] in (1, 2) and
             m.in_channels % 32 == 0 and m.out_channels >= 32):
         return False
+    if always:   # layers whose batch size varies at run time: the kernel (hence the summation order) must not depend on it
+        return True
     st = m.stride[0]
     pix = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
     return -(-pix // 64) * -(-m.out_channels // 64) >= CONV1X1_MIN_WG
@@ -93,7 +122,10 @@ def use_pair(m3, m1, x, residual):
 
 def conv_pair(m3, m1, x, residual):
     """(relu(conv3(x) + residual), relu(conv1(that))) -- see use_pair."""
-    return ops.conv1x1_pair(x, residual, _conv1x1_plan(m3), m3.bias, m3.out_channels, _conv1x1_plan(m1), m1.bias, m1.out_channels)
+    out1, out2 = ops.conv1x1_pair(x, residual, _conv1x1_plan(m3), m3.bias, m3.out_channels, _conv1x1_plan(m1), m1.bias, m1.out_channels)
+    _trace('conv', module=m3, x=x, out=out1, relu=True, residual=residual, residual_up=False, form='pair(conv3)')
+    _trace('conv', module=m1, x=out1, out=out2, relu=True, residual=None, residual_up=False, form='pair(conv1)')
+    return out1, out2
 
 
 def supported(m, x):
@@ -191,37 +223,46 @@ def _ksplit(m, x, ldw):
     return 1
 
 
-def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True):
+def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False):
+    """relu?(m(x) + residual) on the hand-written kernels -- see _conv for the arguments."""
+    y, form = _conv(m, x, relu, residual, residual_up, winograd, pin or winograd == 'always')
+    _trace('conv', module=m, x=x, out=y, relu=relu, residual=residual, residual_up=residual_up, form=form)
+    return y
+
+
+def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
-    winograd=False / 'always' pins the direct / the Winograd form (layers whose batch size varies at run time: the choice,
-    hence the rounding, must not depend on it)."""
+    winograd=False / 'always' pins the direct / the Winograd form; pin=True (implied by 'always') makes every kernel choice
+    (bf16 or fp32, lean 1x1 GEMM or general kernel) independent of the batch size, for layers fed by ROI batches whose size
+    varies at run time: the logits of a ROI must not depend on how many other ROIs share the launch."""
     if supported(m, x):
-        if (not residual_up or tuple(m.kernel_size) == (1, 1)) and _use_bf16(m, [x], always=(winograd == 'always')):
+        if (not residual_up or tuple(m.kernel_size) == (1, 1)) and _use_bf16(m, [x], always=pin):
             hi, lo, ldw = _bf16_plan(m)
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual],
-                                              residual_up=residual_up)[0]
+                                              residual_up=residual_up)[0], PRECISION
         if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
             ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])
             if ks > 1:
-                return ops.conv2d_winograd_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu, residual=residual)
+                return ops.conv2d_winograd_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu, residual=residual), 'winograd splitk%d' % ks
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
-                                             residuals=None if residual is None else [residual])[0]
-        if _use_conv1x1(m, x):
+                                             residuals=None if residual is None else [residual])[0], 'winograd tm%d' % _wino_tm(m, [x])
+        if _use_conv1x1(m, x, always=pin):
             return ops.conv1x1_frag(x, _conv1x1_plan(m), m.bias, m.out_channels, m.stride[0], relu=relu, residual=residual,
-                                    residual_up=residual_up)
+                                    residual_up=residual_up), 'conv1x1'
         wp, ldw = _plan(m)
-        ks = 1 if residual_up else _ksplit(m, x, ldw)
+        ks = 1 if (residual_up or pin) else _ksplit(m, x, ldw)
         if ks > 1:
             return ops.conv2d_nhwc_splitk(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], ks,
-                                          relu=relu, residual=residual)
+                                          relu=relu, residual=residual), 'igemm splitk%d' % ks
         return ops.conv2d_nhwc(x, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
-                               relu=relu, residual=residual, residual_up=residual_up)
+                               relu=relu, residual=residual, residual_up=residual_up), 'igemm'
+    _library(m, x, 'hipconv.supported() is false')
     y = m(x)
     if residual is not None:
         y = y + (F.interpolate(residual, scale_factor=2, mode='nearest') if residual_up else residual)
-    return F.relu(y, inplace=True) if relu else y
+    return (F.relu(y, inplace=True) if relu else y), 'library'
 
 
 def conv_multi(m, xs, relu=False):
@@ -230,12 +271,16 @@ def conv_multi(m, xs, relu=False):
     if len(xs) <= 5 and all(supported(m, x) for x in xs):
         if _use_bf16(m, xs):
             hi, lo, ldw = _bf16_plan(m)
-            return ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu)
-        if _use_winograd(m, xs):
+            ys, form = ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu), PRECISION
+        elif _use_winograd(m, xs):
             wp, ldw = _winograd_plan(m)
-            return ops.conv2d_winograd_multi(xs, wp, ldw, m.bias, m.out_channels, relu=relu)
-        wp, ldw = _plan(m)
-        return ops.conv2d_nhwc_multi(xs, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu)
+            ys, form = ops.conv2d_winograd_multi(xs, wp, ldw, m.bias, m.out_channels, relu=relu), 'winograd tm%d multi' % _wino_tm(m, xs)
+        else:
+            wp, ldw = _plan(m)
+            ys, form = ops.conv2d_nhwc_multi(xs, wp, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu), 'igemm multi'
+        for x, y in zip(xs, ys):
+            _trace('conv', module=m, x=x, out=y, relu=relu, residual=None, residual_up=False, form=form)
+        return ys
     return [conv(m, x, relu=relu) for x in xs]
 
 
@@ -248,6 +293,7 @@ def stem_supported(m, x):
 def conv_stem(m, x, relu=False):
     """The 7x7/2 stem (Cin = 3) on the MFMA kernel: x is the fp32 NCHW blob or already a [N,4,H,W] channels_last image."""
     if not stem_supported(m, x):
+        _library(m, x, 'hipconv.stem_supported() is false')
         y = m(x[:, :m.in_channels] if x.shape[1] != m.in_channels else x)
         return F.relu(y, inplace=True) if relu else y
     w = m.weight
@@ -258,7 +304,9 @@ def conv_stem(m, x, relu=False):
         _plans(m)['stem'] = ent
     is_nhwc4 = x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last)
     x4 = x if is_nhwc4 else ops.image_to_nhwc4(x)
-    return ops.conv2d_stem(x4, ent[1], ent[2], m.bias, m.out_channels, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0], relu=relu)
+    y = ops.conv2d_stem(x4, ent[1], ent[2], m.bias, m.out_channels, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0], relu=relu)
+    _trace('conv', module=m, x=x4[:, :m.in_channels], out=y, relu=relu, residual=None, residual_up=False, form='stem')
+    return y
 
 
 def deconv2x2(m, x, relu=False):
@@ -267,6 +315,7 @@ def deconv2x2(m, x, relu=False):
           tuple(m.stride) == (2, 2) and tuple(m.padding) == (0, 0) and tuple(m.output_padding) == (0, 0) and m.groups == 1 and
           tuple(m.dilation) == (1, 1) and m.in_channels % 32 == 0)
     if not ok:
+        _library(m, x, 'not a 2x2 / stride-2 transposed convolution with Cin % 32 == 0')
         y = m(x)
         return F.relu(y, inplace=True) if relu else y
     w = m.weight
@@ -275,7 +324,9 @@ def deconv2x2(m, x, relu=False):
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_deconv2x2_weight(w.detach())
         _plans(m)['deconv'] = ent
-    return ops.deconv2x2(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
+    y = ops.deconv2x2(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
+    _trace('deconv', module=m, x=x, out=y, relu=relu, form='deconv2x2')
+    return y
 
 
 def clear_cache(model=None):
@@ -311,8 +362,10 @@ def conv_multi_cat(ms, xs, return_flat=False):
     _, wp, ldw, b = ent
     outs = ops.conv2d_nhwc_multi(xs, wp, ldw, b, sum(couts), m0.kernel_size[0], m0.stride[0], m0.padding[0], relu=False)
     res, c0 = [], 0
-    for c in couts:
+    for m, c in zip(ms, couts):
         res.append([o[:, c0:c0 + c] for o in outs])
+        for x, y in zip(xs, res[-1]):
+            _trace('conv', module=m, x=x, out=y, relu=False, residual=None, residual_up=False, form='igemm multi cat')
         c0 += c
     if return_flat:
         return res, getattr(outs[0], '_ups_flat', None), outs

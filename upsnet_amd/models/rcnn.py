@@ -41,7 +41,7 @@ class MaskBranch(nn.Module):
             # depend on how many other ROIs share the launch (the fused pipeline's single pass == the reference's two passes,
             # bit for bit) -- every 2x2 output tile is computed independently of the others, in a fixed K order
             x = hipconv.conv(blk[0], x, relu=True, winograd='always')
-        return hipconv.conv(self.mask_score, hipconv.deconv2x2(self.mask_deconv1[0], x, relu=True))
+        return hipconv.conv(self.mask_score, hipconv.deconv2x2(self.mask_deconv1[0], x, relu=True), pin=True)
 
 
 class RCNN(nn.Module):

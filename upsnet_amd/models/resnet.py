@@ -9,7 +9,7 @@ the res3..res5 blocks. Parameter names are the reference's (`resnet_backbone.res
 How it is built here is table-driven: one block class covers both bottleneck kinds, and because
 every BN is frozen the whole backbone can be re-parameterised for inference (`fold_frozen_bn`): the BN
 affine is folded into the preceding convolution, removing one read+write of every activation.
-Dense convolutions run on PyTorch-ROCm/MIOpen this round (BASELINE.json configs[1]).
+Every convolution runs on the hand-written MFMA kernels (models/hipconv.py); only the 3x3/2 max-pool is a library op.
 """
 import warnings
 
@@ -70,7 +70,9 @@ class _Block(nn.Module):
         launch that never reads the block output back (hipconv.use_pair, csrc/conv1x1_pair.hip; bit-identical results)."""
         y = hipconv.conv(self.conv1, x, relu=True) if y1 is None else y1
         if self.deformable:
-            y = torch.relu_(self.conv2(y, hipconv.conv(self.conv2_offset, y)))
+            off = hipconv.conv(self.conv2_offset, y)
+            y, y_in = torch.relu_(self.conv2(y, off)), y
+            hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, form='dcn_fused')
         else:
             y = hipconv.conv(self.conv2, y, relu=True)
         shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x)

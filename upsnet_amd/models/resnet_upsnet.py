@@ -190,7 +190,7 @@ class resnet_upsnet(resnet_rcnn):
         copy, so the caller can launch image i+1 before reading image i (graph_slots >= 2): the host work between two images
         (result read-back, Python, the next launch) then overlaps with the device. Elsewhere it simply runs forward()."""
         x = data['data']
-        if (self.pipeline == 'fused' and self.use_graph and self.graph_slots >= 2 and self.taps is None and not ops.PROFILE['enabled']
+        if (self.pipeline == 'fused' and self.use_graph and self.graph_slots >= 2 and self.taps is None and hipconv.TRACE is None and not ops.PROFILE['enabled']
                 and x.is_cuda and not torch.is_grad_enabled()):
             ent = self._phase1_graphed(x, data['im_info'], wait=False)
             if ent is not None and ent['host'] is not None:
@@ -295,7 +295,7 @@ class resnet_upsnet(resnet_rcnn):
         key = (tuple(x.shape), x.dtype, x.is_contiguous(), tuple(float(v) for v in np.asarray(im_info_host).reshape(-1)))
         slots = self._graphs.get(key)
         if slots is None:
-            slots = self._graphs[key] = {'next': 0, 'slots': [{'seen': 0} for _ in range(self.graph_slots)]}
+            slots = self._graphs[key] = {'next': 0, 'slots': [{'seen': 0, 'idx': i} for i in range(self.graph_slots)]}
         ent = slots['slots'][slots['next']]
         slots['next'] = (slots['next'] + 1) % len(slots['slots'])
         if 'graph' not in ent:
@@ -311,7 +311,7 @@ class resnet_upsnet(resnet_rcnn):
                 # one stream per instance NUMBER, shared by every model / input shape of the process: a stream is bound to one of the
                 # few hardware queues when it is created, and a second model with fresh streams can land both of its instances on
                 # one queue (bench.py's configs[2] leg: 161 instead of 188 img/s before this)
-                sk_key = (x.device.index, slots['slots'].index(ent))
+                sk_key = (x.device.index, ent['idx'])
                 if sk_key not in _SLOT_STREAMS:
                     _SLOT_STREAMS[sk_key] = torch.cuda.Stream(device=x.device)
                 sk = _SLOT_STREAMS[sk_key]
@@ -354,7 +354,7 @@ class resnet_upsnet(resnet_rcnn):
     def _forward_fused(self, data, st=None, counters=None, try_graph=True):
         """st: the state of an already launched graph replay (forward_async); counters: its four counters, already on the host."""
         x, im_info = data['data'], data['im_info']
-        if st is None and try_graph and self.use_graph and self.taps is None and not ops.PROFILE['enabled'] and x.is_cuda:
+        if st is None and try_graph and self.use_graph and self.taps is None and hipconv.TRACE is None and not ops.PROFILE['enabled'] and x.is_cuda:
             ent = self._phase1_graphed(x, im_info)
             st = None if ent is None else ent['out']
         graphed = st is not None

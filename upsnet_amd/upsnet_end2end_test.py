@@ -24,10 +24,10 @@ from .utils.timer import Timer
 
 WORKLOADS = {
     # name: (config preset, unpadded H, W, cls_gain)
-    'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 0.3),
-    'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 0.3),
+    'upsnet50_cityscapes_1024x2048': (CITYSCAPES_R50, 1024, 2048, 'default'),
+    'upsnet101dcn_coco_800x1333': (COCO_R101_DCN, 800, 1333, 'default'),
     # BASELINE.json configs[4]: alternating Cityscapes-shaped / COCO-shaped images through one UPSNet-101-DCN
-    'upsnet101dcn_mixed_1024x2048_800x1333': (COCO_R101_DCN, (1024, 800), (2048, 1333), 0.3),
+    'upsnet101dcn_mixed_1024x2048_800x1333': (COCO_R101_DCN, (1024, 800), (2048, 1333), 'default'),
 }
 
 
