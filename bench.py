@@ -55,7 +55,10 @@ def ensure_ranks(args):
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        env.setdefault('OMP_NUM_THREADS', '8')
+        # host threads per rank: its share of the visible CPUs (each rank also pins itself to that slice,
+        # upsnet_end2end_test.pin_rank), at most 16 -- the ranks' host work is one Python launch loop + the RCCL proxy
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, ncpu // n))))
         sys.stdout.flush()
         os.execvpe(cmd[0], cmd, env)
 
@@ -78,6 +81,9 @@ def main():
     ap.add_argument('--post', action='store_true', help='also run get_unified_pan_result on the device inside every step')
     ap.add_argument('--no-configs2', action='store_true',
                     help='skip the short second leg (same workload with --conv-precision bf16 = BASELINE.json configs[2], reported as "configs2")')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='pre-flight of an N-rank run without timing: devices, ports, model build, graph capture on every instance of every '
+                         'rank (checked against the eager forward), communicator warm-up, per-rank device memory; prints one JSON line')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048: 1 warm-up + 3 timed passes, ~35 s)')
     args = ap.parse_args()
@@ -87,6 +93,14 @@ def main():
     from upsnet_amd.models import hipconv
     from upsnet_amd.upsnet_end2end_test import upsnet_test
     hipconv.PRECISION = args.conv_precision
+    if args.dry_run:
+        from upsnet_amd.upsnet_end2end_test import preflight
+        rep = preflight(args.workload, in_flight=args.in_flight)
+        if rep is not None:
+            print(json.dumps(rep), flush=True)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        sys.exit(0 if (rep is None or rep['all_ok']) else 1)
 
     # kernel events are recorded on ONE timed image (the first): that image runs eagerly and without stream overlap -- two events
     # per launch, ~190 dispatches instead of one graph replay -- so it is ~2 ms slower than the others and every sampled image

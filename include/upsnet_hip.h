@@ -32,6 +32,11 @@ const char *upsnet_last_error(void);
 /* Library ABI version (bumped on any signature change). */
 int upsnet_abi_version(void);
 
+/* Zero `bytes` bytes at `ptr` (any alignment) with a plain kernel on `stream`. The scratch of the selection ops is cleared this way
+ * instead of hipMemsetAsync (a replacement for the reference's THCudaTensor zero_() / cudaMemset of its scratch, e.g.
+ * upsnet/nms/nms_kernel.cu:112-113): a captured forward then holds kernel nodes only (memset nodes fault at graph replay). */
+int upsnet_zero_fill(void *stream, void *ptr, size_t bytes);
+
 /* ============================== ROIAlign ============================== */
 
 /* Replaces roi_align_forward_gpu_kernel_launcher (upsnet/operators/src/roi_align_cuda.cpp:26-30,

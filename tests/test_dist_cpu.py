@@ -69,3 +69,27 @@ def test_bench_refuses_to_misreport_gpu_count():
     env['WORLD_SIZE'] = '4'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
+
+
+def test_rank_cpu_slices_partition_the_host():
+    """8 ranks on a 256-thread host: disjoint contiguous slices of 32 CPUs, every CPU used once; fewer CPUs than ranks wrap around."""
+    from upsnet_amd.upsnet_end2end_test import rank_cpu_slice
+    cpus = list(range(256))
+    slices = [rank_cpu_slice(r, 8, cpus) for r in range(8)]
+    assert all(len(s) == 32 for s in slices) and sorted(sum(slices, [])) == cpus
+    assert slices[3] == list(range(96, 128))
+    assert rank_cpu_slice(5, 8, [0, 1, 2, 3]) in ([0], [1], [2], [3])
+    assert rank_cpu_slice(0, 1, cpus) == cpus
+
+
+def test_records_are_void_padded_and_single_rank_collective_flag():
+    """the record outside a smaller label map is 255 (void), not class 0; gather_results(collective=False) is the
+    local pack / unpack."""
+    from upsnet_amd.upsnet_end2end_test import gather_results, pack_records, unpack_records
+    lab = torch.full((4, 6), 3, dtype=torch.uint8)
+    rec = pack_records([(7, lab, 2)], 5, 8, torch.device('cpu'))
+    out = unpack_records(rec, 5, 8)
+    m, n = out[7]
+    assert n == 2 and torch.equal(m[:4, :6], lab) and int(m[4:].min()) == 255 and int(m[:, 6:].min()) == 255
+    got = gather_results([(1, lab, 0)], 1, torch.device('cpu'), 4, 6)
+    assert sorted(got) == [1] and torch.equal(got[1][0], lab)

@@ -1,0 +1,86 @@
+"""CPU: the reference's IMPORT TREE is served by this repo (SURVEY 8b "what calls it").
+
+The import lines below are the reference's own, verbatim, restricted to the names of the inference path (training-only names --
+RPNLoss, RCNNLoss, MaskRCNNLoss, ProposalMaskTarget, MaskMatching, MaskTerm, get_params -- and the dataset classes are out of scope,
+SURVEY section 2): upsnet/upsnet_end2end_test.py:34-47, models/resnet_upsnet.py:22-32, models/rcnn.py:23-26, models/fcn.py:22-23,
+models/resnet.py:21, operators/functions/pyramid_proposal.py:18-20, operators/modules/mask_roi.py:20-22. Then the model is built
+the way upsnet_end2end_test.py:162 builds it, and DataParallel is called the way :203,:240 call it."""
+import numpy as np
+import torch
+
+REFERENCE_IMPORT_LINES = """
+from upsnet.config.config import config
+from upsnet.config.parse_args import parse_args
+from lib.utils.timer import Timer
+from upsnet.models import *
+from upsnet.bbox.bbox_transform import bbox_transform, clip_boxes, expand_boxes
+from lib.utils.data_parallel import DataParallel
+from upsnet.models.resnet import resnet_rcnn, ResNetBackbone
+from upsnet.models.fpn import FPN
+from upsnet.models.rpn import RPN
+from upsnet.models.rcnn import RCNN, MaskBranch
+from upsnet.models.fcn import FCNHead
+from upsnet.operators.modules.pyramid_proposal import PyramidProposal
+from upsnet.operators.modules.mask_roi import MaskROI
+from upsnet.operators.modules.unary_logits import SegTerm
+from upsnet.operators.modules.mask_removal import MaskRemoval
+from upsnet.operators.modules.fpn_roi_align import FPNRoIAlign
+from upsnet.operators.modules.roialign import RoIAlign
+from upsnet.operators.functions.roialign import RoIAlignFunction
+from upsnet.operators.modules.view import View
+from upsnet.operators.modules.deform_conv import DeformConv, DeformConvWithOffset
+from upsnet.operators.modules.mod_deform_conv import ModDeformConv, ModDeformConvWithOffsetMask
+from upsnet.operators.functions.deform_conv import DeformConvFunction
+from upsnet.operators.functions.mod_deform_conv import ModDeformConvFunction
+from upsnet.nms.nms import py_nms_wrapper, cpu_nms_wrapper, gpu_nms_wrapper
+from upsnet.rpn.generate_anchors import generate_anchors
+from upsnet.bbox.bbox_transform import bbox_transform as bbox_pred, clip_boxes, bbox_overlaps
+"""
+
+
+def test_reference_import_lines_resolve_to_this_implementation():
+    ns = {}
+    exec(REFERENCE_IMPORT_LINES, ns)
+    import upsnet_amd.config.config as real_cfg
+    import upsnet_amd.operators.modules.deform_conv as real_dc
+    import upsnet.operators.modules.deform_conv as alias_dc
+    assert ns['config'] is real_cfg.config                       # ONE config singleton under both spellings
+    assert alias_dc is real_dc and ns['DeformConv'] is real_dc.DeformConv
+    import lib.utils.timer
+    import upsnet_amd.utils.timer
+    assert lib.utils.timer is upsnet_amd.utils.timer
+    # build the model the way upsnet_end2end_test.py:162 does (config.symbol names a constructor exported by upsnet.models)
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    config = ns['config']
+    resnet_50_upsnet, resnet_101_upsnet = ns['resnet_50_upsnet'], ns['resnet_101_upsnet']   # noqa: F841  (eval below)
+    model = eval(config.symbol)()
+    assert isinstance(model, ns['resnet_rcnn']) and isinstance(model.rcnn, ns['RCNN']) and isinstance(model.fcn_head, ns['FCNHead'])
+    keys = set(model.state_dict())
+    for k in ('resnet_backbone.conv1.conv1.weight', 'resnet_backbone.res2.layers.0.bn3.running_var', 'fpn.fpn_p2_1x1.weight',
+              'rpn.conv_proposal.0.weight', 'rcnn.fc6.0.weight', 'mask_branch.mask_deconv1.0.weight',
+              'fcn_head.fcn_subnet.conv.0.0.conv_offset.weight', 'fcn_head.fcn_subnet.conv.1.0.conv.weight', 'fcn_head.score.bias'):
+        assert k in keys, k                                     # the reference's state-dict keys (checkpoints load unchanged)
+
+
+def test_data_parallel_keeps_the_reference_call_convention_on_cpu():
+    """lib/utils/data_parallel.py:78-116: without CUDA the wrapper is transparent; the constructor signature is the reference's."""
+    from lib.utils.data_parallel import DataParallel
+
+    class Net(torch.nn.Module):
+        def forward(self, data, label=None):
+            return {'y': data['x'] * 2}
+    dp = DataParallel(Net(), device_ids=[0], gather_output=False)
+    if not torch.cuda.is_available():
+        assert dp.device_ids == []
+        out = dp({'x': torch.ones(2)}, None)
+        assert torch.equal(out['y'], torch.full((2,), 2.0))
+
+
+def test_host_box_helpers_match_their_definitions():
+    from upsnet.bbox.bbox_transform import expand_boxes, bbox_overlaps
+    b = np.array([[10., 20., 30., 60.], [0., 0., 9., 9.]])
+    e = expand_boxes(b, 30.0 / 28.0)
+    assert e.dtype == np.float64 and np.allclose(e[0], [20 - 10 * 30 / 28, 40 - 20 * 30 / 28, 20 + 10 * 30 / 28, 40 + 20 * 30 / 28])
+    ov = bbox_overlaps(b, b[1:])
+    assert ov.shape == (2, 1) and ov[1, 0] == 1.0 and ov[0, 0] == 0.0

@@ -1,0 +1,113 @@
+"""GPU: the convolutions of a C1 and a C2 forward are ALL hand-written kernels.
+
+Three independent checks on one eager forward per configuration:
+  1. a TorchDispatchMode sees every ATen operator the forward executes: no `convolution` / `miopen_*` / `conv_transpose` operator
+     may appear (the hand-written kernels are ctypes calls into libupsnet_hip.so and never pass through ATen); the only matrix
+     products allowed are the FC layers (`addmm` / `mm`: hipBLASLt, plumbing per DESIGN 1);
+  2. `hipconv.FALLBACKS` stays empty (and an uncovered layer RAISES instead of running on the library);
+  3. best effort, when the profiler can trace device activity on this box: no kernel whose name looks like a library convolution
+     (MIOpen / CK / im2col / naive_conv), and no more Tensile GEMMs (`Cijk_*`) than there are nn.Linear calls.
+Reference graph: upsnet/models/resnet_upsnet.py:197-248."""
+import pytest
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+pytestmark = pytest.mark.gpu
+
+
+class _OpLog(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.ops = {}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        self.ops[name] = self.ops.get(name, 0) + 1
+        return func(*args, **(kwargs or {}))
+
+
+_LIB_CONV_KERNELS = ('miopen', 'MIOpen', 'im2col', 'Im2Col', 'naive_conv', 'gridwise_convolution', 'igemm_fwd', 'ConvBin', 'conv_fwd',
+                     'implicit_gemm', 'ck::', 'ck_tile', 'Winograd', 'sp3AsmConv', 'gcnAsmConv')
+
+
+@pytest.mark.parametrize("which", ["c1", "c2"])
+def test_forward_contains_no_library_convolution(which):
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50, COCO_R101_DCN
+    from upsnet_amd.models import hipconv
+    update_config_dict(CITYSCAPES_R50 if which == 'c1' else COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model()
+        h, w = (512, 1024) if which == 'c1' else (400, 667)
+        data = make_image(h, w, seed=5, device='cuda')
+        model.use_graph = False
+        n0 = len(hipconv.FALLBACKS)
+        with torch.no_grad():
+            model(data)                     # packs weights etc.
+            log = _OpLog()
+            with log:
+                out = model(data)
+        torch.cuda.synchronize()
+        assert out['panoptic_outputs'].shape[-2:] == (data['data'].shape[2], data['data'].shape[3])
+        conv_ops = {k: v for k, v in log.ops.items() if 'conv' in k.lower() or 'miopen' in k.lower() or 'cudnn' in k.lower()}
+        assert not conv_ops, conv_ops
+        gemms = sum(v for k, v in log.ops.items() if k.split('.')[1] in ('addmm', 'mm', 'linear', 'matmul', 'bmm'))
+        n_linear = 4 + (1 if hasattr(model.fpn, 'fpn_gap') else 0)     # fc6, fc7, cls_score, bbox_pred (+ the GAP branch of C2)
+        assert gemms == n_linear, (gemms, {k: v for k, v in log.ops.items() if 'mm' in k})
+        assert len(hipconv.FALLBACKS) == n0, hipconv.FALLBACKS[n0:]
+        # 3. device-side kernel names (best effort)
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                with torch.no_grad():
+                    model(data)
+                torch.cuda.synchronize()
+            names = [e.name for e in prof.events() if str(getattr(e, 'device_type', '')).endswith('CUDA')]
+        except Exception as e:     # profiler not usable on this box: checks 1 and 2 stand
+            names = []
+            print('device trace unavailable:', e)
+        if names:
+            lib = [n for n in names if any(p in n for p in _LIB_CONV_KERNELS)]
+            assert not lib, sorted(set(lib))
+            assert sum(n.startswith('Cijk_') for n in names) <= n_linear, sorted(set(n for n in names if n.startswith('Cijk_')))
+            assert any('conv_wino16' in n for n in names) and any('conv1x1_frag' in n for n in names), sorted(set(names))[:40]
+            print(len(names), 'device kernels traced;', len(set(names)), 'distinct')
+    finally:
+        update_config_dict(CITYSCAPES_R50)
+
+
+def test_uncovered_layer_raises_instead_of_running_on_the_library():
+    from upsnet_amd.models import hipconv
+    m = torch.nn.Conv2d(32, 32, 3, padding=2, dilation=2).cuda()      # dilated: not covered by the hand-written kernels
+    x = torch.randn(1, 32, 16, 16, device='cuda')
+    n0 = len(hipconv.FALLBACKS)
+    with pytest.raises(RuntimeError, match='not covered by the hand-written kernels'):
+        hipconv.conv(m, x)
+    assert len(hipconv.FALLBACKS) == n0 + 1
+    saved, hipconv.ALLOW_LIBRARY = hipconv.ALLOW_LIBRARY, True
+    try:
+        y = hipconv.conv(m, x, relu=True)
+    finally:
+        hipconv.ALLOW_LIBRARY = saved
+        del hipconv.FALLBACKS[n0:]
+    assert torch.allclose(y, torch.relu(m(x)))
+
+
+def test_data_parallel_drop_in_single_gpu():
+    """upsnet_end2end_test.py:203,240: DataParallel(model, device_ids=gpus, gather_output=False).to(gpus[0]); model(*batch) with one
+    (data, None) tuple per GPU; with one GPU the result is the module's own dict (lib/utils/data_parallel.py:107-108)."""
+    from lib.utils.data_parallel import DataParallel
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.synthetic import build_model, make_image
+    model = build_model()
+    data = make_image(256, 512, seed=2, device='cuda')
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in model(data).items()}
+        dp = DataParallel(model, device_ids=[0], gather_output=False).to(0)
+        dp.eval()
+        batch = [(data, None)]
+        got = dp(*batch)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k

@@ -219,6 +219,39 @@ def test_deform_conv_function_and_module(U):
         m.cpu()(torch.randn(1, 8, 4, 4))
 
 
+def test_deform_conv_module_with_non_square_padding(U):
+    """DeformConv(..., padding=(a, b)) with a != b must keep working -- the second-generation fused kernels take square
+    geometry only, so such a layer is packed for (and runs on) the first-generation kernel, which takes both axes."""
+    from upsnet_amd.operators.modules.deform_conv import DeformConv
+    torch.manual_seed(1)
+    m = DeformConv(32, 48, 3, stride=1, padding=(1, 2), dilation=1, bias=True).cuda()
+    x = torch.randn(1, 32, 12, 15, device='cuda')
+    Ho, Wo = 12, 17
+    off = torch.randn(1, 18, Ho, Wo, device='cuda') * 1.5
+    with torch.no_grad():
+        y = m(x, off)
+    assert y.shape == (1, 48, Ho, Wo)
+    col = oracle.deform_im2col(x[0].cpu().numpy(), off[0].cpu().numpy(), (3, 3), (1, 2), (1, 1), (1, 1), 1)
+    w = m.weight.detach().cpu().numpy().astype(np.float64).reshape(48, -1)
+    ref = (w @ col.reshape(col.shape[0], -1).astype(np.float64)).reshape(48, Ho, Wo) + m.bias.detach().cpu().numpy()[:, None, None]
+    np.testing.assert_allclose(y[0].cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    assert U.pack_dcn_weight(m.weight.detach(), square=False)[0] not in ('frag', 'frag_bf16')
+
+
+def test_zero_fill_kernel_handles_any_address_and_size():
+    """ups_zero_async never falls back to a memset node -- unaligned head / tail bytes are written by the same kernel."""
+    import ctypes
+    from upsnet_amd._lib import lib, stream
+    if not hasattr(lib(), 'upsnet_zero_fill'):
+        pytest.skip('no test entry point')
+    buf = torch.full((4096,), 0xAB, dtype=torch.uint8, device='cuda')
+    for start, n in [(0, 0), (1, 1), (3, 2), (1, 7), (2, 1021), (5, 3), (0, 4096), (7, 4000)]:
+        buf.fill_(0xAB)
+        assert lib().upsnet_zero_fill(stream(), ctypes.c_void_p(buf.data_ptr() + start), ctypes.c_size_t(n)) == 0
+        host = buf.cpu().numpy()
+        assert (host[start:start + n] == 0).all() and (host[:start] == 0xAB).all() and (host[start + n:] == 0xAB).all(), (start, n)
+
+
 # ------------------------------------------------------------------ NMS
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 1500])
 @pytest.mark.parametrize("thresh", [0.5, 0.7])

@@ -17,6 +17,7 @@ P = c_void_p
 _SIGNATURES = {
     "upsnet_last_error": (ctypes.c_char_p, []),
     "upsnet_abi_version": (c_int, []),
+    "upsnet_zero_fill": (c_int, [P, P, c_size_t]),
     "upsnet_roi_align_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_roi_align_forward_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_fpn_roi_align_forward": (c_int, [P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P]),

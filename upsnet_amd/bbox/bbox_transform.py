@@ -35,3 +35,26 @@ def clip_boxes(boxes, im_shape):
     boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], im_shape[1] - 1), 0)
     boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], im_shape[0] - 1), 0)
     return boxes
+
+
+def expand_boxes(boxes, scale):
+    """Boxes [n,4] grown about their centres by `scale` (bbox_transform.py:365-381; float64 result like the reference's np.zeros)."""
+    half = np.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1) * .5
+    ctr = np.stack([boxes[:, 2] + boxes[:, 0], boxes[:, 3] + boxes[:, 1]], 1) * .5
+    half = half * scale
+    out = np.zeros(boxes.shape)
+    out[:, 0:2] = ctr - half
+    out[:, 2:4] = ctr + half
+    return out
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """IoU matrix [n,k] with the +1 pixel convention (bbox_transform.py:24-42 / bbox.pyx); host helper, not on the inference path."""
+    b = np.asarray(boxes, dtype=np.float64)
+    q = np.asarray(query_boxes, dtype=np.float64)
+    iw = np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0]) + 1
+    ih = np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1]) + 1
+    inter = np.clip(iw, 0, None) * np.clip(ih, 0, None)
+    area_b = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    area_q = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)
+    return inter / (area_b[:, None] + area_q[None, :] - inter)

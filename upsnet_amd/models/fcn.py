@@ -53,9 +53,10 @@ class FCNSubNet(nn.Module):
         return x
 
     def _wpack(self, i, dc):
-        key = (dc.weight.data_ptr(), dc.weight._version, ops.dcn_precision())
+        sq = ops.dcn_square(dc.padding, dc.stride, dc.dilation)
+        key = (dc.weight.data_ptr(), dc.weight._version, ops.dcn_precision(), sq)
         if i not in self._packed or self._packed[i][0] != key:
-            self._packed[i] = (key, ops.pack_dcn_weight(dc.weight.detach()))
+            self._packed[i] = (key, ops.pack_dcn_weight(dc.weight.detach(), square=sq))
         return self._packed[i][1]
 
     def forward_levels(self, feats):

@@ -182,11 +182,18 @@ def dcn_precision():
     return 'bf16' if hipconv.PRECISION == 'bf16' and os.environ.get('UPSNET_DCN_BF16', '1') != '0' else 'fp32'
 
 
-def pack_dcn_weight(weight, kind=None):
+def dcn_square(pad, stride, dil):
+    """The second-generation fused kernels take one pad / stride / dilation for both axes."""
+    return pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]
+
+
+def pack_dcn_weight(weight, kind=None, square=True):
     """[Cout,Cin,kh,kw] -> packed weight for deform_conv_fused: ('frag', wp) in MFMA fragment order for csrc/deform_fused.hip
     (('frag_bf16', wp) for csrc/deform_fused_bf16.hip: kind 'frag_bf16', or 'frag' while dcn_precision() is 'bf16'), or
     (wpack [kh*kw*Cin, ldw], ldw) -- the dense convolution's packing -- for the first-generation kernel."""
     kind = kind or DCN_KERNEL
+    if not square:   # padding=(a, b) with a != b etc.: the first-generation kernel (csrc/conv.hip loader mode) covers it
+        kind = 'igemm'
     cout, cin, kh, kw = weight.shape
     if kind == 'frag' and dcn_precision() == 'bf16':
         kind = 'frag_bf16'
@@ -203,12 +210,12 @@ def pack_dcn_weight(weight, kind=None):
     return pack_conv_weight(weight)
 
 
-def cached_dcn_pack(weight):
+def cached_dcn_pack(weight, square=True):
     """Packed deformable-convolution weight cached ON the weight tensor (re-packed when it changes or moves)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL, dcn_precision())
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL, dcn_precision(), bool(square))
     ent = weight.__dict__.get('_ups_dcn_pack')
     if ent is None or ent[0] != key:
-        ent = (key, pack_dcn_weight(weight.detach()))
+        ent = (key, pack_dcn_weight(weight.detach(), square=square))
         weight.__dict__['_ups_dcn_pack'] = ent
     return ent[1]
 
@@ -605,12 +612,16 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
         shapes.append((N, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, cout))
     # the outputs of a multi-map launch are carved from ONE allocation (outs[0]._ups_flat), so that a following elementwise op over
     # all maps (the RPN's sigmoid over 5 levels) is one launch over the flat buffer instead of one per map
+    # (every map starts on a 256-byte boundary of the flat buffer, whatever its channel count: 15-channel RPN heads, 18 / 27-channel
+    # offset maps -- a later 16-byte-per-lane consumer must not see a 4-byte-aligned base)
     sizes = [n * h * w * c for n, h, w, c in shapes]
-    flat = torch.empty((sum(sizes),), dtype=torch.float32, device=xs[0].device)
-    off = 0
-    for (n, h, w, c), sz in zip(shapes, sizes):
-        outs.append(flat[off:off + sz].view(n, h, w, c).permute(0, 3, 1, 2))
-        off += sz
+    starts, off = [], 0
+    for sz in sizes:
+        starts.append(off)
+        off += (sz + 63) // 64 * 64
+    flat = torch.empty((off,), dtype=torch.float32, device=xs[0].device)
+    for (n, h, w, c), sz, st in zip(shapes, sizes, starts):
+        outs.append(flat[st:st + sz].view(n, h, w, c).permute(0, 3, 1, 2))
     outs[0]._ups_flat = flat
     if residuals is not None:
         ress = [nhwc(r.float()) for r in residuals]

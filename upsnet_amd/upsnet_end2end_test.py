@@ -31,11 +31,36 @@ WORKLOADS = {
 }
 
 
+def rank_cpu_slice(local_rank, local_world, cpus=None):
+    """The host CPUs of one rank: the visible CPUs (sched_getaffinity, sorted) cut into local_world contiguous slices. On a
+    256-thread host with 8 ranks that is 32 hardware threads per rank, contiguous ids = one NUMA domain / CCD group per rank on the
+    usual enumeration, so the 8 Python launch loops and their RCCL proxy threads do not migrate across sockets
+    (lib/utils/data_parallel.py:103-116 runs all replicas on GIL-bound threads of ONE process instead)."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    per = max(1, len(cpus) // max(1, local_world))
+    lo = (local_rank % max(1, len(cpus) // per)) * per
+    return cpus[lo:lo + per]
+
+
+def pin_rank(local_rank, local_world):
+    """Pin this process to its CPU slice and size the host thread pools to it (no-op for a single rank, or with UPSNET_PIN=0)."""
+    if local_world <= 1 or os.environ.get('UPSNET_PIN', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    mine = rank_cpu_slice(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(len(mine), int(os.environ.get('OMP_NUM_THREADS', len(mine))))))
+    return mine
+
+
 def init_distributed():
     """torchrun environment -> (rank, world, device). Backend nccl == RCCL on ROCm; gloo for CPU tests."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         ndev = torch.cuda.device_count()
@@ -65,8 +90,10 @@ _REC_HDR = 16   # bytes in front of every label map: image id, instance count (2
 
 
 def pack_records(local, H, W, device):
-    """[(image_id, label_map uint8 [h<=H, w<=W], n_inst)] -> one uint8 tensor [n, 16 + H*W] (header + row-major label map)."""
-    rec = torch.zeros((len(local), _REC_HDR + H * W), dtype=torch.uint8, device=device)
+    """[(image_id, label_map uint8 [h<=H, w<=W], n_inst)] -> one uint8 tensor [n, 16 + H*W] (header + row-major label map; the
+    record outside a smaller label map is 255 = void, never class 0)."""
+    rec = torch.full((len(local), _REC_HDR + H * W), 255, dtype=torch.uint8, device=device)
+    rec[:, :_REC_HDR] = 0
     if local:
         hdr = torch.tensor([[i, n] for i, _, n in local], dtype=torch.int64).view(torch.uint8).view(len(local), _REC_HDR)
         rec[:, :_REC_HDR] = hdr.to(device)
@@ -85,17 +112,19 @@ def unpack_records(rec, H, W):
     return out
 
 
-def gather_results(local, world, device, H=None, W=None, dst=0):
+def gather_results(local, world, device, H=None, W=None, dst=0, collective=None):
     """The path's only collective (upsnet_end2end_test.py:224-247 leaves the outputs on their GPUs and the host collects them;
     data_parallel.py:103-116 gathers to the first device): every rank sends its per-image records -- local = list of
     (image_id, label_map uint8, n_inst) -- to rank `dst` ONLY. Returns a dict image_id -> (label_map [H,W], n_inst) on rank
-    `dst` and None elsewhere. H, W = record shape (the workload's padded size; defaults to the first local map).
+    `dst` and **None on every other rank** (contract since r06: callers must not expect the result on all ranks). H, W = record shape (the workload's padded size; defaults to the first local map).
     One gather of the 8-byte record counts, then one gather of the payload (ranks with fewer records pad to the largest count:
     with image i on rank i mod world the counts differ by at most one)."""
     if H is None or W is None:
         assert local, 'gather_results: give H, W when a rank may hold no image'
         H, W = local[0][1].shape
-    if world == 1:
+    if collective is None:
+        collective = world > 1      # (collective=True with world == 1: the N > 1 code path on a one-rank communicator -- pre-flight tests)
+    if not collective:
         return unpack_records(pack_records(local, H, W, device), H, W)
     if dist.get_backend() == 'gloo':
         device = torch.device('cpu')
@@ -119,6 +148,54 @@ def gather_results(local, world, device, H=None, W=None, dst=0):
     for r in range(world):
         out.update(unpack_records(recv[r][:int(counts[r])], H, W))
     return out
+
+
+def preflight(workload='upsnet50_cityscapes_1024x2048', in_flight=2):
+    """`bench.py --gpus N --dry-run`: everything a timed N-rank run does BEFORE its timed region, without timing anything -- device
+    per rank, model build, graph capture of every input shape on every graph instance (2 per rank by default), one checked forward
+    per instance, the communicator warm-up gather of the final record shape -- and a per-rank report of the device memory it took.
+    Returns (on rank 0) a dict; raises on any rank if its graph replay disagrees with its eager forward."""
+    rank, world, device = init_distributed()
+    preset, H, W, gain = WORKLOADS[workload]
+    sizes = list(zip(H, W)) if isinstance(H, (tuple, list)) else [(H, W)]
+    Hm, Wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    update_config_dict(preset)
+    hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (Hm, Wm))
+    torch.cuda.reset_peak_memory_stats(device)
+    model = build_model(cls_gain=gain, device=device)
+    ok = True
+    with torch.no_grad():
+        for j, (h, w) in enumerate(sizes):
+            data = make_image(h, w, seed=j, device=device)
+            model.use_graph = False
+            want = model(data)['panoptic_outputs'].clone()
+            model.use_graph = True
+            for _ in range(3 * model.graph_slots + model.graph_slots):
+                got = model(data)['panoptic_outputs']
+                ok = ok and bool(torch.equal(got, want))
+    torch.cuda.synchronize(device)
+    graphs = sum(1 for slots in model._graphs.values() for ent in slots['slots'] if 'graph' in ent)
+    if world > 1:
+        dummy = [(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0) for j in range(2)]
+        got = gather_results(dummy, world, device, hp, wp)
+        ok = ok and (got is None if rank != 0 else len(got) == 2 * world)
+        torch.cuda.synchronize(device)
+    free, total = torch.cuda.mem_get_info(device)
+    mine = torch.tensor([rank, int(ok), graphs, torch.cuda.max_memory_reserved(device) >> 20, (total - free) >> 20, total >> 20,
+                         len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 0], dtype=torch.int64,
+                        device=device if (world == 1 or dist.get_backend() != 'gloo') else 'cpu')
+    rows = [mine]
+    if world > 1:
+        rows = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, rows, dst=0)
+        dist.barrier()
+    if rank != 0:
+        return None
+    keys = ('rank', 'graph_replay_equals_eager', 'graphs_captured', 'torch_reserved_peak_mib', 'device_used_mib', 'device_total_mib', 'host_cpus')
+    per_rank = [dict(zip(keys, (int(v) for v in r.tolist()))) for r in rows]
+    return dict(dry_run=True, workload=workload, ranks=world, shapes=['%dx%d' % s for s in sizes], graph_instances_per_rank=model.graph_slots,
+                all_ok=all(r['graph_replay_equals_eager'] == 1 and r['graphs_captured'] == len(sizes) * model.graph_slots for r in per_rank),
+                per_rank=per_rank)
 
 
 def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, seed=0, pipeline='fused', gather=True,
@@ -227,3 +304,27 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return dict(rank=rank, world=world, elapsed=float(t.item()), net_times=list(net_timer.samples), latencies=list(lat), results=results,
                 last_out=out, model=model, image=get(my_ids[-1]), H=H, W=W)
+
+
+def main(argv=None):
+    """Entry point with the reference's command line (upsnet_end2end_test.py:155-290: --cfg yaml [--weight_path ...]) over the
+    synthetic workloads: builds the model from config.symbol / the workload preset, runs the process-per-GPU loop and logs the
+    reference's line `Batch i/N, data_time, net_time, post_time`. Launch under torch.distributed.run for N > 1 ranks."""
+    import logging
+    from .config.parse_args import parse_args
+    args = parse_args('UPSNet inference on MI355X (synthetic inputs)', argv)
+    logging.basicConfig(level=logging.INFO, format='%(asctime)-15s | %(message)s')
+    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, in_flight=args.in_flight)
+    if res['rank'] == 0:
+        nt = sorted(res['net_times'])
+        n_img = args.steps * res['world']
+        logging.info('Batch %d/%d, data_time:%.3f, net_time:%.3f, post_time:%.3f' % (n_img, n_img, 0.0, nt[len(nt) // 2] if nt else 0.0, 0.0))
+        logging.info('%d ranks, %.2f images/sec (whole job), %d label maps gathered on rank 0' %
+                     (res['world'], n_img / res['elapsed'], len(res['results'] or {})))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == '__main__':
+    main()
