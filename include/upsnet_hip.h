@@ -61,6 +61,10 @@ int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], 
                                  const float *rois, int num_rois, const int *num_rois_dev, int pooled_height,
                                  int pooled_width, int sampling_ratio, float *out_nhwc, int *levels_out);
 
+/* Development knob of upsnet_fpn_roi_align_forward: 0 = LDS tap-table kernel, one register set (default); 1 = two sets;
+ * 2 = the r03-r07 kernel (per-bin tap setup in registers). All variants return the same bits. */
+void upsnet_roi_tuning(int variant);
+
 /* ============================== Deformable convolution ============================== */
 
 /* Replaces deformable_im2col_gpu_kernel_launcher (upsnet/operators/src/deform_conv_cuda.cpp:25-30,
@@ -308,7 +312,8 @@ int upsnet_nms_batched(void *stream, const float *boxes, const float *scores, co
                        const uint8_t *pre_removed, int num_problems, int nmax, float thresh, int *keep_idx,
                        int *keep_cnt, void *workspace);
 
-/* Development knob: 1 = the scan stages the suppression mask in LDS (<= 1024 boxes per problem), 0 = reads it from L2 (default). */
+/* Development knob of the greedy scan: 0 = default (row-layout scan for problems of <= 1024 boxes, general scan reading L2 above
+ * that), 1 = general scan on an LDS copy of the mask (<= 1024 boxes), 2 = general scan reading L2 at every size. Same keep lists. */
 void upsnet_nms_tuning(int lds_staging);
 
 /* cpu_nms (upsnet/nms/cpu_nms.pyx:29-80, behind cpu_nms_wrapper, upsnet/nms/nms.py:37-40) on the device: same layout, visiting

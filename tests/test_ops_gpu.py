@@ -39,18 +39,33 @@ def test_roi_align_nchw_bitexact(U, C, H, W, ph, scale):
     assert np.array_equal(out2.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("N,ph", [(300, 7), (64, 14), (1, 7)])
-def test_fpn_roi_align_bitexact(U, N, ph):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("N,ph,C", [(300, 7, 32), (64, 14, 32), (1, 7, 32), (40, 7, 256), (9, 14, 320), (33, 32, 8)])
+def test_fpn_roi_align_bitexact(U, N, ph, C, variant):
+    """variant: 0 = LDS tap-table kernel (default), 1 = its two-register-set form, 2 = the r03-r07 per-bin setup kernel -- the same bits
+    from all three (and from the oracle), incl. C > 256 (two channel passes), C < 256 (idle lanes) and 32x32 bins (table capacity)."""
+    from upsnet_amd._lib import lib
     rng = np.random.default_rng(1)
-    H, W, C = 128, 256, 32
+    H, W = 128, 256
     feats = [rng.normal(size=(1, C, H // s, W // s)).astype(np.float32) for s in (4, 8, 16, 32)]
     rois = gen_rois(rng, N, H, W, 4, 200)
     # force boundary cases of the level formula: sqrt(wh)/224 + 1e-6 == 0.5 / 1 / 2
     for i, side in enumerate([112, 224, 448]):
         if i < N:
             rois[i] = [0, 0, 0, side - 1, side - 1]
+    # boxes partly / wholly outside the image (empty samples on one or both axes), degenerate boxes
+    if N >= 8:
+        rois[3] = [0, -40, -30, 20, 25]
+        rois[4] = [0, W - 10, H - 12, W + 60, H + 40]
+        rois[5] = [0, W + 5, 10, W + 50, 60]
+        rois[6] = [0, 17.3, 21.9, 17.3, 21.9]
+        rois[7] = [0, -300, -300, -200, -250]
     ref = oops.fpn_roi_align(feats, rois, ph, ph)
-    out, lv = U.fpn_roi_align([cu(f) for f in feats], cu(rois), ph, ph, [1 / 4., 1 / 8., 1 / 16., 1 / 32.], return_levels=True)
+    lib().upsnet_roi_tuning(variant)
+    try:
+        out, lv = U.fpn_roi_align([cu(f) for f in feats], cu(rois), ph, ph, [1 / 4., 1 / 8., 1 / 16., 1 / 32.], return_levels=True)
+    finally:
+        lib().upsnet_roi_tuning(0)
     assert np.array_equal(lv.cpu().numpy(), oops.fpn_level(rois))
     assert np.array_equal(out.cpu().numpy(), ref)
 
@@ -220,8 +235,8 @@ def test_deform_conv_function_and_module(U):
 
 
 def test_deform_conv_module_with_non_square_padding(U):
-    """DeformConv(..., padding=(a, b)) with a != b must keep working -- the second-generation fused kernels take square
-    geometry only, so such a layer is packed for (and runs on) the first-generation kernel, which takes both axes."""
+    """DeformConv(..., padding=(a, b)) with a != b must keep working -- the fused kernels take square geometry only, so
+    such a layer runs the reference's own structure (HIP im2col into a column buffer + one GEMM, functions/deform_conv.py:44-56)."""
     from upsnet_amd.operators.modules.deform_conv import DeformConv
     torch.manual_seed(1)
     m = DeformConv(32, 48, 3, stride=1, padding=(1, 2), dilation=1, bias=True).cuda()
@@ -235,7 +250,7 @@ def test_deform_conv_module_with_non_square_padding(U):
     w = m.weight.detach().cpu().numpy().astype(np.float64).reshape(48, -1)
     ref = (w @ col.reshape(col.shape[0], -1).astype(np.float64)).reshape(48, Ho, Wo) + m.bias.detach().cpu().numpy()[:, None, None]
     np.testing.assert_allclose(y[0].cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
-    assert U.pack_dcn_weight(m.weight.detach(), square=False)[0] not in ('frag', 'frag_bf16')
+    assert not U.fused_dcn_supported(32, 48, 1, 1, (1, 2), (1, 1), (1, 1)) and U.fused_dcn_supported(32, 48, 1, 1, (1, 1), (1, 1), (1, 1))
 
 
 def test_zero_fill_kernel_handles_any_address_and_size():
@@ -296,18 +311,37 @@ def test_nms_batched_with_counts_and_preremoved(U):
         assert np.array_equal(keep[p, :cnt[p]], refs[p])
 
 
-@pytest.mark.parametrize("lds", [0, 1])
+@pytest.mark.parametrize("lds", [0, 1, 2])
 def test_nms_scan_both_mask_sources(U, lds):
-    """The greedy scan reads the suppression words of the kept rows from L2 (default) or from an LDS copy of the mask (knob): same
-    keep lists, for 1 .. 2000 boxes (the LDS form covers <= 1024)."""
+    """The three forms of the greedy scan -- 0: row-layout scan for <= 1024 boxes (default; the general scan above that), 1: general
+    scan on an LDS copy of the mask, 2: general scan reading L2 at every size -- give the same keep lists, for 1 .. 2000 boxes, odd
+    and even numbers of 64-blocks, with and without pre-removed boxes, several problems per launch."""
     from upsnet_amd._lib import lib
     rng = np.random.default_rng(5)
     try:
         lib().upsnet_nms_tuning(lds)
-        for n in (1, 63, 64, 65, 500, 1000, 1024, 2000):
+        for n in (1, 63, 64, 65, 129, 300, 500, 960, 1000, 1023, 1024, 2000):
             d = gen_dets(rng, n)
             got = U.gpu_nms(cu(d), 0.5).cpu().numpy()
             assert np.array_equal(got, oops.gpu_nms(d, 0.5)), (lds, n)
+        # batched: ragged counts, pre-removed flags (the RPN's min-size filter), nmax with an odd number of column blocks
+        for P, nmax in ((5, 1000), (8, 300), (3, 1024)):
+            counts = rng.integers(0, nmax + 1, P).astype(np.int32)
+            counts[0] = nmax
+            boxes = np.zeros((P, nmax, 4), np.float32)
+            scores = np.zeros((P, nmax), np.float32)
+            pre = (rng.uniform(size=(P, nmax)) < 0.1).astype(np.uint8)
+            for q in range(P):
+                d = gen_dets(rng, nmax)
+                boxes[q], scores[q] = d[:, :4], d[:, 4]
+            keep, cnt = U.nms_batched(cu(boxes), cu(scores), cu(counts), 0.6, pre_removed=cu(pre))
+            keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+            for q in range(P):
+                c = int(counts[q])
+                alive = np.where(pre[q, :c] == 0)[0]
+                dq = np.hstack([boxes[q, :c], scores[q, :c, None]])[alive]
+                want = alive[oops.gpu_nms(dq, 0.6)] if len(alive) else np.zeros((0,), np.int64)
+                assert int(cnt[q]) == len(want) and np.array_equal(keep[q, :len(want)], want), (lds, P, nmax, q)
     finally:
         lib().upsnet_nms_tuning(0)
 

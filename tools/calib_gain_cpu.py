@@ -42,7 +42,7 @@ for seed in (0, 1):
         score = m.rcnn.cls_score(fc7)
         bbox_pred = _np(m.rcnn.bbox_pred(fc7))
         print("n_rois", rois.shape[0], "fc7 rms %.2f" % float(fc7.pow(2).mean().sqrt()), "cls logit std %.4f" % float(score.std()), flush=True)
-        for gain in (1, 1.5, 2, 2.5, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+        for gain in (4, 5, 6, 7, 8, 9, 10, 12, 20, 25, 30, 35):
             cp = _np(F.softmax(score * gain, dim=1))
             ds, db, dc = oops.mask_roi(rois, bbox_pred, cp, im_info, C, cfg.test.nms_thresh, cfg.test.score_thresh, cfg.test.max_det, False, cfg.network.bbox_reg_weights)
             ps, pb, pc = oops.mask_roi(rois, bbox_pred, cp, im_info, C, 0.5, cfg.test.panoptic_score_thresh, cfg.test.max_det, True, cfg.network.bbox_reg_weights)

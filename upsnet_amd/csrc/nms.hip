@@ -125,11 +125,16 @@ __device__ static inline u64 readlane64(u64 v, int src)
 //   * the suppression words of the kept rows are ORed into the per-column-block state by all 64 lanes: lane = (column block w,
 //     phase tq) reads the rows 4k + tq of the block (16 independent LDS reads), two xor-shuffles combine the four phases.
 // r05's scan (one dependent LDS read per kept row, sequential diagonal) took 120-140 us for 1000 boxes; this one ~15.
-__global__ void __launch_bounds__(NMS_SCAN_T)
+// (<= 128 registers: a scan wave must fit beside the three 124-register waves per SIMD of the deformable kernel it runs next to)
+typedef unsigned nms_uintx2 __attribute__((ext_vector_type(2)));
+
+template <bool LDS>
+__global__ void __launch_bounds__(NMS_SCAN_T) __attribute__((amdgpu_waves_per_eu(4, 4)))
 nms_scan_kernel(const u64 *__restrict__ mask, const u64 *__restrict__ diagT, const int *__restrict__ order,
                 const int *__restrict__ counts, const uint8_t *__restrict__ pre_removed, const int nmax, const int CB,
-                const int use_lds, int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
+                int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
 {
+    constexpr int use_lds = LDS ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *smask = reinterpret_cast<u64 *>(smem_raw);
     const int p = blockIdx.x, tid = threadIdx.x;
@@ -141,58 +146,209 @@ nms_scan_kernel(const u64 *__restrict__ mask, const u64 *__restrict__ diagT, con
     const int pitch = use_lds ? (1 << lg) : CB;          // u64 words per mask row as the scan reads it
     if (use_lds) {
         // only words (row i, column block >= i/64) were produced by nms_mask_kernel; copy exactly those
-        for (int idx = tid; idx < (n << lg); idx += NMS_SCAN_T) {
+        for (int idx = tid; idx < (n << lg); idx += (int)blockDim.x) {
             const int i = idx >> lg, cb = idx & (pitch - 1);
             if (cb < nb && cb >= (i >> 6)) smask[idx] = mp[(long)i * CB + cb];
         }
         __syncthreads();
     }
     if (tid >= 64) return;
-    const u64 *rows = use_lds ? smask : mp;
     const int lane = tid;
+    // mask rows of this problem: LDS copy, or buffer loads (one lane offset per block + a scalar row offset per load: no 64-bit
+    // address arithmetic, and a column block outside (b, nb) is an out-of-range offset that reads 0)
+    const size_t maddr = reinterpret_cast<size_t>(mp);
+    const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)maddr), mhi = __builtin_amdgcn_readfirstlane((unsigned)(maddr >> 32));
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)mhi << 32) | mlo), 0,
+                                                                           (int)((unsigned)nmax * (unsigned)CB * 8u), 0x00020000);
+#define NMS_ROWWORD(ROW_UNIFORM, LANE_ROW, W, OK, DST)                                                                     \
+    if (LDS) { DST = (OK) ? smask[(long)((ROW_UNIFORM) + (LANE_ROW)) * pitch + (W)] : 0ULL; }                              \
+    else {                                                                                                                 \
+        const nms_uintx2 v_ = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (OK) ? (unsigned)((LANE_ROW) * pitch + (W)) * 8u : 0x80000000u, \
+                                                                   (unsigned)(ROW_UNIFORM) * (unsigned)pitch * 8u, 0);     \
+        DST = ((u64)v_.y << 32) | v_.x;                                                                                    \
+    }
     const int *ord = order ? order + (long)p * nmax : nullptr;
     const u64 below = (1ULL << lane) - 1ULL;
     int nkeep = 0;
     // suppression state: lane w holds the words of column blocks w and w + 64 (nmax <= 8192)
     u64 remv0 = 0, remv1 = 0;
     const int wq = lane & 15, tq = lane >> 4;            // OR phase: column block slot, row phase
-    for (int b = 0; b < nb; ++b) {
-        const u64 cur = readlane64(b < 64 ? remv0 : remv1, b & 63);
-        const int i = b * 64 + lane;
-        const bool valid = i < n;
-        const int oi = valid ? (ord ? ord[i] : i) : 0;
-        const bool pre = valid && pre_removed && pre_removed[(long)p * nmax + oi];
-        const u64 tw = valid ? diagT[(long)p * nmax + i] : 0;      // boxes of this block that suppress box i
-        const u64 alive = ~cur & __ballot(valid) & ~__ballot(pre);
+    // Everything a block needs from memory is STATIC (the sort order, the pre-removed flags, the transposed diagonal words and the
+    // mask rows of its 64 boxes for the next 16 column blocks): none of it depends on the scan state, only its USE does (which rows
+    // are ORed in). So the loads of block b+1 are issued before block b is resolved (two statically named register sets, the loop
+    // unrolled by two: no copies), and the kept bits select among already loaded rows. r07 issued them on demand: three dependent
+    // memory latencies per block (order -> pre_removed; diagonal; the kept rows), 16 blocks in a row = 50-90 us for 1000 boxes.
+#define NMS_SET(S) int oi_##S = 0; bool pre_##S = false; u64 tw_##S = 0; u64 r_##S[16];
+#define NMS_FETCH(S, B)                                                                                                    \
+    {                                                                                                                      \
+        const int i_ = (B) * 64 + lane;                                                                                    \
+        const bool v_ = i_ < n;                                                                                            \
+        oi_##S = v_ ? (ord ? ord[i_] : i_) : 0;                                                                            \
+        pre_##S = v_ && pre_removed && pre_removed[(long)p * nmax + oi_##S];                                               \
+        tw_##S = v_ ? diagT[(long)p * nmax + i_] : 0;      /* boxes of this block that suppress box i */                   \
+        const int w_ = (((B) + 1) & ~15) + wq;                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                                     \
+            NMS_ROWWORD((B) * 64 + 4 * k, tq, w_, w_ > (B) && w_ < nb, r_##S[k])                                           \
+    }
+#define NMS_BLOCK(S, B)                                                                                                    \
+    {                                                                                                                      \
+        const int b = (B);                                                                                                 \
+        const u64 cur = readlane64(b < 64 ? remv0 : remv1, b & 63);                                                        \
+        const bool valid = b * 64 + lane < n;                                                                              \
+        const u64 alive = ~cur & __ballot(valid) & ~__ballot(pre_##S);                                                     \
+        u64 kept = alive;                                                                                                  \
+        for (;;) {                                                                                                         \
+            const u64 nk = alive & ~__ballot((tw_##S & kept & below) != 0);                                                \
+            if (nk == kept) break;                                                                                         \
+            kept = nk;                                                                                                     \
+        }                                                                                                                  \
+        if ((kept >> lane) & 1ULL)                                                                                         \
+            keep_idx[(long)p * nmax + nkeep + __builtin_popcountll(kept & below)] = oi_##S;                                \
+        nkeep += __builtin_popcountll(kept);                                                                               \
+        /* OR the rows of the kept boxes into the state of the later column blocks, 16 column blocks per pass; the first pass */ \
+        /* from the prefetched rows, further passes (more than 1024 boxes) on demand */                                    \
+        for (int w0 = (b + 1) & ~15; w0 < nb; w0 += 16) {                                                                  \
+            const int w = w0 + wq;                                                                                         \
+            u64 acc = 0;                                                                                                   \
+            if (w0 == ((b + 1) & ~15)) {                                                                                   \
+                _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                             \
+                    if ((kept >> (4 * k + tq)) & 1ULL) acc |= r_##S[k];                                                    \
+            } else if (w > b && w < nb) {                                                                                  \
+                _Pragma("unroll 4") for (int k = 0; k < 16; ++k) {                                                         \
+                    u64 word_;                                                                                             \
+                    NMS_ROWWORD(b * 64 + 4 * k, tq, w, true, word_)                                                        \
+                    if ((kept >> (4 * k + tq)) & 1ULL) acc |= word_;                                                       \
+                }                                                                                                          \
+            }                                                                                                              \
+            acc |= shfl64(acc, lane ^ 16);                                                                                 \
+            acc |= shfl64(acc, lane ^ 32);                                                                                 \
+            /* lane `wq` of each 16-group now holds the OR for column block w0 + wq; hand it to the lane that owns that block */ \
+            const u64 mine0 = shfl64(acc, lane & 15);               /* value for column block w0 + (lane & 15) */          \
+            if (lane >= (w0 & 63) && lane < (w0 & 63) + 16) {                                                              \
+                if (w0 < 64) remv0 |= mine0; else remv1 |= mine0;                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+    NMS_SET(A)
+    NMS_SET(B)
+    if (nb > 0) NMS_FETCH(A, 0)
+    for (int b0 = 0; b0 < nb; b0 += 2) {
+        if (b0 + 1 < nb) NMS_FETCH(B, b0 + 1)
+        NMS_BLOCK(A, b0)
+        if (b0 + 1 >= nb) break;
+        if (b0 + 2 < nb) NMS_FETCH(A, b0 + 2)
+        NMS_BLOCK(B, b0 + 1)
+    }
+#undef NMS_SET
+#undef NMS_ROWWORD
+#undef NMS_FETCH
+#undef NMS_BLOCK
+    if (lane == 0) keep_cnt[p] = nkeep;
+}
+
+// ---------------------------------------------------------------------------------------------
+// r08: the scan for problems of <= 1024 boxes (every RPN level, every class) in ROW layout, fully unrolled over the <= 16 blocks.
+// What is sequential in greedy NMS is one 64-bit word per block: cur_b = OR over the kept rows of all earlier blocks of their
+// word for column block b. The r05-r07 scan pushed the kept rows of block j eagerly into the state of ALL later column blocks with
+// lane = (column block, row phase): 16 guarded 64-bit ORs on freshly loaded words, three 64-bit LDS-crossbar shuffles and a
+// readlane per block, ~500 dependent instructions of ONE wave = 2.7 us per block, 43 us for 1000 boxes (a lone wave issues an
+// instruction every ~5 cycles). Here lane = ROW: lane l of block j owns row 64 j + l, holds that row's words for the later column
+// blocks (one contiguous 128-byte run: eight 16-byte buffer loads, prefetched one block ahead; scalars two blocks ahead), and ORs
+// them into its private accumulators acc[c] if it is kept -- one exec-masked v_or per word, no cross-lane traffic. Only when block c
+// is reached is acc[c] reduced over the 64 lanes: four DPP steps inside each row of 16 (quad_perm x 2, row_half_mirror, row_mirror:
+// OR is idempotent, so mirrors are as good as rotations) + four v_readlane per half = a SCALAR cur_c in ~25 instructions.
+// The diagonal block is resolved by the same fixed point as before. ~100 instructions per block; keep lists are bit-identical.
+__device__ static inline unsigned nms_row_or(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return v;
+}
+
+__device__ static inline u64 nms_wave_or(u64 v)    // OR over the 64 lanes, wave-uniform result
+{
+    const unsigned lo = nms_row_or((unsigned)v), hi = nms_row_or((unsigned)(v >> 32));
+    const unsigned rl = __builtin_amdgcn_readlane((int)lo, 0) | __builtin_amdgcn_readlane((int)lo, 16) |
+                        __builtin_amdgcn_readlane((int)lo, 32) | __builtin_amdgcn_readlane((int)lo, 48);
+    const unsigned rh = __builtin_amdgcn_readlane((int)hi, 0) | __builtin_amdgcn_readlane((int)hi, 16) |
+                        __builtin_amdgcn_readlane((int)hi, 32) | __builtin_amdgcn_readlane((int)hi, 48);
+    return ((u64)rh << 32) | rl;
+}
+
+typedef unsigned nms_uintx4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+nms_scan16_kernel(const u64 *__restrict__ mask, const u64 *__restrict__ diagT, const int *__restrict__ order,
+                  const int *__restrict__ counts, const uint8_t *__restrict__ pre_removed, const int nmax, const int CB,
+                  int *__restrict__ keep_idx, int *__restrict__ keep_cnt)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = min(counts[p], nmax);
+    const int nb = (n + 63) >> 6;                       // <= 16 (the launcher guarantees nmax <= 1024)
+    const int *ord = order ? order + (long)p * nmax : nullptr;
+    const u64 *dg = diagT + (long)p * nmax;
+    const uint8_t *prm = pre_removed ? pre_removed + (long)p * nmax : nullptr;
+    int *kout = keep_idx + (long)p * nmax;
+    const u64 below = (1ULL << lane) - 1ULL;
+    const size_t maddr = reinterpret_cast<size_t>(mask + (long)p * nmax * CB);
+    const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)maddr), mhi = __builtin_amdgcn_readfirstlane((unsigned)(maddr >> 32));
+    // (rows 64 j + l >= nmax of the last block lie beyond the problem's mask: out of the descriptor's range, they read 0)
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)mhi << 32) | mlo), 0,
+                                                                           (int)((unsigned)nmax * (unsigned)CB * 8u), 0x00020000);
+    const unsigned row_pitch = (unsigned)CB * 8u;
+    u64 acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0;
+    int oi[3];            // sort order of this lane's box in blocks j, j+1, j+2 (ring, index j % 3)
+    bool pre[2];          // pre-removed flag, blocks j, j+1 (index j & 1)
+    u64 tw[2];            // transposed diagonal word
+    nms_uintx4 rw[2][8];  // the row's words for column blocks 2m, 2m+1 (m = 0..7); only m >= (j + 1) / 2 is loaded and used
+#define S16_ORD(J) { const int i_ = (J) * 64 + lane; oi[(J) % 3] = i_ < n ? (ord ? ord[i_] : i_) : 0; }
+#define S16_STATIC(J)                                                                                                      \
+    {                                                                                                                      \
+        const int i_ = (J) * 64 + lane;                                                                                    \
+        const bool v_ = i_ < n;                                                                                            \
+        pre[(J) & 1] = v_ && prm && prm[oi[(J) % 3]];                                                                      \
+        tw[(J) & 1] = v_ ? dg[i_] : 0ULL;                                                                                  \
+        const unsigned vo_ = (unsigned)i_ * row_pitch;                                                                     \
+        _Pragma("unroll") for (int m = ((J) + 1) / 2; m < 8; ++m)                                                          \
+            if (2 * m < CB) rw[(J) & 1][m] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, vo_ + 16u * (unsigned)m, 0, 0);  \
+    }
+    if (nb > 0) S16_ORD(0)
+    if (nb > 1) S16_ORD(1)
+    if (nb > 0) S16_STATIC(0)
+    int nkeep = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= nb) continue;          // (wave-uniform; no `break`: the loop must keep its constant trip count to be unrolled)
+        if (j + 2 < 16 && j + 2 < nb) S16_ORD(j + 2)
+        if (j + 1 < 16 && j + 1 < nb) S16_STATIC(j + 1)
+        const u64 cur = nms_wave_or(acc[j]);
+        const bool valid = j * 64 + lane < n;
+        const u64 alive = ~cur & __ballot(valid) & ~__ballot(pre[j & 1]);
+        const u64 twj = tw[j & 1];
         u64 kept = alive;
         for (;;) {
-            const u64 nk = alive & ~__ballot((tw & kept & below) != 0);
+            const u64 nk = alive & ~__ballot((twj & kept & below) != 0);
             if (nk == kept) break;
             kept = nk;
         }
-        if ((kept >> lane) & 1ULL)
-            keep_idx[(long)p * nmax + nkeep + __builtin_popcountll(kept & below)] = oi;
+        const bool mine = (kept >> lane) & 1ULL;
+        if (mine) kout[nkeep + __builtin_popcountll(kept & below)] = oi[j % 3];
         nkeep += __builtin_popcountll(kept);
-        // OR the rows of the kept boxes into the state of the later column blocks, 16 column blocks per pass
-        for (int w0 = (b + 1) & ~15; w0 < nb; w0 += 16) {
-            const int w = w0 + wq;
-            u64 acc = 0;
-            if (w > b && w < nb) {
+        if (mine) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int t = 4 * k + tq;
-                    if ((kept >> t) & 1ULL) acc |= rows[(long)(b * 64 + t) * pitch + w];
-                }
-            }
-            acc |= shfl64(acc, lane ^ 16);
-            acc |= shfl64(acc, lane ^ 32);
-            // lane `wq` of each 16-group now holds the OR for column block w0 + wq; hand it to the lane that owns that block
-            const u64 mine0 = shfl64(acc, lane & 15);               // value for column block w0 + (lane & 15)
-            if (lane >= (w0 & 63) && lane < (w0 & 63) + 16) {
-                if (w0 < 64) remv0 |= mine0; else remv1 |= mine0;
+            for (int m = (j + 1) / 2; m < 8; ++m) {
+                const nms_uintx4 w = rw[j & 1][m];
+                if (2 * m > j) acc[2 * m] |= ((u64)w.y << 32) | w.x;
+                acc[2 * m + 1] |= ((u64)w.w << 32) | w.z;
             }
         }
     }
+#undef S16_ORD
+#undef S16_STATIC
     if (lane == 0) keep_cnt[p] = nkeep;
 }
 
@@ -226,7 +382,10 @@ extern "C" size_t upsnet_nms_workspace_bytes(int P, int nmax)
 
 // development knob: 1 = stage the suppression mask in LDS (problems of <= 1024 boxes), 0 (default, or UPSNET_NMS_LDS unset) = read it from L2
 static int g_nms_lds = (getenv("UPSNET_NMS_LDS") != nullptr && getenv("UPSNET_NMS_LDS")[0] == '1') ? 1 : 0;
-extern "C" void upsnet_nms_tuning(int lds_staging) { g_nms_lds = lds_staging ? 1 : 0; }
+static int g_nms_scan16 = (getenv("UPSNET_NMS_SCAN16") != nullptr && getenv("UPSNET_NMS_SCAN16")[0] == '0') ? 0 : 1;
+// lds_staging: 0 = default (row-layout scan for <= 1024 boxes, L2 reads otherwise), 1 = LDS-staged mask (r05 form), 2 = the general
+// scan for every size (r07 form)
+extern "C" void upsnet_nms_tuning(int lds_staging) { g_nms_lds = lds_staging == 1 ? 1 : 0; g_nms_scan16 = lds_staging == 0 ? 1 : 0; }
 
 // internal: tie_mode-selectable version used by the proposal / detection pipelines
 int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores, const int *counts,
@@ -257,13 +416,19 @@ int ups_nms_batched_impl(hipStream_t st, const float *boxes, const float *scores
     if (scan_smem > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_scan_kernel),
+            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_scan_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, NMS_LDS_ROWS * (NMS_LDS_ROWS / 64) * 8));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(P), dim3(NMS_SCAN_T), scan_smem, st, w.mask, w.diagT, w.order, counts, pre_removed, nmax, CB,
-                       use_lds, keep_idx, keep_cnt);
+    if (!use_lds && nmax <= 1024 && g_nms_scan16)
+        hipLaunchKernelGGL(nms_scan16_kernel, dim3(P), dim3(64), 0, st, w.mask, w.diagT, w.order, counts, pre_removed, nmax, CB, keep_idx, keep_cnt);
+    else if (use_lds)
+        hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(P), dim3(NMS_SCAN_T), scan_smem, st, w.mask, w.diagT, w.order, counts, pre_removed, nmax, CB,
+                           keep_idx, keep_cnt);
+    else
+        hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(P), dim3(64), 0, st, w.mask, w.diagT, w.order, counts, pre_removed, nmax, CB,
+                           keep_idx, keep_cnt);
     UPS_CHECK_LAUNCH("nms_scan_kernel");
     return 0;
 }
@@ -323,8 +488,8 @@ extern "C" int upsnet_nms_host(int *keep_out, int *num_out, const float *boxes_h
             hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = ups_set_error("nms_host: H2D copy failed"); break; }
         hipLaunchKernelGGL(nms_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, raw, n, boxes_dim, packed);
         hipLaunchKernelGGL(nms_mask_kernel, dim3(CB, CB, 1), dim3(64), 0, 0, packed, cnt, n, CB, thresh, 0, mask, diagT);
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_T), 0, 0, mask, diagT, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
-                           n, CB, 0, keep, kc);
+        hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(1), dim3(64), 0, 0, mask, diagT, (const int *)nullptr, cnt, (const uint8_t *)nullptr,
+                           n, CB, keep, kc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { rc = ups_set_error("nms_host: launch failed: %s", hipGetErrorString(e)); break; }
         if (hipMemcpy(num_out, kc, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||

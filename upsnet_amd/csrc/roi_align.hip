@@ -346,6 +346,199 @@ fpn_roi_align_nhwc_roi_kernel(const FpnFeat ft, const int channels, const float 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// r08: one workgroup per ROI with a SEPARABLE TAP TABLE in LDS (sampling_ratio == 2).
+//
+// The 2*PH sample rows and 2*PW sample columns of a ROI fully determine its PH*PW*4 samples: a sample's corner offsets are
+// (row offset + column offset) and its bilinear weights the products hy*hx, hy*lx, ly*hx, ly*lx of two per-axis factors -- the very
+// expressions of roi_align_kernel.cu:43-95, so the values are bit-identical. The table (16 bytes per sample row / column: two byte
+// offsets, two weights; weights 0 for samples outside the map) is built ONCE per workgroup by 2*(PH+PW) threads instead of once per
+// (bin, wave) by all 64 lanes (the r03-r07 kernel spent ~300 VALU instructions per bin on it and 216 registers: 2 waves per SIMD,
+// VALU active 40 % of the cycles of a kernel that should only move bytes).
+// A wave owns one bin at a time: its 16 corner vectors (16 x 1 KiB for 256 channels) are buffer loads whose tap offset is WAVE-UNIFORM,
+// i.e. a scalar register (soffset) -- no per-lane address arithmetic at all; the lane offset (16 bytes per lane) is loop-invariant.
+// SETS == 1: one register set, <= 128 registers = 4 waves per SIMD (4 workgroups per CU: 1024 ROI slots, the box head's 1000 ROIs are
+// ONE round), the other waves' loads cover a wave's blend. SETS == 2: two statically named sets, the loads of bin i+1 issued before
+// bin i is blended, 3 waves per SIMD.
+struct RoiAxis {
+    unsigned lo, hi;   // byte offset of the low / high row (or column) inside the level's NHWC map
+    float l, h;        // ly, hy (lx, hx); both 0 for a sample outside the map
+};
+
+__device__ static inline RoiAxis roi_axis(const int size, float y, const unsigned pitch_bytes)
+{
+    const bool empty = y < -1.0f || y > (float)size;     // roi_align_kernel.cu:51-55 (one axis of the joint test)
+    if (y <= 0) y = 0;
+    int lo = (int)y, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else { hi = lo + 1; }
+    const float l = y - (float)lo, h = 1.0f - l;
+    RoiAxis a;
+    a.lo = (unsigned)lo * pitch_bytes; a.hi = (unsigned)hi * pitch_bytes;
+    a.l = empty ? 0.f : l; a.h = empty ? 0.f : h;
+    return a;
+}
+
+#define ROI_MAXP 32   // pooled_h, pooled_w <= 32 on this path
+
+struct RoiTaps {       // one bin: 16 wave-uniform corner offsets (scalar registers) + the per-axis weight factors of its 2 x 2 samples
+    unsigned o[16];
+    float yl[2], yh[2], xl[2], xh[2];
+};
+// weight of corner q (0..3 = v1..v4) of sample s (= iy * 2 + ix): hy*hx, hy*lx, ly*hx, ly*lx (roi_align_kernel.cu:84-88)
+#define ROI_W(T, S, Q) ((((Q) & 2) ? (T).yl[(S) >> 1] : (T).yh[(S) >> 1]) * (((Q) & 1) ? (T).xl[(S) & 1] : (T).xh[(S) & 1]))
+
+__device__ static inline void roi_bin_taps(const RoiAxis *__restrict__ ytab, const RoiAxis *__restrict__ xtab, const int ph, const int pw, RoiTaps &t)
+{
+    RoiAxis y[2], x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // (uniform addresses: LDS broadcast reads; offsets go to scalar registers)
+        y[i] = ytab[2 * ph + i];
+        x[i] = xtab[2 * pw + i];
+        y[i].lo = __builtin_amdgcn_readfirstlane(y[i].lo); y[i].hi = __builtin_amdgcn_readfirstlane(y[i].hi);
+        x[i].lo = __builtin_amdgcn_readfirstlane(x[i].lo); x[i].hi = __builtin_amdgcn_readfirstlane(x[i].hi);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {   // sample (iy, ix) = (s >> 1, s & 1); corners in the reference's order v1..v4
+        const RoiAxis &a = y[s >> 1], &b = x[s & 1];
+        t.o[4 * s + 0] = a.lo + b.lo; t.o[4 * s + 1] = a.lo + b.hi; t.o[4 * s + 2] = a.hi + b.lo; t.o[4 * s + 3] = a.hi + b.hi;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { t.yl[i] = y[i].l; t.yh[i] = y[i].h; t.xl[i] = x[i].l; t.xh[i] = x[i].h; }
+}
+
+typedef unsigned roi_uintx4 __attribute__((ext_vector_type(4)));
+
+#define ROI_LOAD16(V, T) _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                      \
+        const roi_uintx4 r_ = __builtin_amdgcn_raw_buffer_load_b128(frsrc, lane_off, (T).o[q_], 0);                 \
+        V[q_] = make_float4(__uint_as_float(r_.x), __uint_as_float(r_.y), __uint_as_float(r_.z), __uint_as_float(r_.w)); }   \
+    __builtin_amdgcn_sched_barrier(0);   /* all 16 loads are issued before anything of the blend (the scheduler would otherwise trade them for occupancy) */
+
+// reference order: sample (iy, ix), corners 1..4, then the mean over the 4 samples (roi_align_kernel.cu:199-231)
+#define ROI_BLEND_STORE(V, T, BIN) {                                                                              \
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
+        _Pragma("unroll") for (int sq = 0; sq < 4; ++sq) {                                                        \
+            float4 val;                                                                                           \
+            const float w0_ = ROI_W(T, sq, 0);                                                                    \
+            val.x = w0_ * V[4 * sq].x; val.y = w0_ * V[4 * sq].y; val.z = w0_ * V[4 * sq].z; val.w = w0_ * V[4 * sq].w; \
+            _Pragma("unroll") for (int q = 1; q < 4; ++q) {                                                       \
+                const float wq_ = ROI_W(T, sq, q);                                                                \
+                val.x = val.x + wq_ * V[4 * sq + q].x; val.y = val.y + wq_ * V[4 * sq + q].y;                     \
+                val.z = val.z + wq_ * V[4 * sq + q].z; val.w = val.w + wq_ * V[4 * sq + q].w;                     \
+            }                                                                                                     \
+            acc.x += val.x; acc.y += val.y; acc.z += val.z; acc.w += val.w;                                       \
+        }                                                                                                         \
+        acc.x /= 4.0f; acc.y /= 4.0f; acc.z /= 4.0f; acc.w /= 4.0f;                                               \
+        roi_uintx4 s_;                                                                                            \
+        s_.x = __float_as_uint(acc.x); s_.y = __float_as_uint(acc.y); s_.z = __float_as_uint(acc.z); s_.w = __float_as_uint(acc.w); \
+        __builtin_amdgcn_raw_buffer_store_b128(s_, orsrc, lane_off, (unsigned)(BIN) * row_bytes, 0); }
+
+template <int SETS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SETS == 1 ? 4 : 3, SETS == 1 ? 5 : 3)))
+fpn_roi_align_nhwc_tab_kernel(const FpnFeat ft, const int channels, const float *__restrict__ rois, const int num_rois,
+                              const int *__restrict__ num_rois_dev, const int pooled_h, const int pooled_w,
+                              float *__restrict__ out, int *__restrict__ levels_out)
+{
+    __shared__ RoiAxis ytab[2 * ROI_MAXP], xtab[2 * ROI_MAXP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = blockIdx.x;
+    const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
+    const int c4n = channels >> 2;
+    const int nbins_all = pooled_h * pooled_w;
+    const int per = (nbins_all + gridDim.y - 1) / gridDim.y;   // blockIdx.y splits the bins of a ROI when there are few ROIs
+    const int bin0 = blockIdx.y * per, nbins = min(nbins_all, bin0 + per);
+    if (n >= nvalid) {  // padded tail of a fixed-size roi buffer: defined output (zeros)
+        float4 *o4 = reinterpret_cast<float4 *>(out + (long)n * nbins_all * channels);
+        for (int i = bin0 * c4n + threadIdx.x; i < nbins * c4n; i += blockDim.x) o4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float *r = rois + (long)n * 5;
+    const float rx1 = r[1], ry1 = r[2], rx2 = r[3], ry2 = r[4];
+    const int lvl = __builtin_amdgcn_readfirstlane(fpn_level_of(rx1, ry1, rx2, ry2));
+    if (levels_out && threadIdx.x == 0 && blockIdx.y == 0) levels_out[n] = lvl;
+    const float spatial_scale = ft.scale[lvl];
+    const int height = ft.h[lvl], width = ft.w[lvl];
+    const unsigned row_bytes = (unsigned)channels * 4u;
+    {   // the tap table: thread s < 2*PH -> sample row s, thread 64 + s (s < 2*PW) -> sample column s
+        const float roi_start_w = rx1 * spatial_scale, roi_start_h = ry1 * spatial_scale;
+        const float roi_end_w = rx2 * spatial_scale, roi_end_h = ry2 * spatial_scale;
+        const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+        const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+        const float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+        const int s = threadIdx.x & 63;
+        if (threadIdx.x < 64) {
+            if (s < 2 * pooled_h) {
+                const float y = roi_start_h + (float)(s >> 1) * bin_size_h + ((float)(s & 1) + .5f) * bin_size_h / 2.0f;
+                ytab[s] = roi_axis(height, y, (unsigned)width * row_bytes);
+            }
+        } else if (threadIdx.x < 128) {
+            if (s < 2 * pooled_w) {
+                const float x = roi_start_w + (float)(s >> 1) * bin_size_w + ((float)(s & 1) + .5f) * bin_size_w / 2.0f;
+                xtab[s] = roi_axis(width, x, row_bytes);
+            }
+        }
+    }
+    __syncthreads();
+    // buffer descriptors: the level's feature map (reads) and this ROI's output rows (stores)
+    const size_t fbase = (size_t)ft.ptr[lvl];
+    const unsigned flo = __builtin_amdgcn_readfirstlane((unsigned)fbase), fhi = __builtin_amdgcn_readfirstlane((unsigned)(fbase >> 32));
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)fhi << 32) | flo), 0,
+                                                                           (int)((unsigned)height * (unsigned)width * row_bytes), 0x00020000);
+    const size_t obase = (size_t)(out + (long)n * nbins_all * channels);
+    const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)obase), ohi = __builtin_amdgcn_readfirstlane((unsigned)(obase >> 32));
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)ohi << 32) | olo), 0,
+                                                                           (int)((unsigned)nbins_all * row_bytes), 0x00020000);
+    for (int c4 = lane; c4 < c4n; c4 += 64) {          // 256 channels: one pass
+        const unsigned lane_off = (unsigned)c4 * 16u;
+        int bin = bin0 + wave, ph = bin / pooled_w, pw = bin - ph * pooled_w;
+#define ROI_ADVANCE() { bin += 4; pw += 4; while (pw >= pooled_w) { pw -= pooled_w; ++ph; } }
+        if (SETS == 1) {
+            for (; bin < nbins;) {
+                RoiTaps t;
+                float4 v[16];
+                roi_bin_taps(ytab, xtab, ph, pw, t);
+                ROI_LOAD16(v, t)
+                ROI_BLEND_STORE(v, t, bin)
+                ROI_ADVANCE()
+            }
+        } else {
+            RoiTaps ta, tb;
+            float4 v[16], u[16];
+            if (bin < nbins) {
+                roi_bin_taps(ytab, xtab, ph, pw, ta);
+                ROI_LOAD16(v, ta)
+            }
+            while (bin < nbins) {
+                const int bin_a = bin;
+                ROI_ADVANCE()
+                const bool has_b = bin < nbins;
+                if (has_b) {
+                    roi_bin_taps(ytab, xtab, ph, pw, tb);
+                    ROI_LOAD16(u, tb)
+                }
+                ROI_BLEND_STORE(v, ta, bin_a)
+                if (!has_b) break;
+                const int bin_b = bin;
+                ROI_ADVANCE()
+                if (bin < nbins) {
+                    roi_bin_taps(ytab, xtab, ph, pw, ta);
+                    ROI_LOAD16(v, ta)
+                }
+                ROI_BLEND_STORE(u, tb, bin_b)
+            }
+        }
+#undef ROI_ADVANCE
+    }
+}
+
+// 0 (default): table kernel, one register set; 1: table kernel, two sets; 2: the r03-r07 per-ROI kernel; A/B knob (also env UPSNET_ROI_KERNEL)
+static int g_roi_variant = -1;
+extern "C" void upsnet_roi_tuning(int variant) { g_roi_variant = variant; }
+static int roi_variant()
+{
+    if (g_roi_variant < 0) { const char *e = getenv("UPSNET_ROI_KERNEL"); g_roi_variant = e ? atoi(e) : 0; }
+    return g_roi_variant;
+}
+
 extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
                                             const int feat_w[4], const float spatial_scale[4], int channels,
                                             const float *rois, int num_rois, const int *num_rois_dev,
@@ -368,9 +561,17 @@ extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const fea
         int nsplit = (1536 + num_rois - 1) / num_rois;   // aim at >= 1536 workgroups, >= 8 bins each
         if (nsplit > nb / 8) nsplit = nb / 8;
         if (nsplit < 1) nsplit = 1;
-        hipLaunchKernelGGL(fpn_roi_align_nhwc_roi_kernel, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
-                           num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
-        UPS_CHECK_LAUNCH("fpn_roi_align_nhwc_roi_kernel");
+        const int variant = (pooled_height <= ROI_MAXP && pooled_width <= ROI_MAXP) ? roi_variant() : 2;
+        if (variant == 0)
+            hipLaunchKernelGGL(fpn_roi_align_nhwc_tab_kernel<1>, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+        else if (variant == 1)
+            hipLaunchKernelGGL(fpn_roi_align_nhwc_tab_kernel<2>, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+        else
+            hipLaunchKernelGGL(fpn_roi_align_nhwc_roi_kernel, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+        UPS_CHECK_LAUNCH("fpn_roi_align_nhwc (per-ROI workgroups)");
         return 0;
     }
     long bins = (long)num_rois * pooled_height * pooled_width;

@@ -53,10 +53,9 @@ class FCNSubNet(nn.Module):
         return x
 
     def _wpack(self, i, dc):
-        sq = ops.dcn_square(dc.padding, dc.stride, dc.dilation)
-        key = (dc.weight.data_ptr(), dc.weight._version, ops.dcn_precision(), sq)
+        key = (dc.weight.data_ptr(), dc.weight._version, ops.dcn_precision())
         if i not in self._packed or self._packed[i][0] != key:
-            self._packed[i] = (key, ops.pack_dcn_weight(dc.weight.detach(), square=sq))
+            self._packed[i] = (key, ops.pack_dcn_weight(dc.weight.detach()))
         return self._packed[i][1]
 
     def forward_levels(self, feats):
@@ -65,7 +64,7 @@ class FCNSubNet(nn.Module):
         for i in range(self.num_layers):
             layer = self.conv[i][0]
             dc = layer.conv
-            if not ops.fused_dcn_supported(dc.in_channels, dc.out_channels, dc.deformable_groups, dc.groups):
+            if not ops.fused_dcn_supported(dc.in_channels, dc.out_channels, dc.deformable_groups, dc.groups, dc.padding, dc.stride, dc.dilation):
                 xs = [self.conv[i](x) for x in xs]
                 continue
             offsets = hipconv.conv_multi(layer.conv_offset, xs)

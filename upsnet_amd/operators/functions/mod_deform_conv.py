@@ -33,8 +33,8 @@ class ModDeformConvFunction(Function):
         ctx.conf = (in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
         B, C, H, W = data.shape
         Ho, Wo = ops.out_hw(H, W, kernel_size, padding, stride, dilation)
-        if ops.fused_dcn_supported(in_channels, out_channels, deformable_groups, groups):
-            wpack = ops.cached_dcn_pack(weight, square=ops.dcn_square(padding, stride, dilation))   # packed once per weight (version-checked)
+        if ops.fused_dcn_supported(in_channels, out_channels, deformable_groups, groups, padding, stride, dilation):
+            wpack = ops.cached_dcn_pack(weight)   # packed once per weight (version-checked), not per call
             outs = [ops.deform_conv_fused([data[i:i + 1]], [offset[i:i + 1]], wpack, bias, in_channels, out_channels,
                                           kernel_size, stride, padding, dilation, masks=[mask[i:i + 1]])[0] for i in range(B)]
             return outs[0] if B == 1 else torch.cat(outs, 0)

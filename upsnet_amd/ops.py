@@ -183,17 +183,16 @@ def dcn_precision():
 
 
 def dcn_square(pad, stride, dil):
-    """The second-generation fused kernels take one pad / stride / dilation for both axes."""
+    """The fused kernels (both generations) take one pad / stride / dilation for both axes; other geometries run the reference's own
+    structure (im2col into a caller-allocated column buffer + one GEMM) through the NCHW drop-in entry point."""
     return pad[0] == pad[1] and stride[0] == stride[1] and dil[0] == dil[1]
 
 
-def pack_dcn_weight(weight, kind=None, square=True):
+def pack_dcn_weight(weight, kind=None):
     """[Cout,Cin,kh,kw] -> packed weight for deform_conv_fused: ('frag', wp) in MFMA fragment order for csrc/deform_fused.hip
     (('frag_bf16', wp) for csrc/deform_fused_bf16.hip: kind 'frag_bf16', or 'frag' while dcn_precision() is 'bf16'), or
     (wpack [kh*kw*Cin, ldw], ldw) -- the dense convolution's packing -- for the first-generation kernel."""
     kind = kind or DCN_KERNEL
-    if not square:   # padding=(a, b) with a != b etc.: the first-generation kernel (csrc/conv.hip loader mode) covers it
-        kind = 'igemm'
     cout, cin, kh, kw = weight.shape
     if kind == 'frag' and dcn_precision() == 'bf16':
         kind = 'frag_bf16'
@@ -210,18 +209,18 @@ def pack_dcn_weight(weight, kind=None, square=True):
     return pack_conv_weight(weight)
 
 
-def cached_dcn_pack(weight, square=True):
+def cached_dcn_pack(weight):
     """Packed deformable-convolution weight cached ON the weight tensor (re-packed when it changes or moves)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL, dcn_precision(), bool(square))
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), DCN_KERNEL, dcn_precision())
     ent = weight.__dict__.get('_ups_dcn_pack')
     if ent is None or ent[0] != key:
-        ent = (key, pack_dcn_weight(weight.detach(), square=square))
+        ent = (key, pack_dcn_weight(weight.detach()))
         weight.__dict__['_ups_dcn_pack'] = ent
     return ent[1]
 
 
-def fused_dcn_supported(cin, cout, deformable_groups, groups):
-    return groups == 1 and deformable_groups == 1 and cin % 32 == 0
+def fused_dcn_supported(cin, cout, deformable_groups, groups, pad=(0, 0), stride=(1, 1), dil=(1, 1)):
+    return groups == 1 and deformable_groups == 1 and cin % 32 == 0 and dcn_square(pad, stride, dil)
 
 
 def _nhwc_out(n, c, h, w, device):
