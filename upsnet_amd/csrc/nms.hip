@@ -48,7 +48,8 @@ nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ score
     Mp = min(Mp, M);
     for (int i = tid; i < Mp; i += bd)
         keys[i] = i < n ? ups_make_key(scores[(long)p * nmax + i], (unsigned)i, tie_mode) : 0ULL;
-    ups_block_sort_desc(keys, Mp);
+    if (Mp <= 128) ups_block_rank_sort_desc(keys, n, Mp);   // (unique, non-zero keys; small sets only, see sort.h)
+    else ups_block_sort_desc(keys, Mp);
     const float4 *b4 = reinterpret_cast<const float4 *>(boxes) + (long)p * nmax;
     for (int i = tid; i < n; i += bd) {
         const int idx = (int)ups_key_index(keys[i], tie_mode);

@@ -639,7 +639,7 @@ panoptic_fuse_up_kernel(const float *__restrict__ score, const long pix_stride, 
     FuseInst *s_inst = reinterpret_cast<FuseInst *>(s_src + (size_t)S * SH * SW);  // [FUSE_MAXK]
     int *s_list = reinterpret_cast<int *>(s_inst + FUSE_MAXK);
     unsigned char *s_touch = reinterpret_cast<unsigned char *>(s_list + FUSE_MAXK);
-    __shared__ int s_nlist;
+    __shared__ int s_nlist, s_first_unlisted;
 
     const int H = Hs * SCALE, W = Ws * SCALE;
     const long hw = (long)H * W;
@@ -680,9 +680,13 @@ panoptic_fuse_up_kernel(const float *__restrict__ score, const long pix_stride, 
         s_touch[j] = tm || ts;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { int n = 0; for (int j = 0; j < k; ++j) if (s_touch[j]) s_list[n++] = j; s_nlist = n; }
+    if (threadIdx.x == 0) {
+        int n = 0, u0 = k;
+        for (int j = 0; j < k; ++j) { if (s_touch[j]) s_list[n++] = j; else if (u0 == k) u0 = j; }
+        s_nlist = n; s_first_unlisted = u0;
+    }
     __syncthreads();
-    const int nlist = s_nlist;
+    const int nlist = s_nlist, u0 = s_first_unlisted;
 
     // thread -> 4 consecutive pixels of one tile row
     const int y = ty0 + threadIdx.x / (FUP_TW / 4);
@@ -717,17 +721,26 @@ panoptic_fuse_up_kernel(const float *__restrict__ score, const long pix_stride, 
     int n_in[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { mi_listed[q] = -INFINITY; n_in[q] = 0; }
-    int li = 0;
-    for (int j = 0; j < k; ++j) {
-        const bool listed = li < nlist && s_list[li] == j;
-        if (listed) ++li;
+    // Instances in index order (first maximum wins, resnet_upsnet.py:241-243). An instance that touches this tile nowhere has the
+    // logit 0 at every pixel of it; of all those only the FIRST (index u0) can ever become the arg-max (the others are not strictly
+    // greater), so the loop visits the touching instances only and drops the one zero candidate in at its place in the order --
+    // O(instances touching the tile) per pixel instead of O(k).
+    bool zero_done = u0 >= k;
+    for (int li = 0; li <= nlist; ++li) {
+        const int j = li < nlist ? s_list[li] : k;
+        if (!zero_done && u0 < j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (0.f > best[q]) { best[q] = 0.f; bi[q] = s_stuff + u0; }
+            zero_done = true;
+        }
+        if (li == nlist) break;
+        const FuseInst &fi = s_inst[j];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int x = x0 + q;
             float si = 0.f, mk = 0.f;
             bool inseg = false;
-            if (listed && x < W) {
-                const FuseInst &fi = s_inst[j];
+            if (x < W) {
                 if (fi.sem_ch >= 0 && y >= fi.sb.y0 && y < fi.sb.y1 && x >= fi.sb.x0 && x < fi.sb.x1) { si = FUP_AT(fi.sem_ch, q); inseg = true; }
                 if (real && y >= fi.mb.y_0 && y < fi.mb.y_1 && x >= fi.mb.x_0 && x < fi.mb.x_1)
                     mk = pan_resize_at(logits + fi.logit_off, ms, fi.mb.w, fi.mb.h, x - fi.mb.bx0, y - fi.mb.by0);

@@ -164,7 +164,7 @@ prop_compact_kernel(const PropLevels lv, const ups_u64 *__restrict__ keys, PropS
 }
 
 // one workgroup per level: sort the (<= k) survivors descending, zero-pad to k
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 prop_sortk_kernel(const PropLevels lv, const PropSel *__restrict__ sel, ups_u64 *__restrict__ out, const int k, const int M)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -173,7 +173,7 @@ prop_sortk_kernel(const PropLevels lv, const PropSel *__restrict__ sel, ups_u64 
     const int c = (int)min(sel[l].cnt, (unsigned)k);
     ups_u64 *__restrict__ buf = out + lv.key_off[l];
     for (int i = threadIdx.x; i < M; i += blockDim.x) keys[i] = i < c ? buf[i] : 0ULL;
-    ups_block_sort_desc(keys, M);
+    ups_block_sort_desc(keys, M);     // (one key per thread at M = 1024: 34 -> ~16 us vs the 256-thread launch of r07)
     for (int i = threadIdx.x; i < k; i += blockDim.x) buf[i] = keys[i];
 }
 
@@ -215,7 +215,12 @@ prop_decode_kernel(const PropLevels lv, const ups_u64 *keys, int pre_n, const fl
     pre_removed[(long)l * pre_n + i] = !((ws >= ms) && (hs >= ms));
 }
 
-// single workgroup: concatenate per-level kept boxes (<= post_n each), rank by (score desc, concat idx asc)
+// single workgroup: concatenate per-level kept boxes (<= post_n each), rank by (score desc, concat idx asc), keep the first post_n.
+// Every level's kept list is already in that order (the NMS keeps in visiting order = score descending, the concatenation index grows
+// along the list), so the ranking is a MERGE of nlev sorted runs, not a sort: the rank of an element is its position in its own run
+// plus, for every other run, the number of keys there that precede it -- one binary search per other run (nlev - 1 searches of ~10
+// LDS reads), all elements in parallel, no barrier after the key gather. (r01-r07: an 8192-key bitonic sort, 91 barrier-separated
+// compare-exchange steps = 59-65 us; this is ~10.) Unique keys (score bits << 32 | ~index): same order as the sort, bit for bit.
 __global__ void __launch_bounds__(1024)
 prop_merge_kernel(const int nlev, const int pre_n, const int post_n, const float *__restrict__ boxes,
                   const float *__restrict__ scores, const int *__restrict__ keep_idx, const int *__restrict__ keep_cnt,
@@ -231,32 +236,40 @@ prop_merge_kernel(const int nlev, const int pre_n, const int post_n, const float
     }
     __syncthreads();
     const int total = s_start[nlev];
-    const int M = ups_next_pow2(total < 64 ? 64 : total);
-    for (int i = threadIdx.x; i < M; i += blockDim.x) {
-        ups_u64 k = 0;
-        if (i < total) {
-            int l = 0;
-            for (int q = 1; q < nlev; ++q) if (i >= s_start[q]) l = q;
-            const int src = keep_idx[(long)l * pre_n + (i - s_start[l])];
-            k = ups_make_key(scores[(long)l * pre_n + src], (unsigned)i, 1);
-        }
-        keys[i] = k;
-    }
-    ups_block_sort_desc(keys, M);
     const int nout = min(total, post_n);
-    for (int i = threadIdx.x; i < post_n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int l = 0;
+        for (int q = 1; q < nlev; ++q) if (i >= s_start[q]) l = q;
+        const int src = keep_idx[(long)l * pre_n + (i - s_start[l])];
+        keys[i] = ups_make_key(scores[(long)l * pre_n + src], (unsigned)i, 1);
+    }
+    // rows beyond the merged count: defined output (zeros)
+    for (int i = nout + threadIdx.x; i < post_n; i += blockDim.x) {
         float *r = rois_out + (long)i * 5;
-        if (i < nout) {
-            const int ci = (int)ups_key_index(keys[i], 1);
-            int l = 0;
-            for (int q = 1; q < nlev; ++q) if (ci >= s_start[q]) l = q;
-            const int src = keep_idx[(long)l * pre_n + (ci - s_start[l])];
+        r[0] = r[1] = r[2] = r[3] = r[4] = 0.f;
+        scores_out[i] = 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int l = 0;
+        for (int q = 1; q < nlev; ++q) if (i >= s_start[q]) l = q;
+        const ups_u64 key = keys[i];
+        int rank = i - s_start[l];
+        for (int q = 0; q < nlev; ++q) {
+            if (q == l) continue;
+            int lo = s_start[q], hi = s_start[q + 1];         // first position of run q whose key does NOT precede `key`
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys[mid] > key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo - s_start[q];
+        }
+        if (rank < post_n) {
+            const int src = keep_idx[(long)l * pre_n + (i - s_start[l])];
             const float *b = boxes + ((long)l * pre_n + src) * 4;
+            float *r = rois_out + (long)rank * 5;
             r[0] = 0.f; r[1] = b[0]; r[2] = b[1]; r[3] = b[2]; r[4] = b[3];
-            scores_out[i] = scores[(long)l * pre_n + src];
-        } else {
-            r[0] = r[1] = r[2] = r[3] = r[4] = 0.f;
-            scores_out[i] = 0.f;
+            scores_out[rank] = scores[(long)l * pre_n + src];
         }
     }
     if (threadIdx.x == 0) *num_out = nout;
@@ -381,7 +394,7 @@ extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const fl
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(prop_sortk_kernel, dim3(nlev), dim3(256), (size_t)M2 * 8, st, lv, sel, kbuf[1], pre_n, M2);
+    hipLaunchKernelGGL(prop_sortk_kernel, dim3(nlev), dim3(M2 < 1024 ? M2 : 1024), (size_t)M2 * 8, st, lv, sel, kbuf[1], pre_n, M2);
     UPS_CHECK_LAUNCH("prop_sortk_kernel");
     const int cur = 1;
     // every level now holds its pre_n sorted keys (zero padded) at key_off[l] of kbuf[1]
