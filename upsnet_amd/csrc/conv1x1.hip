@@ -165,59 +165,70 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 #undef C1_FRAG
 
     // ---- epilogue: + bias, + residual (RESUP: through the nearest x2 upsampling), ReLU, NHWC store. Accumulator element r of
-    // lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3), column l32 of the 32x32 block
+    // lane (lhalf, l32): row 8 (r >> 2) + 4 lhalf + (r & 3), column l32 of the 32x32 block.
+    // r08: residual loads and stores go through buffer descriptors: one loop-invariant lane offset (its column + its row half) and a
+    // SCALAR row offset per element -- no 64-bit address arithmetic per element (r07: ~8 VALU instructions for each of the 64 loads /
+    // stores of a lane, and 5 spilled registers in the 128-wide form); rows beyond the map and padded columns are out-of-range
+    // offsets (loads return 0, stores are dropped), so there is no per-element predicate either.
     const int co = 32 * cb + l32;
     const bool co_ok = co < p.Cout;
-    const int coc = co_ok ? co : 0;
-    const float bv = p.bias != nullptr ? p.bias[coc] : 0.f;
+    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
     const bool has_res = sg.res != nullptr;
+    const unsigned crow = (unsigned)p.Cout * 4u;                        // bytes of one output pixel
+    const unsigned lane_off = co_ok ? (4u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
+    const size_t oaddr = reinterpret_cast<size_t>(sg.out);
+    const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)oaddr), ohi = __builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32));
+    const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)sg.M * crow);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)ohi << 32) | olo), 0, (int)obytes, 0x00020000);
+    const size_t raddr = reinterpret_cast<size_t>(has_res ? sg.res : sg.out);
+    const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)raddr), rhi = __builtin_amdgcn_readfirstlane((unsigned)(raddr >> 32));
     const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
+    const unsigned rbytes = __builtin_amdgcn_readfirstlane(RESUP ? (unsigned)(sg.N * Hr * Wr) * crow : obytes);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)rhi << 32) | rlo), 0, (int)rbytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const long pbase = p0 + 32 * (NR == 2 ? i : wm) + 4 * lhalf;
+        const long pb0 = p0 + 32 * (NR == 2 ? i : wm);                 // first of the 32 consecutive output pixels of this block (wave-uniform)
+        const unsigned row0 = (unsigned)pb0 * crow;
         float rr[16];
         if (has_res) {
-            long ridx[16];
-            if (RESUP) {
-                // the 32 rows of this block are consecutive output pixels starting at a multiple of 32. Wo % 32 == 0 (every FPN
-                // level of the workloads): they lie in one image row, so the half-resolution source is one base + (column >> 1)
-                // -- no division per row. Other widths: the general decomposition, one row at a time.
-                const long pb0 = p0 + 32 * (NR == 2 ? i : wm);
-                if ((sg.Wo & 31) == 0) {
-                    const long pb = pb0 < sg.M ? pb0 : 0;
-                    const int n_b = (int)(pb / HoWo);
-                    const int rem_b = (int)(pb - (long)n_b * HoWo);
-                    const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;      // w_b: multiple of 32
-                    const long rb = ((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1) + 2 * lhalf;
+            if (RESUP && (sg.Wo & 31) == 0) {
+                // Wo % 32 == 0 (every FPN level of the workloads): the 32 rows lie in one image row, the half-resolution source is one
+                // base + (column >> 1) -- no division per row; the lane's row half (4 lhalf) shifts the source column by 2 lhalf
+                const long pb = pb0 < sg.M ? pb0 : 0;
+                const int n_b = (int)(pb / HoWo);
+                const int rem_b = (int)(pb - (long)n_b * HoWo);
+                const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;      // w_b: multiple of 32
+                const unsigned rb = (unsigned)(((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1)) * crow;
+                const unsigned lane_r = co_ok ? (2u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ridx[r] = rb + (((r & 3) + 8 * (r >> 2)) >> 1);
-                } else {
+                for (int r = 0; r < 16; ++r)
+                    rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, pb0 < sg.M ? lane_r : 0x80000000u,
+                                                                                  rb + (unsigned)(((r & 3) + 8 * (r >> 2)) >> 1) * crow, 0));
+            } else if (RESUP) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        long pp = pbase + (r & 3) + 8 * (r >> 2);
-                        pp = pp < sg.M ? pp : sg.M - 1;
-                        const int n = (int)(pp / HoWo);
-                        const int rem = (int)(pp - (long)n * HoWo);
-                        const int h = rem / sg.Wo, w = rem - h * sg.Wo;
-                        ridx[r] = ((long)n * Hr + (h >> 1)) * Wr + (w >> 1);
-                    }
+                for (int r = 0; r < 16; ++r) {   // general decomposition, one row at a time
+                    long pp = pb0 + 4 * lhalf + (r & 3) + 8 * (r >> 2);
+                    const bool ok = pp < sg.M && co_ok;
+                    pp = pp < sg.M ? pp : sg.M - 1;
+                    const int n = (int)(pp / HoWo);
+                    const int rem = (int)(pp - (long)n * HoWo);
+                    const int h = rem / sg.Wo, w = rem - h * sg.Wo;
+                    const unsigned ri = (unsigned)(((long)n * Hr + (h >> 1)) * Wr + (w >> 1));
+                    rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? ri * crow + 4u * (unsigned)co : 0x80000000u, 0, 0));
                 }
-            }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                long pp = pbase + (r & 3) + 8 * (r >> 2);
-                pp = pp < sg.M ? pp : sg.M - 1;
-                rr[r] = sg.res[(RESUP ? ridx[r] : pp) * p.Cout + coc];
+                for (int r = 0; r < 16; ++r)
+                    rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, lane_off, row0 + (unsigned)((r & 3) + 8 * (r >> 2)) * crow, 0));
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long pp = pbase + (r & 3) + 8 * (r >> 2);
             float v = i == 0 ? acc0[r] : acc1[r];
             if (p.bias != nullptr) v = v + bv;
             if (has_res) v = v + rr[r];
             if (p.relu) v = fmaxf(v, 0.f);
-            if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, lane_off, row0 + (unsigned)((r & 3) + 8 * (r >> 2)) * crow, 0);
         }
     }
 }
@@ -241,6 +252,7 @@ extern "C" int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const 
                        1, 1, stride, 0, 1, relu);
     if (rc) return rc;
     UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "conv1x1_frag_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    UPS_REQUIRE((long)p.seg[0].M * Cout < (1L << 29), "conv1x1_frag_nhwc_f32: output exceeds 2 GiB; split the batch");
     if (residual_up) {
         UPS_REQUIRE(residual, "conv1x1_frag_nhwc_f32: residual_up without a residual");
         UPS_REQUIRE(p.seg[0].Ho % 2 == 0 && p.seg[0].Wo % 2 == 0, "conv1x1_frag_nhwc_f32: residual_up needs even output dims");
