@@ -406,13 +406,24 @@ conv_igemm_f32_kernel(const ConvParams p)
     constexpr bool res_up = RESUP == 1, scatter = RESUP == 2;
     const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
     const int Cr = p.Cout >> 2;   // scatter: real output channels
+    // r08: residual loads and stores through buffer descriptors with 32-bit byte offsets (no 64-bit index per element); an element
+    // beyond the map / a padded column is an out-of-range offset: the load returns 0, the store is dropped.
+    const unsigned crow = (unsigned)(scatter ? Cr : p.Cout) * 4u;       // bytes of one output pixel
+    const size_t oaddr = reinterpret_cast<size_t>(sg.out);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)oaddr)),
+        0, (int)__builtin_amdgcn_readfirstlane((unsigned)sg.M * (unsigned)p.Cout * 4u), 0x00020000);   // (scatter: 4 M pixels of Cout / 4 channels)
+    const size_t raddr = reinterpret_cast<size_t>(has_res ? sg.res : sg.out);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(raddr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)raddr)),
+        0, (int)__builtin_amdgcn_readfirstlane((unsigned)(res_up ? (long)sg.N * Hr * Wr : sg.M) * (unsigned)p.Cout * 4u), 0x00020000);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const long pbase = p0 + wm * (WM * 32) + 32 * i + 4 * akr;
         // pixel coordinates of this thread's 16 rows (only for the two coordinate-dependent epilogues): one division for the
         // first row; the other rows (offsets <= 27) are reached by increments with at most one line / image wrap when
         // Wo >= 32 (otherwise divide per row)
-        long ridx[16];
+        unsigned ridx[16];      // res_up: half-resolution source pixel; scatter: top-left pixel of the 2x2 output block
         if (RESUP != 0) {
             const long pb = pbase < sg.M ? pbase : sg.M - 1;
             const int n_b = (int)(pb / HoWo);
@@ -435,8 +446,8 @@ conv_igemm_f32_kernel(const ConvParams p)
                         h = rem / sg.Wo; w = rem - h * sg.Wo;
                     }
                 }
-                ridx[r] = res_up ? ((long)n * Hr + (h >> 1)) * Wr + (w >> 1)
-                                 : ((long)n * 2 * sg.Ho + 2 * h) * (2 * sg.Wo) + 2 * w;
+                ridx[r] = res_up ? (unsigned)((n * Hr + (h >> 1)) * Wr + (w >> 1))
+                                 : (unsigned)((n * 2 * sg.Ho + 2 * h) * (2 * sg.Wo) + 2 * w);
             }
         }
 #pragma unroll
@@ -445,20 +456,21 @@ conv_igemm_f32_kernel(const ConvParams p)
             const bool co_ok = co < p.Cout;
             const int coc = co_ok ? co : 0;
             int cb = coc;          // bias / output channel
-            long soff = 0;         // scatter: element offset of (dy, dx) inside the 2x upsampled map
+            unsigned soff = 0;     // scatter: byte offset of (dy, dx, channel) inside the 2x upsampled map
             if (scatter) {
                 const int q = coc / Cr;
                 cb = coc - q * Cr;
-                soff = ((long)(q >> 1) * (2 * sg.Wo) + (q & 1)) * Cr + cb;
+                soff = (unsigned)(((q >> 1) * (2 * sg.Wo) + (q & 1)) * Cr + cb) * 4u;
             }
             const float bv = has_bias ? p.bias[cb] : 0.f;
             float rr[16];
             if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    long pp = pbase + (r & 3) + 8 * (r >> 2);
-                    pp = pp < sg.M ? pp : sg.M - 1;
-                    rr[r] = sg.res[(res_up ? ridx[r] : pp) * p.Cout + coc];
+                    const long pp = pbase + (r & 3) + 8 * (r >> 2);
+                    const bool ok = co_ok && pp < sg.M;
+                    const unsigned src = res_up ? ridx[r] : (unsigned)pp;
+                    rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? src * ((unsigned)p.Cout * 4u) + 4u * (unsigned)co : 0x80000000u, 0, 0));
                 }
             }
 #pragma unroll
@@ -468,10 +480,9 @@ conv_igemm_f32_kernel(const ConvParams p)
                 if (has_bias) v = v + bv;
                 if (has_res) v = v + rr[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (co_ok && pp < sg.M) {
-                    if (scatter) sg.out[ridx[r] * Cr + soff] = v;
-                    else sg.out[pp * p.Cout + co] = v;
-                }
+                const bool ok = co_ok && pp < sg.M;
+                const unsigned dst = scatter ? ridx[r] * crow + soff : (unsigned)pp * crow + 4u * (unsigned)co;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? dst : 0x80000000u, 0, 0);
             }
         }
     }

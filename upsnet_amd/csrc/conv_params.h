@@ -59,6 +59,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
             UPS_REQUIRE(s.Ho > 0 && s.Wo > 0, "%s: empty output for feature map %d", who, i);
             UPS_REQUIRE((long)nb * height[i] * width[i] * Cin < (1L << 30), "%s: feature map %d exceeds 4 GiB (32-bit byte offsets); split the batch", who, i);
             s.M = (long)nb * s.Ho * s.Wo;
+            UPS_REQUIRE(s.M * Cout < (1L << 29), "%s: output %d exceeds 2 GiB (32-bit byte offsets in the epilogue); split the batch", who, i);
             s.tile_start = tiles;
             tiles += (int)((s.M + 127) / 128);
         } else {

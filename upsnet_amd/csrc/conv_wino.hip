@@ -251,27 +251,35 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
         const int rem_ = (int)(pp_ - (long)N_ * HoWo);                                                                \
         H_ = rem_ / sg.Wo; W_ = rem_ - H_ * sg.Wo;                                                                    \
     }
-    // one output row (two pixels) of a tile: + bias, + residual, ReLU, store (split-K: raw partial sums)
+    // one output row (two pixels) of a tile: + bias, + residual, ReLU, store (split-K: raw partial sums). r08: 32-bit byte offsets
+    // through buffer descriptors (r07 built a 64-bit element index per row: ~15 VALU instructions for each of the 16-32 rows of a
+    // lane); the second pixel of a row that falls beyond the map is an out-of-range offset (load 0 / store dropped).
+    const unsigned crow = (unsigned)p.Cout * 4u;
+    const unsigned co4 = 4u * (unsigned)co;
+    const size_t oaddr_ = reinterpret_cast<size_t>(SPLITK ? (float *)(p.partial + (long)kz * p.m_total * p.Cout) : sg.out);
+    const unsigned obytes_ = __builtin_amdgcn_readfirstlane((unsigned)(SPLITK ? p.m_total : (long)sg.N * sg.OH * sg.OW) * crow);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(oaddr_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)oaddr_)),
+        0, (int)obytes_, 0x00020000);
+    const size_t raddr_ = reinterpret_cast<size_t>(has_res ? sg.res : sg.out);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(raddr_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)raddr_)),
+        0, (int)__builtin_amdgcn_readfirstlane((unsigned)((long)sg.N * sg.OH * sg.OW) * crow), 0x00020000);
 #define WG_STORE_ROW(N_, OY, OX, V0, V1)                                                                              \
     if ((OY) < sg.OH) {                                                                                               \
         float v0_ = (V0), v1_ = (V1);                                                                                 \
-        const bool x1_ = (OX) + 1 < sg.OW;                                                                            \
-        const long o0_ = (((long)(N_) * sg.OH + (OY)) * sg.OW + (OX)) * p.Cout + co;                                  \
-        const long o1_ = o0_ + p.Cout;                                                                                \
-        if (SPLITK) {                                                                                                 \
-            float *part_ = p.partial + (long)kz * p.m_total * p.Cout;                                                 \
-            part_[o0_] = v0_;                                                                                         \
-            if (x1_) part_[o1_] = v1_;                                                                                \
-        } else {                                                                                                      \
+        const unsigned o0_ = (unsigned)(((N_) * sg.OH + (OY)) * sg.OW + (OX)) * crow + co4;                           \
+        const unsigned o1_ = ((OX) + 1 < sg.OW) ? o0_ + crow : 0x80000000u;                                           \
+        if (!SPLITK) {                                                                                                \
             v0_ = v0_ + bv; v1_ = v1_ + bv;                                                                           \
             if (has_res) {                                                                                            \
-                v0_ = v0_ + sg.res[o0_];                                                                              \
-                if (x1_) v1_ = v1_ + sg.res[o1_];                                                                     \
+                v0_ = v0_ + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, o0_, 0, 0));                  \
+                v1_ = v1_ + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, o1_, 0, 0));                  \
             }                                                                                                         \
             if (p.relu) { v0_ = fmaxf(v0_, 0.f); v1_ = fmaxf(v1_, 0.f); }                                             \
-            sg.out[o0_] = v0_;                                                                                        \
-            if (x1_) sg.out[o1_] = v1_;                                                                               \
         }                                                                                                             \
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0_), orsrc, o0_, 0, 0);                                \
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1_), orsrc, o1_, 0, 0);                                \
     }
     if constexpr (NX == 2) {
         float4 *mine = reinterpret_cast<float4 *>(smem_raw + pair * 32768 + xh_u * 16384) + lane;
@@ -358,8 +366,10 @@ int g_wino_tm = 0;   // 0 auto; 32 / 64 forced (upsnet_conv_tuning, A/B runs)
 static int conv_wino16_launch(hipStream_t st, ConvParams &p)
 {
     UPS_REQUIRE(p.Cin % 16 == 0 && (p.ldw == 32 || p.ldw % 64 == 0), "conv2d_winograd_nhwc_f32: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
-    for (int i = 0; i < p.nseg; ++i)
+    for (int i = 0; i < p.nseg; ++i) {
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].OH * p.seg[i].OW * p.Cout < (1L << 29), "conv2d_winograd_nhwc_f32: output %d exceeds 2 GiB; split the batch", i);
+    }
     if (p.ksplit > 1) {
         const int nslabs = p.Cin / 16;
         UPS_REQUIRE(p.nseg == 1 && p.partial, "conv2d_winograd_nhwc_f32_splitk: one map and a workspace");

@@ -374,21 +374,28 @@ __global__ void __launch_bounds__(256, WPE) dcn_fused_f32_kernel(const ConvParam
     const int co = 32 * cb + l32;
     const bool co_ok = co < p.Cout;
     const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+    // (r08: 32-bit byte offsets through a buffer descriptor; a pixel beyond the map / a padded column is an out-of-range offset)
+    const unsigned crow = (unsigned)p.Cout * 4u;
+    const bool split = p.ksplit > 1;
+    const size_t oaddr = reinterpret_cast<size_t>(split ? (float *)(p.partial + (long)kz * p.m_total * p.Cout) : sg.out);
+    const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)(split ? p.m_total : (long)sg.N * sg.Ho * sg.Wo) * crow);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)oaddr)),
+        0, (int)obytes, 0x00020000);
+    const unsigned tile0 = (unsigned)((t_n * sg.Ho + 8 * t_y) * sg.Wo + 8 * t_x) * crow + 4u * (unsigned)co;   // tile origin + the lane's column
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int px = 32 * i + 4 * lhalf + (r & 3) + 8 * (r >> 2);       // = tile row 4 i + (r >> 2), column 4 lhalf + (r & 3)
-            const int ho = 8 * t_y + (px >> 3), wo = 8 * t_x + (px & 7);
+            const int dy = px >> 3, dx = px & 7;
             float v = i == 0 ? acc0[r] : acc1[r];
-            const long pp = ((long)t_n * sg.Ho + ho) * sg.Wo + wo;
-            if (p.ksplit > 1) {   // raw partial sums [kz][pixel][Cout]; bias / ReLU in the reduce kernel
-                if (co_ok && ho < sg.Ho && wo < sg.Wo) p.partial[((long)kz * p.m_total + pp) * p.Cout + co] = v;
-                continue;
+            if (!split) {         // (split-K: raw partial sums [kz][pixel][Cout]; bias / ReLU in the reduce kernel)
+                v = v + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
             }
-            v = v + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (co_ok && ho < sg.Ho && wo < sg.Wo) sg.out[pp * p.Cout + co] = v;
+            const bool ok = co_ok && 8 * t_y + dy < sg.Ho && 8 * t_x + dx < sg.Wo;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? tile0 + (unsigned)(dy * sg.Wo + dx) * crow : 0x80000000u, 0, 0);
         }
     }
 }
@@ -411,8 +418,10 @@ static int dcn_fused_launch(void *stream, int nlev, const float *const x[], cons
     int rc = conv_fill(p, "deform_conv_fused_nhwc", nlev, x, nullptr, offset, mask, out, nullptr, height, width, cin, cout, wpack, ldw, bias,
                        kh, kw, stride, pad, dil, relu);
     if (rc) return rc;
-    for (int i = 0; i < p.nseg; ++i)   // bit 31 of a corner offset flags "outside the image": offsets of real pixels must stay below it
+    for (int i = 0; i < p.nseg; ++i) {   // bit 31 of a corner offset flags "outside the image": offsets of real pixels must stay below it
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * cin < (1L << 29), "deform_conv_fused_nhwc: feature map %d exceeds 2 GiB; split the batch", i);
+        UPS_REQUIRE((long)p.seg[i].N * p.seg[i].Ho * p.seg[i].Wo * cout < (1L << 29), "deform_conv_fused_nhwc: output %d exceeds 2 GiB; split the batch", i);
+    }
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) {   // 8 x 8 pixel tiles
         p.seg[i].tile_start = tiles;
