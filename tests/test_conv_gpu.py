@@ -354,6 +354,82 @@ def test_conv_bf16_matrix_cores_vs_torch(N, Cin, Cout, H, W, k, stride, pad, rel
     assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,pad,relu,res", [
+    (1, 256, 64, 40, 56, 1, 1, 0, True, None), (1, 64, 256, 40, 56, 1, 1, 0, True, 'bf16'), (1, 256, 512, 41, 57, 1, 2, 0, False, None),
+    (1, 512, 128, 24, 40, 1, 1, 0, True, 'fp32'), (2, 128, 128, 19, 33, 3, 1, 1, True, None), (1, 64, 64, 16, 32, 3, 1, 1, True, None),
+    (1, 2048, 256, 8, 16, 1, 1, 0, False, None), (1, 128, 160, 37, 45, 3, 1, 1, False, 'bf16'),
+])
+@pytest.mark.parametrize("in16,out16", [(True, True), (True, False), (False, True)])
+def test_conv_bf16_activations(N, Cin, Cout, H, W, k, stride, pad, relu, res, in16, out16):
+    """bf16 mode with bf16 ACTIVATIONS between layers (r08): bf16 NHWC inputs are loaded unconverted (8 channels per 16 bytes), a
+    bf16 residual is widened in the epilogue, and the fp32 accumulator + bias + residual + ReLU is rounded ONCE to the bf16 output.
+    Reference: the same convolution in float64 on the bf16-rounded operands; a bf16 result must be within one rounding of it."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + Cout + H + k)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cout, Cin, k, k, device='cuda') / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    xin = x.bfloat16() if in16 else x
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = None
+    if res is not None:
+        r = torch.randn(N, Cout, Ho, Wo, device='cuda')
+        r = r.bfloat16() if res == 'bf16' else r
+    ref = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), b.double(), stride=stride, padding=pad)
+    if r is not None:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    hi, lo, ldw = ops.pack_conv_weight_bf16(w, split=False)
+    out = ops.conv2d_nhwc_bf16_multi([xin], hi, None, ldw, b, Cout, k, stride, pad, relu=relu, residuals=None if r is None else [r],
+                                     out_dtype=torch.bfloat16 if out16 else torch.float32)[0]
+    assert out.shape == ref.shape and out.dtype == (torch.bfloat16 if out16 else torch.float32)
+    assert out.permute(0, 2, 3, 1).is_contiguous()
+    got, want = out.double().cpu().numpy(), ref.cpu().numpy()
+    if not in16:      # fp32 input rounded inside the kernel: same operands as the reference
+        pass
+    tol = 2.0 ** -8 if out16 else 1e-4     # bf16: one rounding (8 significant bits) of an fp32-accurate value
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+    again = ops.conv2d_nhwc_bf16_multi([xin], hi, None, ldw, b, Cout, k, stride, pad, relu=relu, residuals=None if r is None else [r],
+                                       out_dtype=torch.bfloat16 if out16 else torch.float32)[0]
+    assert torch.equal(again, out)
+
+
+def test_backbone_block_keeps_bf16_activations_between_layers():
+    """models/resnet.py in the bf16 mode: a bottleneck stage reads the fp32 stem output, runs every layer on the bf16 kernels with
+    bf16 tensors in between (conv1 -> conv2 -> conv3 + bf16 shortcut) and returns bf16; against the fp32-mode stage within bf16
+    accuracy of the activations' scale."""
+    from upsnet_amd.models import hipconv
+    from upsnet_amd.models.resnet import res_block, fold_frozen_bn
+    torch.manual_seed(3)
+    stage = res_block(128, 2, stride=2).cuda().eval()
+    saved_min, hipconv.BF16_MIN_WG = hipconv.BF16_MIN_WG, 0        # (a test-size map has few tiles: take the bf16 kernels anyway)
+    with torch.no_grad():
+        for m in stage.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.fill_(0.5)
+                m.weight.fill_(0.7)
+    fold_frozen_bn(stage)
+    stage = stage.to(memory_format=torch.channels_last)
+    x = torch.randn(1, 256, 48, 64, device='cuda').contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = stage(x)
+        hipconv.PRECISION = 'bf16'
+        try:
+            assert hipconv.act_dtype() == torch.bfloat16
+            hipconv.TRACE = []
+            out = stage(x)
+            trace, hipconv.TRACE = hipconv.TRACE, None
+        finally:
+            hipconv.PRECISION = 'fp32'
+            hipconv.TRACE = None
+            hipconv.BF16_MIN_WG = saved_min
+    assert ref.dtype == torch.float32 and out.dtype == torch.bfloat16
+    assert all(r['out'].dtype == torch.bfloat16 for r in trace) and trace[0]['x'].dtype == torch.float32 and trace[-1]['x'].dtype == torch.bfloat16
+    scale = float(ref.abs().max())
+    assert float((out.float() - ref).abs().max()) < 0.03 * scale
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,split", [(1, 256, 256, 32, 64, True), (2, 512, 256, 18, 22, True), (1, 64, 96, 6, 10, False)])
 def test_conv_bf16_lateral_with_upsampled_residual(N, Cin, Cout, H, W, split):
     """FPN top-down add on the bf16 kernel: conv1x1(x) + nearest_up2(residual) with the upsampling folded into the residual read

@@ -7,8 +7,11 @@
 //   SPLIT 3 ("bf16x3")  a = a_hi + a_lo, b = b_hi + b_lo (both parts bf16), a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi: the dropped
 //                       term is ~2^-16 relative, the sum is accumulated in fp32 -- within the 1e-4 fp32-logit tolerance of the
 //                       north star, at 3/16 of the MFMA time of exact fp32 products.
-// Activations stay fp32 in HBM (NHWC, same tensors as the fp32 path); they are split to bf16 when the staged registers are
-// written to LDS. Weights are split and packed once (upsnet_conv_pack_weight_bf16) as [K slab][column][32 k], so a lane's MFMA
+// Activations are fp32 in HBM by default (NHWC, same tensors as the fp32 path) and are rounded / split to bf16 when the staged
+// registers are written to LDS. r08 (bf16 mode only): a layer may also READ a bf16 NHWC tensor (IO bit 0: 16-byte loads carry 8
+// channels and go to LDS unconverted), WRITE bf16 (IO bit 1: fp32 accumulator + bias + residual + ReLU, rounded once) and add a
+// bf16 residual (run-time flag) -- the backbone then keeps its activations in bf16 between layers: the 1x1 layers of the bf16
+// mode were HBM-bound on fp32 activations (res3 conv3: 151 MB for 4.3 GFLOP = 40 us at 4 TB/s, 4 % of the bf16 MFMA peak). Weights are split and packed once (upsnet_conv_pack_weight_bf16) as [K slab][column][32 k], so a lane's MFMA
 // operand (8 consecutive k of one row / column) is ONE 16-byte LDS read: As/Bs are [64 rows][32 k] bf16 with an 80-byte row
 // pitch (conflict-free ds_read_b128). Workgroup = 64 pixels x 64 channels, 4 waves (32 x 32 each), K slabs of one tap x 32
 // channels, double-buffered LDS, loads of slab s+1 in flight while slab s is contracted, one barrier per slab; operand
@@ -41,6 +44,35 @@ __device__ static inline void cb_split4(const float4 v, const bool valid, bf16x4
     }
 }
 
+// epilogue helpers: buffer descriptor over a tensor, element load (fp32 or bf16 -> fp32), element store (fp32 or bf16); an element
+// index of 0x3FFFFFFF is beyond every tensor (x 4 and x 2 bytes both exceed the 2 GiB limit of the entry point without wrapping): the load returns 0, the store is dropped
+__device__ static inline __amdgpu_buffer_rsrc_t cb_rsrc(const void *ptr, const unsigned bytes)
+{
+    const size_t a = reinterpret_cast<size_t>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ static inline float cb_load_elem(const __amdgpu_buffer_rsrc_t r, const unsigned elem, const bool is16)
+{
+    if (is16) {
+        const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r, elem * 2u, 0, 0);
+        return __uint_as_float((unsigned)b << 16);
+    }
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4u, 0, 0));
+}
+template <bool IS16>
+__device__ static inline void cb_store_elem(const __amdgpu_buffer_rsrc_t r, const unsigned elem, const float v)
+{
+    if (IS16) {
+        const __bf16 h = (__bf16)v;      // round to nearest even
+        unsigned short b;
+        __builtin_memcpy(&b, &h, 2);
+        __builtin_amdgcn_raw_buffer_store_b16(b, r, elem * 2u, 0, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, elem * 4u, 0, 0);
+    }
+}
+
 // Tile (r06): 128 pixels x 128 channels per workgroup, 4 waves of 64 x 64 (2 x 2 MFMA blocks, 64 accumulator registers). The r01
 // form (64 x 64 per workgroup, 32 x 32 per wave) moved 16 KiB from L2 for every 2 MFMAs of a wave: 21.8 flop per L2 byte, i.e.
 // 20 TB/s of L2 traffic at the 445 TFLOP/s it reached -- it was L2-bound at 18 % of the bf16 peak. This form doubles the
@@ -48,11 +80,14 @@ __device__ static inline void cb_split4(const float4 v, const bool valid, bf16x4
 // 24 (bf16x3) MFMAs per wave between two barriers instead of 2 / 6, and reads 4 LDS fragments per 4 / 12 MFMAs instead of 2 per 1 / 3.
 // WN: 32-column MFMA blocks per wave: 2 -> 128 output channels per workgroup (used by both modes: 69 KiB of LDS for bf16x3 with
 // the unpadded swizzled rows = two workgroups per CU), 1 -> 64 (kept for measurements: slower, 629 vs ~520 us on FPN P2).
-template <int SPLIT, int WN>
+template <int SPLIT, int WN, int IO = 0>
 __global__ void __launch_bounds__(256, 2)
 conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
 {
     constexpr int BN = 64 * WN;
+    constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+    constexpr unsigned XB = IN16 ? 2u : 4u;      // bytes per input element
+    static_assert(!(IN16 && SPLIT == 3), "bf16 inputs carry no low part");
     __shared__ __attribute__((aligned(16))) __bf16 Ah[2][CB_BM][CB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BN][CB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? CB_BM : 1][CB_PITCH];
@@ -97,13 +132,13 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
             const int rem = (int)(pp - (long)n * HoWo);
             const int ki = tap / p.KW, kj = tap - ki * p.KW;
             const int hi = (rem / sg.Wo) * p.stride - p.pad + ki * p.dil, wi = (rem % sg.Wo) * p.stride - p.pad + kj * p.dil;
-            if (hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W) o = 4u * (unsigned)(((n * sg.H + hi) * sg.W + wi) * p.Cin);
+            if (hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W) o = XB * (unsigned)(((n * sg.H + hi) * sg.W + wi) * p.Cin);
         }
         toff[tap][px] = o;
     }
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
-    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * XB * (unsigned)p.Cin);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
     // B staging: thread -> 8 consecutive k (one 16-byte octet) of columns bcol and bcol + 64
     const int bcol = tid >> 2, boct = tid & 3;
@@ -114,6 +149,9 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
 
     int f_cs = 0, f_tap = 0;   // (channel slab, tap) of the next step to fetch
     float4 ra0, ra1, ra2, ra3;
+    // bf16 inputs: thread -> octet (8 channels, 16 bytes) oct16 of pixels prow16 and prow16 + 64: two loads, two ds_write_b128
+    const int oct16 = tid & 3, prow16 = tid >> 2;
+    uintx4 rx0, rx1;
     uint4 rbh0, rbh1, rbl0, rbl1;
     const unsigned ob64 = 64u * CB_BK * 2u;   // byte distance of column bcol + 64 inside a slab
 
@@ -130,9 +168,15 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
 #define CB_FETCH                                                                                          \
     {                                                                                                     \
+        if (IN16) {                                                                                       \
+            const unsigned c_ = (unsigned)(f_cs * (CB_BK * 2) + oct16 * 16);                              \
+            rx0 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff[f_tap][prow16] + c_, 0, 0);           \
+            rx1 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, toff[f_tap][prow16 + 64] + c_, 0, 0);      \
+        } else {                                                                                          \
         const unsigned c_ = (unsigned)(f_cs * (CB_BK * 4) + ch4 * 16);                                    \
         CB_LDX(ra0, toff[f_tap][prow] + c_) CB_LDX(ra1, toff[f_tap][prow + 32] + c_)                      \
         CB_LDX(ra2, toff[f_tap][prow + 64] + c_) CB_LDX(ra3, toff[f_tap][prow + 96] + c_)                 \
+        }                                                                                                 \
         const unsigned ob = ob0 + (unsigned)(f_tap * cslabs + f_cs) * slab_bytes;                         \
         rbh0 = *reinterpret_cast<const uint4 *>(whb + ob);                                                \
         if (WN == 2) rbh1 = *reinterpret_cast<const uint4 *>(whb + ob + ob64);                            \
@@ -148,7 +192,10 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
     }
 #define CB_STASH(BUF)                                                                                     \
     {                                                                                                     \
-        CB_STASH_PX(BUF, 0) CB_STASH_PX(BUF, 1) CB_STASH_PX(BUF, 2) CB_STASH_PX(BUF, 3)                   \
+        if (IN16) {                                                                                       \
+            *reinterpret_cast<uintx4 *>(&Ah[BUF][prow16][CB_SW(prow16, oct16)]) = rx0;                    \
+            *reinterpret_cast<uintx4 *>(&Ah[BUF][prow16 + 64][CB_SW(prow16 + 64, oct16)]) = rx1;          \
+        } else { CB_STASH_PX(BUF, 0) CB_STASH_PX(BUF, 1) CB_STASH_PX(BUF, 2) CB_STASH_PX(BUF, 3) }        \
         *reinterpret_cast<uint4 *>(&Bh[BUF][bcol][CB_SW(bcol, boct)]) = rbh0;                                      \
         if (WN == 2) *reinterpret_cast<uint4 *>(&Bh[BUF][bcol + 64][CB_SW(bcol + 64, boct)]) = rbh1;                   \
         if (SPLIT == 3) {                                                                                 \
@@ -198,32 +245,37 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
 #undef CB_FETCH
 #undef CB_STASH
 
-    // ---- epilogue: + bias, + residual, ReLU (as conv.hip), per 32 x 32 block of the wave
+    // ---- epilogue: + bias, + residual, ReLU (as conv.hip), per 32 x 32 block of the wave; residual fp32 or bf16 (p.io bit 2),
+    // output fp32 or bf16 (OUT16), both through buffer descriptors with 32-bit element offsets
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
+    const bool res16 = (p.io & 4) != 0;
+    const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
+    const unsigned oelems = (unsigned)sg.M * (unsigned)p.Cout;
+    const unsigned relems = p.res_up ? (unsigned)(sg.N * Hr * Wr) * (unsigned)p.Cout : oelems;
+    const __amdgpu_buffer_rsrc_t orsrc = cb_rsrc(sg.out, oelems * (OUT16 ? 2u : 4u));
+    const __amdgpu_buffer_rsrc_t rrsrc = cb_rsrc(has_res ? sg.res : sg.out, relems * (res16 ? 2u : 4u));
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int co = n0 + wn * (32 * WN) + 32 * j + aij;
         const bool co_ok = co < p.Cout;
-        const int coc = co_ok ? co : 0;
-        const float bv = has_bias ? p.bias[coc] : 0.f;
+        const float bv = (has_bias && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long pbase = p0 + wm * 64 + 32 * i + 4 * akr;
-            float rr[16];
+            unsigned ridx[16];       // element index of the residual pixel's first channel
             if (has_res && p.res_up) {
                 // residual at half resolution, read through a nearest x2 upsampling (FPN top-down add, fpn.py:34,90-96). The 32 rows
                 // of the block are consecutive output pixels from a multiple of 32: with Wo % 32 == 0 they lie in one image row
                 const long HoWo_ = (long)sg.Ho * sg.Wo;
-                const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
                 if ((sg.Wo & 31) == 0) {
                     const long pb0 = p0 + wm * 64 + 32 * i;
                     const long pb = pb0 < sg.M ? pb0 : 0;
                     const int n_b = (int)(pb / HoWo_);
                     const int rem_b = (int)(pb - (long)n_b * HoWo_);
                     const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;
-                    const long rb = ((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1) + 2 * akr;
+                    const unsigned rb = (unsigned)((n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1) + 2 * akr);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rr[r] = sg.res[(rb + (((r & 3) + 8 * (r >> 2)) >> 1)) * p.Cout + coc];
+                    for (int r = 0; r < 16; ++r) ridx[r] = (rb + (unsigned)(((r & 3) + 8 * (r >> 2)) >> 1)) * (unsigned)p.Cout;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -232,15 +284,19 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
                         const int n = (int)(pp / HoWo_);
                         const int rem = (int)(pp - (long)n * HoWo_);
                         const int h = rem / sg.Wo, w = rem - h * sg.Wo;
-                        rr[r] = sg.res[(((long)n * Hr + (h >> 1)) * Wr + (w >> 1)) * p.Cout + coc];
+                        ridx[r] = (unsigned)((n * Hr + (h >> 1)) * Wr + (w >> 1)) * (unsigned)p.Cout;
                     }
                 }
-            } else if (has_res) {
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ridx[r] = (unsigned)(pbase + (r & 3) + 8 * (r >> 2)) * (unsigned)p.Cout;
+            }
+            float rr[16];
+            if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    long pp = pbase + (r & 3) + 8 * (r >> 2);
-                    pp = pp < sg.M ? pp : sg.M - 1;
-                    rr[r] = sg.res[pp * p.Cout + coc];
+                    const bool ok = co_ok && pbase + (r & 3) + 8 * (r >> 2) < sg.M;
+                    rr[r] = cb_load_elem(rrsrc, ok ? ridx[r] + (unsigned)co : 0x3FFFFFFFu, res16);
                 }
             }
 #pragma unroll
@@ -250,7 +306,7 @@ conv_bf16_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf1
                 if (has_bias) v = v + bv;
                 if (has_res) v = v + rr[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (co_ok && pp < sg.M) sg.out[pp * p.Cout + co] = v;
+                cb_store_elem<OUT16>(orsrc, (co_ok && pp < sg.M) ? (unsigned)pp * (unsigned)p.Cout + (unsigned)co : 0x3FFFFFFFu, v);
             }
         }
     }
@@ -283,10 +339,13 @@ __device__ static inline int h3_perm(const int l)
 // TPS: taps per step (= per barrier and per weight stage): 1 in both modes. TPS = 3 (one kernel row per barrier, 24 MFMAs per wave
 // and step in bf16 like bf16x3 has per tap) was measured SLOWER in bf16: 345 vs 227 us on FPN-P2 (244 registers, six weight
 // loads + stores per thread in a row); kept as a template parameter for further experiments.
-template <int SPLIT, int TPS>
+template <int SPLIT, int TPS, int IO = 0>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, const __bf16 *__restrict__ wlo)
 {
+    constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+    constexpr unsigned XB = IN16 ? 2u : 4u;
+    static_assert(!(IN16 && SPLIT == 3), "bf16 inputs carry no low part");
     __shared__ __attribute__((aligned(16))) __bf16 Ph[2][H3_NPX * 32];
     __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT == 3 ? 2 : 1][SPLIT == 3 ? H3_NPX * 32 : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Bh[2][TPS][CB_BN][CB_PITCH];
@@ -320,18 +379,20 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
 
     // patch loader: element e = tid + 256 j -> patch pixel e >> 3, channels 4 (e & 7) .. +3 of the slab; byte offsets with bit 31 =
     // zero padding / beyond the patch
+    // (bf16 inputs: element e -> patch pixel e >> 2, channels 8 (e & 3) .. +7: half as many 16-byte loads)
+    constexpr int NLD = IN16 ? H3_LD / 2 : H3_LD;
     unsigned po[H3_LD];
 #pragma unroll
-    for (int j = 0; j < H3_LD; ++j) {
-        const int e = tid + 256 * j, px = e >> 3;
+    for (int j = 0; j < NLD; ++j) {
+        const int e = tid + 256 * j, px = IN16 ? e >> 2 : e >> 3;
         const int hy = y0 + px / H3_PW, wx = x0 + px % H3_PW;
         po[j] = 0x80000000u;
         if (px < H3_NPX && hy >= 0 && hy < sg.H && wx >= 0 && wx < sg.W)
-            po[j] = 4u * (unsigned)(((t_n * sg.H + hy) * sg.W + wx) * p.Cin + 4 * (e & 7));
+            po[j] = XB * (unsigned)(((t_n * sg.H + hy) * sg.W + wx) * p.Cin + (IN16 ? 8 * (e & 3) : 4 * (e & 7)));
     }
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
-    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * XB * (unsigned)p.Cin);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
     // B staging: thread -> 8 consecutive k (one 16-byte octet) of columns bcol and bcol + 64
     const int bcol = tid >> 2, boct = tid & 3;
@@ -360,12 +421,14 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
 
 #define H3_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
-#define H3_FETCH_PATCH(CS) { _Pragma("unroll") for (int j = 0; j < H3_LD; ++j) H3_LDX(ra[j], po[j] + (unsigned)(CS) * (CB_BK * 4)) }
+#define H3_FETCH_PATCH(CS) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) H3_LDX(ra[j], po[j] + (unsigned)(CS) * (CB_BK * XB)) }
 #define H3_STASH_PATCH(BUF)                                                                               \
     {                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < H3_LD; ++j) {                                               \
-            const int e = tid + 256 * j, px = e >> 3, c4 = e & 7;                                         \
-            if (px < H3_NPX) {                                                                            \
+        _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                 \
+            const int e = tid + 256 * j, px = IN16 ? e >> 2 : e >> 3, c4 = e & 7;                         \
+            if (IN16) {                                                                                   \
+                if (px < H3_NPX) *reinterpret_cast<float4 *>(&Ph[BUF][H3_SW(px, e & 3)]) = ra[j];         \
+            } else if (px < H3_NPX) {                                                                     \
                 bf16x4 h_, l_;                                                                            \
                 cb_split4(ra[j], true, h_, l_);                                                           \
                 *reinterpret_cast<bf16x4 *>(&Ph[BUF][H3_SW(px, c4 >> 1) + 4 * (c4 & 1)]) = h_;            \
@@ -459,29 +522,30 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
 #undef H3_FETCH_B
 #undef H3_STASH_B
 
-    // ---- epilogue: + bias, + residual, ReLU; accumulator row -> tile pixel (y, x) -> output pixel
+    // ---- epilogue: + bias, + residual, ReLU; accumulator row -> tile pixel (y, x) -> output pixel (fp32 or bf16 output / residual)
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr;
+    const bool res16 = (p.io & 4) != 0;
+    const unsigned oelems = (unsigned)sg.M * (unsigned)p.Cout;
+    const __amdgpu_buffer_rsrc_t orsrc = cb_rsrc(sg.out, oelems * (OUT16 ? 2u : 4u));
+    const __amdgpu_buffer_rsrc_t rrsrc = cb_rsrc(has_res ? sg.res : sg.out, oelems * (res16 ? 2u : 4u));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = n0 + wn * 64 + 32 * j + aij;
         const bool co_ok = co < p.Cout;
-        const int coc = co_ok ? co : 0;
-        const float bv = has_bias ? p.bias[coc] : 0.f;
+        const float bv = (has_bias && co_ok) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            long opix[16];
-            bool ok[16];
+            unsigned oidx[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = 64 * wm + 32 * i + h3_perm(4 * akr + (r & 3) + 8 * (r >> 2));
                 const int ho = H3_TH * t_y + (q >> 4), wo = H3_TW * t_x + (q & 15);
-                ok[r] = co_ok && ho < sg.Ho && wo < sg.Wo;
-                opix[r] = ((long)t_n * sg.Ho + min(ho, sg.Ho - 1)) * sg.Wo + min(wo, sg.Wo - 1);
+                oidx[r] = (co_ok && ho < sg.Ho && wo < sg.Wo) ? (unsigned)((t_n * sg.Ho + ho) * sg.Wo + wo) * (unsigned)p.Cout + (unsigned)co : 0x3FFFFFFFu;
             }
             float rr[16];
             if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rr[r] = sg.res[opix[r] * p.Cout + coc];
+                for (int r = 0; r < 16; ++r) rr[r] = cb_load_elem(rrsrc, oidx[r], res16);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -489,7 +553,7 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
                 if (has_bias) v = v + bv;
                 if (has_res) v = v + rr[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (ok[r]) sg.out[opix[r] * p.Cout + co] = v;
+                cb_store_elem<OUT16>(orsrc, oidx[r], v);
             }
         }
     }
@@ -501,7 +565,9 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
                                        int relu)
 {
     ConvParams p;
-    const int res_up = (relu >> 1) & 1;   // relu: bit 0 = ReLU, bit 1 = the residual is at half resolution (nearest x2 upsampled add)
+    // relu: bit 0 = ReLU, bit 1 = the residual is at half resolution (nearest x2 upsampled add), bits 2 / 3 / 4 = the input / the
+    // output / the residual tensors are bf16 (NHWC, same shapes) instead of fp32 -- bf16 mode only (wpack_lo == NULL)
+    const int res_up = (relu >> 1) & 1, io = (relu >> 2) & 7;
     relu &= 1;
     int rc = conv_fill(p, "conv2d_nhwc_bf16", nseg, x, residual, nullptr, nullptr, out, batch, height, width, Cin, Cout,
                        reinterpret_cast<const float *>(wpack_hi), ldw, bias, KH, KW, stride, pad, 1, relu);
@@ -513,6 +579,10 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
         p.res_up = 1;
     }
     UPS_REQUIRE(ldw % CB_BN == 0, "conv2d_nhwc_bf16: ldw must be a multiple of %d (got %d)", CB_BN, ldw);
+    UPS_REQUIRE(io == 0 || wpack_lo == nullptr, "conv2d_nhwc_bf16: bf16 tensors only in the plain bf16 mode (no low weight part)");
+    p.io = ((io & 1) ? 1 : 0) | ((io & 2) ? 2 : 0) | ((io & 4) ? 4 : 0);
+    for (int i = 0; i < p.nseg; ++i)
+        UPS_REQUIRE(p.seg[i].M * Cout < (1L << 29), "conv2d_nhwc_bf16: output %d exceeds 2 GiB; split the batch", i);
     UPS_REQUIRE(KH * KW <= 9, "conv2d_nhwc_bf16: at most 9 taps");
     for (int i = 0; i < p.nseg; ++i)   // bit 31 of a pixel offset flags the zero padding
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * Cin < (1L << 29), "conv2d_nhwc_bf16: feature map %d exceeds 2 GiB; split the batch", i);
@@ -528,7 +598,12 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
         p.n_tiles = ldw / CB_BN;
         const int g3 = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
         if (lo) hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<3, 1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
-        else hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+        else switch (io & 3) {
+            case 0: hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1, 0>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo); break;
+            case 1: hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1, 1>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo); break;
+            case 2: hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1, 2>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo); break;
+            default: hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1, 3>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo); break;
+        }
         UPS_CHECK_LAUNCH("conv3x3_bf16_halo_kernel");
         return 0;
     }
@@ -536,9 +611,16 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
     for (int i = 0; i < p.nseg; ++i) { p.seg[i].tile_start = tiles; tiles += (int)((p.seg[i].M + CB_BM - 1) / CB_BM); }
     p.m_tiles = tiles;
     p.n_tiles = ldw / CB_BN;
+    // small layers (res4 / res5 / P5 maps: fewer 128 x 128 tiles than CUs): 128 x 64 tiles, twice the workgroups (plain bf16 mode)
+    static const int narrow_below = getenv("UPSNET_BF16_NARROW_BELOW") ? atoi(getenv("UPSNET_BF16_NARROW_BELOW")) : 384;
+    const bool narrow = !lo && p.m_tiles * p.n_tiles < narrow_below;
+    if (narrow) p.n_tiles = ldw / 64;
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+#define CB_GO(WN_, IO_) hipLaunchKernelGGL((conv_bf16_kernel<1, WN_, IO_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo)
     if (lo) hipLaunchKernelGGL((conv_bf16_kernel<3, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
-    else hipLaunchKernelGGL((conv_bf16_kernel<1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, hi, lo);
+    else if (narrow) switch (io & 3) { case 0: CB_GO(1, 0); break; case 1: CB_GO(1, 1); break; case 2: CB_GO(1, 2); break; default: CB_GO(1, 3); break; }
+    else switch (io & 3) { case 0: CB_GO(2, 0); break; case 1: CB_GO(2, 1); break; case 2: CB_GO(2, 2); break; default: CB_GO(2, 3); break; }
+#undef CB_GO
     UPS_CHECK_LAUNCH("conv_bf16_kernel");
     return 0;
 }

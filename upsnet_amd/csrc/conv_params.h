@@ -28,6 +28,7 @@ struct ConvParams {
     int ksplit;        // split-K: the K walk is divided over `ksplit` workgroups per tile; each writes raw partial sums
     float *partial;    // [ksplit][sum of M over the maps][Cout] (workspace), reduced by conv_splitk_reduce_kernel
     long m_total;      // sum of M over the maps
+    int io;            // conv_bf16.hip: bit 0 / 1 / 2 = the input / output / residual tensors are bf16 instead of fp32
 };
 
 // Validates the arguments of a convolution entry point and fills the per-map descriptors (output geometry, pixel counts).
@@ -44,7 +45,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
     UPS_REQUIRE((long)KH * KW * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
     p.w = wpack; p.bias = bias; p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu; p.res_up = 0;
-    p.ksplit = 1; p.partial = nullptr; p.m_total = 0;
+    p.ksplit = 1; p.partial = nullptr; p.m_total = 0; p.io = 0;
     int tiles = 0;
     for (int i = 0; i < CV_MAXSEG; ++i) {
         ConvSeg &s = p.seg[i];

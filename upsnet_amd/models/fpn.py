@@ -45,7 +45,7 @@ class FPN(nn.Module):
     def forward(self, res2, res3, res4, res5):
         p5_1x1 = hipconv.conv(self.fpn_p5_1x1, res5)
         if hasattr(self, 'fpn_gap'):
-            gap = self.fpn_gap(F.adaptive_avg_pool2d(res5, (1, 1)).flatten(1)).view(-1, self.feature_dim, 1, 1)
+            gap = self.fpn_gap(F.adaptive_avg_pool2d(res5.float(), (1, 1)).flatten(1)).view(-1, self.feature_dim, 1, 1)
             p5_1x1 = p5_1x1 + gap
         # top-down pathway: the lateral 1x1 and the "+ upsampled" add are one kernel (residual epilogue)
         # (and for nearest upsampling the x2 upsample is folded into the residual read: nothing is materialised)

@@ -58,6 +58,14 @@ CONV1X1_MIN_WG = int(os.environ.get('UPSNET_CONV1X1_MIN_WG', '256'))
 # configs[2]: bf16 products, fp32 accumulation). The stem, the deconvolution, the FPN top-down laterals and the deformable
 # convolutions always use the fp32 kernel.
 PRECISION = os.environ.get('UPSNET_CONV_PRECISION', 'fp32')
+# 'bf16' mode: the backbone keeps its activations in bf16 between layers (the kernels read / write 2-byte elements; the fp32
+# accumulator + bias + residual + ReLU is rounded once per layer). UPSNET_BF16_ACT=0: fp32 activations as in r07 (A/B runs).
+BF16_ACT = os.environ.get('UPSNET_BF16_ACT', '1') != '0'
+
+
+def act_dtype():
+    """dtype the backbone stores its activations in: torch.bfloat16 in the 'bf16' mode (BASELINE configs[2]), else float32."""
+    return torch.bfloat16 if (PRECISION == 'bf16' and BF16_ACT) else torch.float32
 
 
 def _plans(m):
@@ -129,7 +137,8 @@ def conv_pair(m3, m1, x, residual):
 
 
 def supported(m, x):
-    return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and
+    return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and
+            (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and PRECISION == 'bf16')) and
             ops.conv_supported(m.in_channels, m.kernel_size[0], m.kernel_size[1], m.groups, m.dilation) and
             m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.padding_mode == 'zeros')
 
@@ -142,8 +151,8 @@ BF16_MIN_WG = int(os.environ.get('UPSNET_BF16_MIN_WG', '192'))
 def _use_bf16(m, xs, always=False):
     if PRECISION == 'fp32' or m.kernel_size[0] * m.kernel_size[1] > 9 or m.out_channels < 64:
         return False
-    if always:   # layers whose batch size varies at run time: the choice (hence the rounding) must not depend on it
-        return True
+    if always or xs[0].dtype == torch.bfloat16:   # layers whose batch size varies at run time: the choice (hence the rounding) must
+        return True                               # not depend on it; bf16 activations: only the bf16 kernels read them
     k, st, pd, dl = m.kernel_size[0], m.stride[0], m.padding[0], m.dilation[0]
     wgs = 0
     for x in xs:
@@ -223,14 +232,19 @@ def _ksplit(m, x, ldw):
     return 1
 
 
-def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False):
-    """relu?(m(x) + residual) on the hand-written kernels -- see _conv for the arguments."""
-    y, form = _conv(m, x, relu, residual, residual_up, winograd, pin or winograd == 'always')
+def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False, out_dtype=None):
+    """relu?(m(x) + residual) on the hand-written kernels -- see _conv for the arguments. out_dtype=torch.bfloat16 (bf16 mode, a
+    layer the bf16 kernels take): the result is stored as bf16; a bf16 `x` on a layer those kernels do not take is widened first."""
+    if x.dtype == torch.bfloat16 and not (supported(m, x) and _use_bf16(m, [x])):
+        x = x.float()
+    if residual is not None and residual.dtype == torch.bfloat16 and not (supported(m, x) and _use_bf16(m, [x], always=pin or winograd == 'always')):
+        residual = residual.float()
+    y, form = _conv(m, x, relu, residual, residual_up, winograd, pin or winograd == 'always', out_dtype)
     _trace('conv', module=m, x=x, out=y, relu=relu, residual=residual, residual_up=residual_up, form=form)
     return y
 
 
-def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False):
+def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False, out_dtype=None):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
     winograd=False / 'always' pins the direct / the Winograd form; pin=True (implied by 'always') makes every kernel choice
     (bf16 or fp32, lean 1x1 GEMM or general kernel) independent of the batch size, for layers fed by ROI batches whose size
@@ -238,9 +252,10 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
     if supported(m, x):
         if (not residual_up or tuple(m.kernel_size) == (1, 1)) and _use_bf16(m, [x], always=pin):
             hi, lo, ldw = _bf16_plan(m)
+            od = out_dtype if (out_dtype == torch.bfloat16 and lo is None) else torch.float32
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual],
-                                              residual_up=residual_up)[0], PRECISION
+                                              residual_up=residual_up, out_dtype=od)[0], PRECISION
         if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
             ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])

@@ -68,17 +68,20 @@ class _Block(nn.Module):
         nxt = the next block of the stage. Returns (block output, the next block's conv1 output or None): where the two 1x1 layers
         at a block boundary are HBM-bound (res2), conv3 + shortcut + ReLU of this block and conv1 + ReLU of the next run as one
         launch that never reads the block output back (hipconv.use_pair, csrc/conv1x1_pair.hip; bit-identical results)."""
-        y = hipconv.conv(self.conv1, x, relu=True) if y1 is None else y1
+        # bf16 mode: activations stay bf16 between the layers of the backbone (hipconv.act_dtype); a deformable 3x3 and its offset
+        # predictor read fp32, so the 1x1 in front of them writes fp32 there
+        ad = hipconv.act_dtype()
+        y = hipconv.conv(self.conv1, x, relu=True, out_dtype=torch.float32 if self.deformable else ad) if y1 is None else y1
         if self.deformable:
             off = hipconv.conv(self.conv2_offset, y)
             y, y_in = torch.relu_(self.conv2(y, off)), y
             hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, form='dcn_fused')
         else:
-            y = hipconv.conv(self.conv2, y, relu=True)
-        shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x)
+            y = hipconv.conv(self.conv2, y, relu=True, out_dtype=ad)
+        shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x, out_dtype=ad)
         if nxt is not None and isinstance(nxt.bn1, nn.Identity) and hipconv.use_pair(self.conv3, nxt.conv1, y, shortcut):
             return hipconv.conv_pair(self.conv3, nxt.conv1, y, shortcut)
-        return hipconv.conv(self.conv3, y, relu=True, residual=shortcut), None
+        return hipconv.conv(self.conv3, y, relu=True, residual=shortcut, out_dtype=ad), None
 
 
 class Bottleneck(_Block):

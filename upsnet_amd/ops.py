@@ -969,21 +969,36 @@ def pack_conv_weight_bf16(weight, split=True):
     return hi, lo, ldw
 
 
-def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None, residual_up=False):
+def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, relu=False, residuals=None, residual_up=False,
+                           out_dtype=torch.float32):
     """conv2d_nhwc_multi on the bf16 matrix cores: wlo None -> plain bf16 products, else the 3-term split (fp32-equivalent).
-    residual_up (1x1 kernels): the residuals are at half resolution, added through a nearest x2 upsampling."""
+    residual_up (1x1 kernels): the residuals are at half resolution, added through a nearest x2 upsampling.
+    Plain bf16 mode only: inputs / residuals may be torch.bfloat16 tensors (all maps of a launch alike) and out_dtype may be
+    torch.bfloat16 -- bf16 activations between layers (the kernels then load / store 2-byte elements, no conversion pass)."""
     require_cuda(whi, *xs)
     assert 1 <= len(xs) <= 5
-    xs = [nhwc(x.float()) for x in xs]
+    in16 = xs[0].dtype == torch.bfloat16
+    out16 = out_dtype == torch.bfloat16
+    if (in16 or out16) and wlo is not None:
+        raise RuntimeError("conv2d_nhwc_bf16_multi: bf16 tensors only in the plain bf16 mode")
+    xs = [nhwc(x if (in16 and x.dtype == torch.bfloat16) else x.float()) for x in xs]
+    if in16 and any(x.dtype != torch.bfloat16 for x in xs):
+        raise RuntimeError("conv2d_nhwc_bf16_multi: mixed input dtypes in one launch")
     cin = xs[0].shape[1]
     outs, ress = [], None
     for x in xs:
         N, C, H, W = x.shape
         if C != cin:
             raise RuntimeError("conv2d_nhwc_bf16_multi: channel mismatch")
-        outs.append(_nhwc_out(N, cout, (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1, x.device))
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        outs.append(torch.empty((N, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2) if out16
+                    else _nhwc_out(N, cout, Ho, Wo, x.device))
+    res16 = False
     if residuals is not None:
-        ress = [nhwc(r.float()) for r in residuals]
+        res16 = residuals[0].dtype == torch.bfloat16 and wlo is None
+        ress = [nhwc(r if (res16 and r.dtype == torch.bfloat16) else r.float()) for r in residuals]
+        if res16 and any(r.dtype != torch.bfloat16 for r in ress):
+            raise RuntimeError("conv2d_nhwc_bf16_multi: mixed residual dtypes in one launch")
         for r, o in zip(ress, outs):
             want = (o.shape[0], o.shape[1], o.shape[2] // 2, o.shape[3] // 2) if residual_up else tuple(o.shape)
             if tuple(r.shape) != want:
@@ -995,13 +1010,16 @@ def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, re
                                         int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
                                         int_array([x.shape[3] for x in xs]), int(cin), ptr(whi), ptr(wlo), int(ldw),
                                         ptr(None if bias is None else f32c(bias)), int(cout), int(ksize), int(ksize), int(stride), int(pad),
-                                        int(bool(relu)) | (2 if (residual_up and ress is not None) else 0)), "conv2d_nhwc_bf16")
+                                        int(bool(relu)) | (2 if (residual_up and ress is not None) else 0) | (4 if in16 else 0) |
+                                        (8 if out16 else 0) | (16 if res16 else 0)), "conv2d_nhwc_bf16")
     if PROFILE['enabled']:
         ev1.record()
         npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
         nin = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
         PROFILE['events'].append(('conv_bf16', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
-                                  4.0 * (cin * nin + cout * npix * (2 if ress is not None else 1)) + 2.0 * cout * cin * ksize * ksize))
+                                  (2.0 if in16 else 4.0) * cin * nin + (2.0 if out16 else 4.0) * cout * npix +
+                                  ((2.0 if res16 else 4.0) * cout * npix * (0.25 if residual_up else 1.0) if ress is not None else 0.0) +
+                                  2.0 * cout * cin * ksize * ksize))
     return outs
 
 
