@@ -92,74 +92,146 @@ mask_bits_kernel(const float *__restrict__ rois, const float *__restrict__ logit
     if (lane == 0 && local) atomicAdd(&mask_sum[inst], local);
 }
 
-// grid = num_thing_classes, block = PAN_T
-__global__ void __launch_bounds__(PAN_T)
+// grid = num_thing_classes, block = MR_T (4 waves). r08 rewrite.
+// The reference walks the instances in score order and keeps a per-class occupancy plane (mask_removal.py:60-89): an instance is
+// kept unless more than `fraction` of its mask is already occupied by KEPT earlier instances of its class. r01-r07 restated that
+// literally -- one instance after the other, read-modify-write of a global occupancy bit-plane, a workgroup reduction and two
+// barriers per instance: 5-9 us per instance, 89-127 us per image, all of it latency. But the decision of instance i depends only
+// on the decisions of the earlier same-class instances whose BOXES intersect its box (usually none or one or two), and the
+// occupancy inside box i is just the OR of those instances' bitmaps, which are static (mask_bits_kernel). So:
+//   * rounds instead of a walk: in every round each undecided instance whose intersecting predecessors are all decided is resolved
+//     -- independent instances in parallel, one wavefront each, no workgroup reduction;
+//   * no occupancy plane: overlap_i = popcount(bits_i & OR_{kept j < i, box_j meets box_i} bits_j) over box i, read-only data;
+//   * the number of rounds is the longest chain of intersecting boxes (2-4 in practice), not the number of instances.
+// Decisions are the reference's, bit for bit: same integer overlap, same fp64 ratio test.
+#define MR_T 256
+#define MR_MAXCAND 64
+struct MrBox { int x0, x1, y0, y1; };   // clipped pixel box [x0, x1) x [y0, y1); empty if x1 <= x0 or y1 <= y0
+
+__global__ void __launch_bounds__(MR_T)
 mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ prob, const int64_t *__restrict__ cls_idx,
                     const int m_cap, const int *__restrict__ m_dev, const int H, const int W, const int WW,
                     const double fraction_threshold, const unsigned long long *__restrict__ bits, const int *__restrict__ mask_sum,
                     unsigned long long *__restrict__ occbits, int *__restrict__ sorted_idx, uint8_t *__restrict__ kept_flag)
 {
+    (void)occbits;
     const int m = m_dev ? min(m_cap, *m_dev) : m_cap;
     __shared__ ups_u64 s_keys[PAN_MAXINST];
-    __shared__ int s_my[PAN_MAXINST];
-    __shared__ float s_box[PAN_MAXINST][4];
-    __shared__ long s_red[PAN_T / 64];
-    __shared__ int s_cnt[PAN_T / 64];
+    __shared__ int s_pos[PAN_MAXINST];          // this class's instances in score order: position in the global score order ...
+    __shared__ int s_inst[PAN_MAXINST];         // ... and instance index
+    __shared__ MrBox s_box[PAN_MAXINST];
+    __shared__ int s_sum[PAN_MAXINST];
+    __shared__ unsigned char s_state[PAN_MAXINST];   // 0 undecided, 1 kept, 2 dropped
+    __shared__ unsigned char s_ready[PAN_MAXINST];
+    __shared__ int s_cand[MR_T / 64][MR_MAXCAND];
+    __shared__ int s_nmy, s_left;
     const int tid = threadIdx.x, my_cls = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = ups_next_pow2(m < 64 ? 64 : m);
-    for (int i = tid; i < M; i += PAN_T) s_keys[i] = i < m ? ups_make_key(prob[i], (unsigned)i, 0) : 0ULL;
-    ups_block_sort_desc(s_keys, M);
-    // ---- ordered compaction of this class's instances (m <= PAN_MAXINST == PAN_T: one element per thread)
-    int idx = 0;
-    bool mine = false;
-    if (tid < m) {
-        idx = (int)ups_key_index(s_keys[tid], 0);
-        if (my_cls == 0) sorted_idx[tid] = idx;
-        mine = (int)cls_idx[idx] - 1 == my_cls;
-    }
-    const unsigned long long bal = __ballot(mine);
-    if (lane == 0) s_cnt[wave] = __builtin_popcountll(bal);
-    __syncthreads();
-    int base = 0, n_my = 0;
-    for (int w = 0; w < PAN_T / 64; ++w) { const int c = s_cnt[w]; if (w < wave) base += c; n_my += c; }
-    if (mine) {
-        const int pos = base + __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));
-        s_my[pos] = tid;
-        s_box[pos][0] = rois[(long)idx * 4 + 0]; s_box[pos][1] = rois[(long)idx * 4 + 1];
-        s_box[pos][2] = rois[(long)idx * 4 + 2]; s_box[pos][3] = rois[(long)idx * 4 + 3];
+    for (int i = tid; i < M; i += MR_T) s_keys[i] = i < m ? ups_make_key(prob[i], (unsigned)i, 0) : 0ULL;
+    if (M <= 256) ups_block_rank_sort_desc(s_keys, m, M);   // (unique, non-zero keys; see sort.h for the size rule)
+    else ups_block_sort_desc(s_keys, M);
+    // ---- ordered compaction of this class's instances (one wave, 64 score positions per trip)
+    for (int t = tid; t < m; t += MR_T) {
+        const int idx = (int)ups_key_index(s_keys[t], 0);
+        if (my_cls == 0) sorted_idx[t] = idx;
+        s_pos[t] = ((int)cls_idx[idx] - 1 == my_cls) ? idx : -1;       // (class flag until the compaction below)
     }
     __syncthreads();
-    unsigned long long *__restrict__ occ = occbits + (long)my_cls * H * WW;
-    for (int j = 0; j < n_my; ++j) {
-        const int si = s_my[j];
-        const int inst = (int)ups_key_index(s_keys[si], 0);
-        const PanBox b = pan_box(s_box[j], H, W);
-        const int rx = b.x_1 - b.x_0, ry = b.y_1 - b.y_0;
-        bool keep = false;
-        if (rx > 0 && ry > 0) {
-            const long sum = mask_sum[inst];
-            if (sum > 0) {
-                const int wc0 = b.x_0 >> 6, nw = ((b.x_1 - 1) >> 6) - wc0 + 1;
-                const long items = (long)ry * nw;
-                const unsigned long long *__restrict__ bj = bits + (long)inst * H * WW;
-                long ov = 0;
-                for (long it = tid; it < items; it += PAN_T) {
-                    const long off = (long)(b.y_0 + (int)(it / nw)) * WW + wc0 + (int)(it % nw);
-                    ov += __builtin_popcountll(bj[off] & occ[off]);
-                }
-                ov = pan_block_sum(ov, s_red);
-                keep = !((double)ov / (double)sum > fraction_threshold);  // mask_removal.py:82
-                if (keep) {
-                    for (long it = tid; it < items; it += PAN_T) {
-                        const long off = (long)(b.y_0 + (int)(it / nw)) * WW + wc0 + (int)(it % nw);
-                        occ[off] |= bj[off];
-                    }
-                }
-                __syncthreads();  // occupancy updated before the next instance of this class reads it
+    if (wave == 0) {
+        int base = 0;
+        for (int t0 = 0; t0 < m; t0 += 64) {
+            const int t = t0 + lane;
+            const int idx = t < m ? s_pos[t] : -1;
+            const unsigned long long bal = __ballot(idx >= 0);
+            __builtin_amdgcn_wave_barrier();
+            if (idx >= 0) {
+                const int pos = base + __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));   // pos <= t: that slot has been read
+                const PanBox b = pan_box(rois + (long)idx * 4, H, W);
+                MrBox mb;
+                mb.x0 = b.x_0; mb.x1 = b.x_1; mb.y0 = b.y_0; mb.y1 = b.y_1;
+                const int sum = mask_sum[idx];
+                const bool live = mb.x1 > mb.x0 && mb.y1 > mb.y0 && sum > 0;
+                s_pos[pos] = t; s_inst[pos] = idx; s_box[pos] = mb; s_sum[pos] = sum;
+                s_state[pos] = live ? 0 : 2;
+                if (!live) kept_flag[t] = 0;
             }
+            base += __builtin_popcountll(bal);
         }
-        if (tid == 0) kept_flag[si] = keep ? 1 : 0;
+        if (lane == 0) s_nmy = base;
     }
+    __syncthreads();
+    const int n_my = s_nmy;
+#define MR_MEET(A, B) ((A).x0 < (B).x1 && (B).x0 < (A).x1 && (A).y0 < (B).y1 && (B).y0 < (A).y1)
+    for (;;) {
+        // ---- which undecided instances have all their intersecting predecessors decided?
+        if (tid == 0) s_left = 0;
+        __syncthreads();
+        int mine_left = 0;
+        for (int i = tid; i < n_my; i += MR_T) {
+            bool ready = false;
+            if (s_state[i] == 0) {
+                ready = true;
+                const MrBox bi = s_box[i];
+                for (int j = 0; j < i; ++j)
+                    if (s_state[j] == 0 && MR_MEET(bi, s_box[j])) { ready = false; break; }
+                ++mine_left;
+            }
+            s_ready[i] = ready ? 1 : 0;
+        }
+        if (mine_left) atomicAdd(&s_left, mine_left);
+        __syncthreads();
+        if (s_left == 0) break;
+        // ---- resolve the ready ones, one wavefront per instance (the r-th ready instance goes to wave r mod 4)
+        int r = 0;
+        for (int i = 0; i < n_my; ++i) {
+            if (!s_ready[i]) continue;
+            if ((r++ & (MR_T / 64 - 1)) != wave) continue;
+            const MrBox bi = s_box[i];
+            // kept predecessors whose box meets this one (lane-parallel scan, ballot compaction into the wave's list)
+            int ncand = 0;
+            for (int j0 = 0; j0 < i; j0 += 64) {
+                const int j = j0 + lane;
+                const bool c = j < i && s_state[j] == 1 && MR_MEET(bi, s_box[j]);
+                const unsigned long long bal = __ballot(c);
+                if (c) { const int at = ncand + __builtin_popcountll(bal & ((1ULL << lane) - 1ULL)); if (at < MR_MAXCAND) s_cand[wave][at] = j; }
+                ncand += __builtin_popcountll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool listed = ncand <= MR_MAXCAND;     // (more than 64 overlapping kept predecessors: scan all of them instead)
+            const int wc0 = bi.x0 >> 6, nw = ((bi.x1 - 1) >> 6) - wc0 + 1;
+            const long items = (long)(bi.y1 - bi.y0) * nw;
+            const unsigned long long *__restrict__ bsrc = bits + (long)s_inst[i] * H * WW;
+            long ov = 0;
+            if (ncand > 0) {
+                for (long it = lane; it < items; it += 64) {
+                    const int y = bi.y0 + (int)(it / nw), wc = wc0 + (int)(it % nw);
+                    const long off = (long)y * WW + wc;
+                    const unsigned long long w = bsrc[off];
+                    unsigned long long occ = 0;
+                    const int nscan = listed ? ncand : i;
+                    for (int c = 0; c < nscan; ++c) {
+                        const int j = listed ? s_cand[wave][c] : c;
+                        if (!listed && !(s_state[j] == 1)) continue;
+                        const MrBox bj = s_box[j];
+                        // instance j's bitmap holds defined words only inside its own box rows / words
+                        if (y >= bj.y0 && y < bj.y1 && wc >= (bj.x0 >> 6) && wc <= ((bj.x1 - 1) >> 6))
+                            occ |= bits[(long)s_inst[j] * H * WW + off];
+                    }
+                    ov += __builtin_popcountll(w & occ);
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)ov, d, 64), hi = __shfl_xor((unsigned)((unsigned long long)ov >> 32), d, 64);
+                    ov += (long)(((unsigned long long)hi << 32) | lo);
+                }
+            }
+            const bool keep = !((double)ov / (double)s_sum[i] > fraction_threshold);  // mask_removal.py:82
+            if (lane == 0) { s_state[i] = keep ? 1 : 2; kept_flag[s_pos[i]] = keep ? 1 : 0; }
+        }
+        __syncthreads();
+    }
+#undef MR_MEET
 }
 
 __global__ void __launch_bounds__(256)
@@ -250,12 +322,11 @@ extern "C" int upsnet_mask_removal(void *stream, const float *mask_rois, const f
     int *sums = (int *)(ws + pl.sums), *sorted_idx = (int *)(ws + pl.sorted);
     uint8_t *kept = ws + pl.kept;
     hipStream_t st = (hipStream_t)stream;
-    if (ups_zero_async(occ, (size_t)ncls * H * pl.WW * 8, st)) return 1;
     if (ups_zero_async(sums, (size_t)m * 4, st)) return 1;
     if (ups_zero_async(kept, ((size_t)m + 3) & ~(size_t)3, st)) return 1;   // (its slot is 256-byte aligned and padded)
     hipLaunchKernelGGL(mask_bits_kernel, dim3(m, 32), dim3(256), 0, st, mask_rois, mask_logit, m, m_dev, mask_size, H, W, pl.WW, bits, sums);
     UPS_CHECK_LAUNCH("mask_bits_kernel");
-    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(PAN_T), 0, st, mask_rois, cls_prob, cls_idx, m, m_dev, H, W, pl.WW,
+    hipLaunchKernelGGL(mask_removal_kernel, dim3(ncls), dim3(MR_T), 0, st, mask_rois, cls_prob, cls_idx, m, m_dev, H, W, pl.WW,
                        fraction_threshold, bits, sums, occ, sorted_idx, kept);
     UPS_CHECK_LAUNCH("mask_removal_kernel");
     hipLaunchKernelGGL(mask_removal_finalize_kernel, dim3(1), dim3(64), 0, st, cls_idx, m, m_dev, sorted_idx, kept, keep_inds, num_keep,
