@@ -220,6 +220,15 @@ def main():
                                'achieved': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12, 3),
                                'frac': round((f_c - f_w) / max(t_c - t_w, 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                'frac_of_launch_bounds': bound_frac('conv', False)[0], 'hbm_bound_launches': bound_frac('conv', False)[1]}}
+        # MFMA work actually issued per image (dense family at its executed flops + the deformable launches) against the peak over the
+        # WHOLE steady-state image time (two images in flight: everything else -- ROIAlign, the selection chain, FC GEMMs, launch gaps --
+        # is in the denominator too): the matrix-pipe utilisation of the production mode, not of one kernel
+        roofline['steady_state'] = {
+            'executed_mfma_flops_per_image': (f_exec + f_d) / n_sampled, 'ms_per_img_p50': round(p50_ms, 3),
+            'achieved': round((f_exec + f_d) / n_sampled / (p50_ms * 1e-3) / 1e12, 3),
+            'frac_of_peak_whole_image': round((f_exec + f_d) / n_sampled / (p50_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'note': 'fp32 MFMA flops issued by the convolution kernels of one image / (157.3 TFLOP/s x steady-state time per image); the '
+                    'FC GEMMs (hipBLASLt) are not counted'}
         n_b, t_b, f_b, b_b = agg('conv_bf16')
         if n_b and t_b > 0:   # --conv-precision bf16 / bf16x3 (BASELINE configs[2]): the layers that ran on the bf16 matrix cores
             mult = 3.0 if args.conv_precision == 'bf16x3' else 1.0

@@ -191,6 +191,13 @@ int upsnet_image_to_nhwc4(void *stream, const float *nchw, int batch, int channe
 
 /* ============================== Dense convolution ============================== */
 
+/* upsnet_conv2d_nhwc_f32 (below) with per-map weights: wpack[i] packs the weights of map i (same geometry, Cin, Cout, ldw); no bias,
+ * no residual. Replaces the four per-level products W_l y_l of the FCN head's 1x1 score layer (upsnet/models/fcn.py:101-104, the
+ * 512-channel concat + conv commuted below the bilinear upsamples) as one launch. */
+int upsnet_conv2d_nhwc_f32_multiw(void *stream, int nseg, const float *const x[], float *const out[], const int batch[],
+                                  const int height[], const int width[], int Cin, const float *const wpack[], int ldw, int Cout,
+                                  int KH, int KW, int stride, int pad, int relu);
+
 /* Replaces nn.Conv2d (+ folded frozen BatchNorm + bias + residual add + ReLU) of the backbone / FPN / RPN / heads
  * (upsnet/models/resnet.py:53-100, fpn.py:78-104, rpn.py:52-57, rcnn.py:79-87, fcn.py:88-108): NHWC fp32 implicit
  * GEMM on v_mfma_f32_32x32x2_f32 with a fused epilogue. Up to 5 feature maps sharing the weights per launch.

@@ -165,6 +165,20 @@ def test_hipconv_routes_1x1_layers_to_the_gemm_kernel():
         np.testing.assert_allclose(ys.cpu().numpy(), F.relu(m(small)).cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_conv_multi_map_launch_with_per_map_weights():
+    """upsnet_conv2d_nhwc_f32_multiw (the four per-level score products of the FCN head in one launch): bit-identical to one launch per map."""
+    from upsnet_amd import ops
+    torch.manual_seed(7)
+    xs = [torch.randn(1, 128, 64 >> l, 96 >> l, device='cuda') for l in range(4)]
+    ws = [torch.randn(19, 128, 1, 1, device='cuda') / 128 ** 0.5 for _ in range(4)]
+    packs = [ops.pack_conv_weight(w) for w in ws]
+    one = [ops.conv2d_nhwc(x, wp, ldw, None, 19, 1, 1, 0) for x, (wp, ldw) in zip(xs, packs)]
+    multi = ops.conv2d_nhwc_multiw(xs, [wp for wp, _ in packs], packs[0][1], 19, 1, 1, 0)
+    for a, b, x, w in zip(one, multi, xs, ws):
+        assert torch.equal(a, b)
+        np.testing.assert_allclose(b.cpu().numpy(), F.conv2d(x.double(), w.double()).float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("S,H,W,nlev,bias", [(19, 32, 64, 4, True), (133, 24, 40, 4, True), (5, 8, 8, 2, False), (19, 16, 16, 1, True)])
 def test_fcn_score_combine_vs_oracle(S, H, W, nlev, bias):
     """Bit-exact vs the C oracle (same expression order, no FMA)."""

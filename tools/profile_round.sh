@@ -1,24 +1,44 @@
 #!/bin/bash
-# One GPU-box visit producing what profiles/<tag>_* is written from. Usage: tools/profile_round.sh <tag>
-#   1. rocprofv3 --kernel-trace of the eager, single-stream bench (per-kernel averages not inflated by co-running kernels)
+# One GPU-box visit producing everything profiles/<tag>_* and the generated tables of DESIGN.md are written from. Usage: tools/profile_round.sh <tag>
+#   1. rocprofv3 --kernel-trace of the eager, single-stream bench (a kernel's duration is its own): kernel stats, per-call durations, timeline
 #   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs, kernel-trace only -- never with other trace domains)
-#   3. the default bench line (graph replay, overlapped streams, cpu_baseline included)
-TAG=${1:-r05}
+#   3. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE: per kernel (serial) and over the default run (graph replay, two images in flight)
+#   4. per-launch table of the convolution kernels (algorithmic TFLOP/s and GB/s from the bench's own events)
+#   5. the default bench line (graph replay, overlapped streams, cpu_baseline, configs2) + the other workloads + the bf16 mode's own line
+#   6. the parity summary: worst error / bound of the strict fp64 tests at full size
+TAG=${1:-r08}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
+export PYTHONPATH=$REPO
 cd /tmp && export TMPDIR=/tmp
 EAGER="env UPSNET_OVERLAP=0 UPSNET_GRAPH=0"
-$EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-configs2 > $OUT/${TAG}_trace_bench.log 2>&1
-python $REPO/tools/rocpd_stats.py $(find /tmp/p_trace -name "*.db" | head -1) 70 > $OUT/${TAG}_kernel_stats.txt 2>&1
-python $REPO/tools/rocpd_calls.py $(find /tmp/p_trace -name "*.db" | head -1) fpn_roi_align nms_sort nms_mask nms_scan dcn_fused panoptic_fuse > $OUT/${TAG}_per_call.txt 2>&1
+B="python $REPO/bench.py --no-cpu-baseline --no-configs2"
+db() { find $1 -name "*.db" | head -1; }
+$EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- $B --steps 10 --warmup 5 > $OUT/${TAG}_trace_bench.log 2>&1
+python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace) 70 > $OUT/${TAG}_kernel_stats.txt 2>&1
+python $REPO/tools/rocpd_calls.py $(db /tmp/p_trace) fpn_roi_align nms_sort nms_mask nms_scan dcn_fused panoptic_fuse mask_removal prop_merge prop_sortk mroi_finalize > $OUT/${TAG}_per_call.txt 2>&1
+python $REPO/tools/rocpd_timeline.py $(db /tmp/p_trace) > $OUT/${TAG}_timeline_serial.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  $EAGER rocprofv3 --kernel-trace --pmc $C -d /tmp/p_$C -o t -- python $REPO/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-configs2 > $OUT/${TAG}_pmc_$C.log 2>&1
-  python $REPO/tools/rocpd_pmc.py $(find /tmp/p_$C -name "*.db" | head -1) > $OUT/${TAG}_pmc_$C.txt 2>&1
+  $EAGER rocprofv3 --kernel-trace --pmc $C -d /tmp/p_$C -o t -- $B --steps 3 --warmup 3 > $OUT/${TAG}_pmc_$C.log 2>&1
+  python $REPO/tools/rocpd_pmc.py $(db /tmp/p_$C) > $OUT/${TAG}_pmc_$C.txt 2>&1
 done
+$EAGER rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma -o t -- $B --steps 3 --warmup 3 > $OUT/${TAG}_pmc_mfma.log 2>&1
+python $REPO/tools/mfma_util.py $(db /tmp/p_mfma) > $OUT/${TAG}_mfma_util_serial.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma2 -o t -- $B --steps 20 --warmup 6 > $OUT/${TAG}_pmc_mfma_graph.log 2>&1
+python $REPO/tools/mfma_util.py $(db /tmp/p_mfma2) --total > $OUT/${TAG}_mfma_util_graph.txt 2>&1
 cd $REPO
 python tools/make_pmc_json.py $TAG $OUT/${TAG}_pmc_FETCH_SIZE.txt $OUT/${TAG}_pmc_WRITE_SIZE.txt > $OUT/${TAG}_conv_pmc.json 2> $OUT/${TAG}_conv_pmc.err
 cp $OUT/${TAG}_conv_pmc.json profiles/${TAG}_conv_pmc.json   # (so that the bench line of this very run can report roofline.traffic)
+python tools/layer_table.py > $OUT/${TAG}_layer_table.txt 2>&1
+python tools/microbench_roialign.py > $OUT/${TAG}_roialign.txt 2>&1
 python bench.py > $OUT/${TAG}_bench.log 2>&1
+python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --in-flight 1 > $OUT/${TAG}_bench_serial.log 2>&1
+python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 > $OUT/${TAG}_bench_bf16.log 2>&1
+python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16x3 > $OUT/${TAG}_bench_bf16x3.log 2>&1
+python bench.py --steps 40 --warmup 8 --no-configs2 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3.log 2>&1
+python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-configs2 --workload upsnet101dcn_mixed_1024x2048_800x1333 > $OUT/${TAG}_bench_c4.log 2>&1
+python bench.py --gpus 1 --dry-run > $OUT/${TAG}_dry_run.log 2>&1
+timeout 900 python -m pytest tests/test_trunk_gpu.py tests/test_layerwise_gpu.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep -E "worst|launches|passed|failed" > $OUT/${TAG}_parity.txt
 tail -1 $OUT/${TAG}_bench.log | cut -c1-300
 head -12 $OUT/${TAG}_kernel_stats.txt

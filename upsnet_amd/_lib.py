@@ -43,6 +43,7 @@ _SIGNATURES = {
     "upsnet_conv1x1_tuning": (None, [c_int]),
     "upsnet_conv1x1_pair_nhwc_f32": (c_int, [P, P, P, P, P, c_long, c_int, P, P, c_int, P, P, c_int]),
     "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "upsnet_conv2d_nhwc_f32_multiw": (c_int, [P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_tuning": (None, [c_int, c_int]),
     "upsnet_conv_pack_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "upsnet_nms_host": (c_int, [P, P, P, c_int, c_int, c_float, c_int]),

@@ -183,7 +183,7 @@ conv_igemm_f32_kernel(const ConvParams p)
     const char *xbase = reinterpret_cast<const char *>(sg.x);
     const unsigned ldw4 = 4u * (unsigned)p.ldw;
     const unsigned cin4 = 4u * (unsigned)p.Cin, wcin4 = cin4 * (unsigned)sg.W;  // byte steps to the right / lower pixel
-    const char *wb0 = reinterpret_cast<const char *>(p.w) + 4 * n0;
+    const char *wb0 = reinterpret_cast<const char *>(sg.w != nullptr ? sg.w : p.w) + 4 * n0;
     const char *wb1 = wb0 + (size_t)BROWS * ldw4, *wb2 = wb0 + (size_t)2 * BROWS * ldw4, *wb3 = wb0 + (size_t)3 * BROWS * ldw4;
     unsigned ob = (unsigned)(tid / (BN / 4)) * ldw4 + 16u * (unsigned)(tid % (BN / 4));  // advances BK rows per slab
     unsigned oa0 = 0, oa1 = 0, oa2 = 0, oa3 = 0;               // dense: byte offset of this thread's float4 per pixel
@@ -569,6 +569,23 @@ extern "C" int upsnet_conv2d_nhwc_f32(void *stream, int nseg, const float *const
             UPS_REQUIRE(p.seg[i].Ho % 2 == 0 && p.seg[i].Wo % 2 == 0, "conv2d_nhwc_f32: residual_up needs even output dims (map %d: %dx%d)", i, p.seg[i].Ho, p.seg[i].Wo);
         p.res_up = 1;
     }
+    return conv_dispatch<0>((hipStream_t)stream, p);
+}
+
+/* The same geometry applied to several maps, each with ITS OWN packed weights, in one launch (no bias / residual): the per-level
+ * column blocks of the FCN head's commuted 1x1 score (fcn.py:101-104: conv1x1(cat(up(y_l))) = sum_l up(W_l y_l)) -- four ~10 us launches
+ * of 19 output channels are latency, not work. Every output is computed exactly as by upsnet_conv2d_nhwc_f32 on that map alone. */
+extern "C" int upsnet_conv2d_nhwc_f32_multiw(void *stream, int nseg, const float *const x[], float *const out[], const int batch[],
+                                             const int height[], const int width[], int Cin, const float *const wpack[], int ldw, int Cout,
+                                             int KH, int KW, int stride, int pad, int relu)
+{
+    UPS_REQUIRE(wpack, "conv2d_nhwc_f32_multiw: null weight array");
+    for (int i = 0; i < nseg && i < CV_MAXSEG; ++i) UPS_REQUIRE(wpack[i], "conv2d_nhwc_f32_multiw: null weights for map %d", i);
+    ConvParams p;
+    int rc = conv_fill(p, "conv2d_nhwc_f32_multiw", nseg, x, nullptr, nullptr, nullptr, out, batch, height, width, Cin, Cout, wpack[0], ldw,
+                       nullptr, KH, KW, stride, pad, 1, relu);
+    if (rc) return rc;
+    for (int i = 0; i < nseg; ++i) p.seg[i].w = wpack[i];
     return conv_dispatch<0>((hipStream_t)stream, p);
 }
 

@@ -11,6 +11,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct ConvSeg {
     const float *x, *res, *off, *mask;
+    const float *w;   // this map's own packed weights (conv.hip, upsnet_conv2d_nhwc_f32_multiw); NULL: the launch's shared p.w
     float *out;
     int N, H, W, Ho, Wo;
     int OH, OW;  // Winograd: real output size (Ho, Wo then count 2x2 output tiles)
@@ -53,6 +54,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
             const int nb = batch ? batch[i] : 1;
             UPS_REQUIRE(x[i] && out[i] && nb > 0 && height[i] > 0 && width[i] > 0, "%s: bad feature map %d", who, i);
             s.x = x[i]; s.out = out[i]; s.res = res ? res[i] : nullptr; s.off = off ? off[i] : nullptr; s.mask = mask ? mask[i] : nullptr;
+            s.w = nullptr;
             s.N = nb; s.H = height[i]; s.W = width[i];
             s.OH = s.OW = 0;
             s.Ho = (height[i] + 2 * pad - (dil * (KH - 1) + 1)) / stride + 1;
@@ -64,7 +66,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
             s.tile_start = tiles;
             tiles += (int)((s.M + 127) / 128);
         } else {
-            s.x = s.res = s.off = s.mask = nullptr; s.out = nullptr;
+            s.x = s.res = s.off = s.mask = nullptr; s.w = nullptr; s.out = nullptr;
             s.N = s.H = s.W = s.Ho = s.Wo = s.OH = s.OW = 0; s.M = 0; s.tile_start = 0x7fffffff;
         }
     }

@@ -111,7 +111,8 @@ class FCNHead(nn.Module):
         if (commute and ys[0].is_cuda and ys[0].shape[0] == 1 and ys[0].shape[2] % 8 == 0 and ys[0].shape[3] % 8 == 0 and
                 all(y.shape[1] * 4 == self.score.in_channels and ops.conv_supported(y.shape[1], 1, 1, 1, (1, 1)) for y in ys)):
             packs = self._score_parts()
-            parts = [ops.conv2d_nhwc(y, wp, ldw, None, S, 1, 1, 0) for y, (wp, ldw) in zip(ys, packs)]
+            # (one launch for the four levels, each with its own column block of the score weight)
+            parts = ops.conv2d_nhwc_multiw(ys, [wp for wp, _ in packs], packs[0][1], S, 1, 1, 0)
             return ops.fcn_score_combine(parts, self.score.bias)
         fpn_p2, fpn_p3, fpn_p4, fpn_p5 = ys
         fpn_p3 = F.interpolate(fpn_p3, None, 2, mode='bilinear', align_corners=False)

@@ -647,6 +647,31 @@ def conv2d_nhwc_multi(xs, wpack, ldw, bias, cout, ksize, stride, pad, relu=False
     return outs
 
 
+def conv2d_nhwc_multiw(xs, wpacks, ldw, cout, ksize, stride, pad, relu=False):
+    """Up to 5 maps through the same convolution GEOMETRY, each with its own packed weights, in one launch (no bias / residual)."""
+    require_cuda(*xs, *wpacks)
+    assert 1 <= len(xs) <= 5 and len(wpacks) == len(xs)
+    xs = [nhwc(x.float()) for x in xs]
+    cin = xs[0].shape[1]
+    outs = [_nhwc_out(x.shape[0], cout, (x.shape[2] + 2 * pad - ksize) // stride + 1, (x.shape[3] + 2 * pad - ksize) // stride + 1, x.device)
+            for x in xs]
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_nhwc_f32_multiw(stream(), len(xs), ptr_array(xs), ptr_array(outs), int_array([x.shape[0] for x in xs]),
+                                              int_array([x.shape[2] for x in xs]), int_array([x.shape[3] for x in xs]), int(cin),
+                                              ptr_array(wpacks), int(ldw), int(cout), int(ksize), int(ksize), int(stride), int(pad),
+                                              int(bool(relu))), "conv2d_nhwc_f32_multiw")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = sum(o.shape[0] * o.shape[2] * o.shape[3] for o in outs)
+        nin = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * ksize * ksize * npix,
+                                  4.0 * (cin * nin + cout * npix + len(xs) * cout * cin * ksize * ksize),
+                                  "direct %dx%d/%d %d->%d %s per-map weights" % (ksize, ksize, stride, cin, cout, [tuple(x.shape[2:]) for x in xs])))
+    return outs
+
+
 def conv2d_nhwc(x, wpack, ldw, bias, cout, ksize, stride, pad, relu=False, residual=None, residual_up=False):
     """x: logical NCHW tensor (any batch); returns a channels_last [N,Cout,Ho,Wo] tensor.
     out = relu?(conv(x) + bias + residual) in one kernel."""
