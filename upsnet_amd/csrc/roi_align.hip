@@ -94,45 +94,79 @@ __device__ static inline void roi_bin_nhwc_g2(const float4 *__restrict__ feat, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// NCHW drop-in: one thread per output element (n, c, ph, pw), pw fastest.
-__global__ void __launch_bounds__(256)
-roi_align_nchw_kernel(const long nthreads, const float *__restrict__ feat, const float spatial_scale,
-                      const int channels, const int height, const int width, const int pooled_h,
-                      const int pooled_w, const int sampling_ratio, const float *__restrict__ rois,
-                      float *__restrict__ out)
+// NCHW drop-in (upsnet_roi_align_forward, the reference launcher's signature and layouts). What the contract fixes is the
+// arithmetic of one output element (roi_align_kernel.cu:43-95,199-231); how the work is organised is this file's own: one
+// workgroup per ROI (x a slice of its channels). The ROI is decoded ONCE and its sample grid -- PH*grid_h sample rows, PW*grid_w
+// sample columns, any sampling_ratio incl. the adaptive ceil(roi / pooled) -- is tabulated per AXIS in LDS (low / high index,
+// the two weights, 0 / 0 for a sample outside the map); a thread then owns (channel, bin) outputs of that ROI and only reads the
+// table and the channel plane: the reference recomputes the whole ROI decode + bilinear setup for every output element.
+struct RoiAxisN { int lo, hi; float l, h; };
+__device__ static inline RoiAxisN roi_axis_n(const int size, float y)
 {
-    for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
-         index += (long)blockDim.x * gridDim.x) {
-        int pw = index % pooled_w;
-        int ph = (index / pooled_w) % pooled_h;
-        int c = (index / pooled_w / pooled_h) % channels;
-        int n = index / pooled_w / pooled_h / channels;
-        const float *r = rois + (long)n * 5;
-        int roi_batch_ind = (int)roundf(r[0]);
-        float roi_start_w = r[1] * spatial_scale, roi_start_h = r[2] * spatial_scale;
-        float roi_end_w = r[3] * spatial_scale, roi_end_h = r[4] * spatial_scale;
-        float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
-        float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
-        float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
-        const float *plane = feat + ((long)roi_batch_ind * channels + c) * height * width;
-        int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
-        int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
-        const float count = (float)(grid_h * grid_w);
+    const bool empty = y < -1.0f || y > (float)size;
+    if (y <= 0) y = 0;
+    int lo = (int)y, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else { hi = lo + 1; }
+    const float l = y - (float)lo;
+    RoiAxisN a;
+    a.lo = lo; a.hi = hi; a.l = empty ? 0.f : l; a.h = empty ? 0.f : 1.0f - l;
+    return a;
+}
+
+#define ROI_NCHW_MAXAXIS 4096   // (sample rows + columns) the LDS table holds at most: 64 KiB
+
+__global__ void __launch_bounds__(256)
+roi_align_nchw_kernel(const float *__restrict__ feat, const float spatial_scale, const int channels, const int height, const int width,
+                      const int pooled_h, const int pooled_w, const int sampling_ratio, const float *__restrict__ rois,
+                      float *__restrict__ out, const int cap_y, const int cap_x)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = blockIdx.x;
+    const float *r = rois + (long)n * 5;
+    const int roi_batch_ind = (int)roundf(r[0]);
+    const float roi_start_w = r[1] * spatial_scale, roi_start_h = r[2] * spatial_scale;
+    const float roi_end_w = r[3] * spatial_scale, roi_end_h = r[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.0f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_size_h = roi_height / (float)pooled_h, bin_size_w = roi_width / (float)pooled_w;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+    const long ny = (long)pooled_h * grid_h, nx = (long)pooled_w * grid_w;
+    // (an adaptive grid of a box far larger than the map can exceed the table: such a ROI evaluates its axis entries on the fly)
+    const bool tabulated = ny <= cap_y && nx <= cap_x;
+    RoiAxisN *ytab = reinterpret_cast<RoiAxisN *>(smem_raw), *xtab = ytab + cap_y;
+#define ROI_N_YENT(PH_, IY_) roi_axis_n(height, roi_start_h + (float)(PH_) * bin_size_h + ((float)(IY_) + .5f) * bin_size_h / (float)grid_h)
+#define ROI_N_XENT(PW_, IX_) roi_axis_n(width, roi_start_w + (float)(PW_) * bin_size_w + ((float)(IX_) + .5f) * bin_size_w / (float)grid_w)
+    if (tabulated) {
+        for (int s = threadIdx.x; s < (int)ny; s += blockDim.x) { const int ph = s / grid_h; ytab[s] = ROI_N_YENT(ph, s - ph * grid_h); }
+        for (int s = threadIdx.x; s < (int)nx; s += blockDim.x) { const int pw = s / grid_w; xtab[s] = ROI_N_XENT(pw, s - pw * grid_w); }
+    }
+    __syncthreads();
+    const float count = (float)(grid_h * grid_w);
+    const int bins = pooled_h * pooled_w;
+    const long per_roi = (long)channels * bins;
+    const float *img = feat + (long)roi_batch_ind * channels * height * width;
+    for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < per_roi; e += (long)gridDim.y * blockDim.x) {
+        const int c = (int)(e / bins), bin = (int)(e - (long)c * bins);
+        const int ph = bin / pooled_w, pw = bin - ph * pooled_w;
+        const float *plane = img + (long)c * height * width;
         float acc = 0.f;
         for (int iy = 0; iy < grid_h; ++iy) {
-            const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+            const RoiAxisN ya = tabulated ? ytab[ph * grid_h + iy] : ROI_N_YENT(ph, iy);
             for (int ix = 0; ix < grid_w; ++ix) {
-                const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
-                RoiTap t;
-                float val = 0.f;
-                if (roi_tap(height, width, y, x, t))
-                    val = roi_blend(t, plane[t.y_low * width + t.x_low], plane[t.y_low * width + t.x_high],
-                                    plane[t.y_high * width + t.x_low], plane[t.y_high * width + t.x_high]);
+                const RoiAxisN xa = tabulated ? xtab[pw * grid_w + ix] : ROI_N_XENT(pw, ix);
+                const float w1 = ya.h * xa.h, w2 = ya.h * xa.l, w3 = ya.l * xa.h, w4 = ya.l * xa.l;
+                float val = w1 * plane[ya.lo * width + xa.lo];
+                val = val + w2 * plane[ya.lo * width + xa.hi];
+                val = val + w3 * plane[ya.hi * width + xa.lo];
+                val = val + w4 * plane[ya.hi * width + xa.hi];
                 acc += val;
             }
         }
-        out[index] = acc / count;
+        out[(long)n * per_roi + e] = acc / count;
     }
+#undef ROI_N_YENT
+#undef ROI_N_XENT
 }
 
 extern "C" int upsnet_roi_align_forward(void *stream, const float *bottom_data, float spatial_scale,
@@ -143,13 +177,18 @@ extern "C" int upsnet_roi_align_forward(void *stream, const float *bottom_data, 
     UPS_REQUIRE(bottom_data && bottom_rois && top_data, "roi_align_forward: null pointer");
     UPS_REQUIRE(num_rois >= 0 && channels > 0 && height > 0 && width > 0 && pooled_height > 0 && pooled_width > 0,
                 "roi_align_forward: bad shape");
-    long n = (long)num_rois * channels * pooled_height * pooled_width;
-    if (n == 0) return 0;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, bottom_data,
-                       spatial_scale, channels, height, width, pooled_height, pooled_width, sampling_ratio,
-                       bottom_rois, top_data);
+    if (num_rois == 0) return 0;
+    // table capacity: a fixed sampling ratio -> exact (capped); adaptive (sampling_ratio <= 0) -> 1024 samples per axis
+    int ny = sampling_ratio > 0 ? pooled_height * sampling_ratio : 1024, nx = sampling_ratio > 0 ? pooled_width * sampling_ratio : 1024;
+    if (ny > ROI_NCHW_MAXAXIS / 2) ny = ROI_NCHW_MAXAXIS / 2;
+    if (nx > ROI_NCHW_MAXAXIS / 2) nx = ROI_NCHW_MAXAXIS / 2;
+    const size_t smem = (size_t)(ny + nx) * sizeof(RoiAxisN);      // <= 64 KiB
+    long per_roi = (long)channels * pooled_height * pooled_width;
+    int ysplit = (int)((per_roi + 256 * 8 - 1) / (256 * 8));      // ~8 outputs per thread
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > 64) ysplit = 64;
+    hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(num_rois, ysplit), dim3(256), smem, (hipStream_t)stream, bottom_data, spatial_scale, channels,
+                       height, width, pooled_height, pooled_width, sampling_ratio, bottom_rois, top_data, ny, nx);
     UPS_CHECK_LAUNCH("roi_align_nchw_kernel");
     return 0;
 }
