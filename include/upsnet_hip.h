@@ -256,6 +256,16 @@ int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], cons
 int upsnet_conv_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, void *wpack_hi,
                                  void *wpack_lo);
 
+/* One identity bottleneck of the backbone (upsnet/models/resnet.py:84-100: conv1 1x1 C -> Cm, conv2 3x3 Cm -> Cm, conv3 1x1 Cm -> C,
+ * C = 4 Cm, stride 1, no projection; frozen BN folded; out = relu(conv3(relu(conv2(relu(conv1(x))))) + x)) as ONE launch on the bf16
+ * matrix cores -- the bf16 mode of BASELINE.json configs[2]; the intermediates never leave the LDS. x, out: [N,H,W,C] bf16 NHWC;
+ * cmid in {64, 128, 256, 512}; w1 / w2 / w3: bf16 in MFMA-fragment order [out channel / 32][k / 16][64 lanes][8]
+ * (element (cb, ks, lane, e) = W[cb 32 + lane % 32][ks 16 + (lane / 32) 8 + e], k = input channel for the 1x1 layers and
+ * (ky 3 + kx) Cm + c for the 3x3 layer); b1, b2 [Cm], b3 [C] fp32. Every intermediate is rounded to bf16 where the three separate
+ * launches of upsnet_conv2d_nhwc_bf16 round it. */
+int upsnet_bottleneck_bf16(void *stream, const void *x, void *out, int batch, int height, int width, int cmid, const void *w1,
+                           const void *w2, const void *w3, const float *b1, const float *b2, const float *b3);
+
 /* 7x7/2 stem (upsnet/models/resnet.py:347-356, conv1 + frozen BN + ReLU): Cin <= 4 input given as NHWC with 4 channels
  * (x [N,H,W,4], 4th channel ignored by zero weights; see upsnet_image_to_nhwc4 / upsnet_prep_image_u8). One K slab of the
  * implicit GEMM is one kernel row: 8 consecutive pixels x 4 channels. wpack [KH*32, ldw] from upsnet_conv_pack_weight_stem

@@ -1,6 +1,10 @@
-cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_trunk_gpu.py -m gpu -q -p no:cacheprovider -k "roi_align or non_square or zero_fill or upsnet101" --tb=short 2>&1 | tail -30 > gpurun_out/r08b_pytest.log
-tail -12 gpurun_out/r08b_pytest.log
-timeout 600 python tools/microbench_roialign.py > gpurun_out/r08b_roialign.txt 2>&1
-cat gpurun_out/r08b_roialign.txt
-bash tools/profile_round.sh r08b
+set -x
+cd /root/repo
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_bottleneck_bf16_gpu.py -x -q 2>&1 | tail -30 > gpurun_out/bnk_test.log
+timeout 600 python bench.py --conv-precision bf16 > gpurun_out/bnk_bench_bf16.log 2>&1
+export TMPDIR=/tmp
+R=$PWD
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bf16 -o bf16 -- python $R/bench.py --conv-precision bf16 --steps 20 --warmup 5 > $R/gpurun_out/prof_bf16.log 2>&1)
+ls -R gpurun_out/prof_bf16 | head
+tail -3 gpurun_out/bnk_test.log; tail -1 gpurun_out/bnk_bench_bf16.log | cut -c1-300

@@ -1,0 +1,376 @@
+// bottleneck_bf16.hip -- a whole identity bottleneck of the ResNet backbone in ONE launch on the bf16 matrix cores (gfx950).
+//
+// Reference: Bottleneck.forward (upsnet/models/resnet.py:84-100), identity blocks (stride 1, no projection):
+//     out = relu( bn3(conv3( relu(bn2(conv2( relu(bn1(conv1(x))) ))) )) + x )      conv1 1x1 C->Cm, conv2 3x3 Cm->Cm, conv3 1x1 Cm->C = 4 Cm
+// with every BatchNorm frozen (folded into the weights / a bias at load time). BASELINE.json configs[2] ("bf16 compute / fp32
+// accumulate"), bf16 activations in HBM (r08).
+//
+// Why: in the bf16 mode a 1x1 layer of res3-res5 is < 2 us of matrix-pipe time and takes 25-35 us as a launch of its own (launch,
+// ramp, two rounds of workgroups, epilogue; profiles/r08): three launches and ~230 MB of HBM traffic per block for 67 MB that must
+// move (x in, out out). Here a workgroup owns a TH x TW tile of output pixels:
+//   A  t1 = relu(W1 x + b1) on the HALOED (TH+2) x (TW+2) patch (the 1x1 layer is recomputed on the halo: 1.4x at 8x16, 1.9x at 4x8
+//      -- cheap on the bf16 cores), x streamed through LDS in 32-channel slabs (double-buffered), t1 kept in LDS as bf16 (zero outside
+//      the image: conv2 pads t1, not x);
+//   B  t2 = relu(W2 * t1 + b2): nine taps = the same LDS rows shifted by dy (TW+2) + dx; t2 kept in LDS as bf16;
+//   C  out = relu(W3 t2 + b3 + x) in passes of 128 output channels: staged through LDS so that the HBM stores are 16 bytes per lane
+//      along the channel vector of a pixel.
+// The MFMA operands are SWAPPED with respect to conv_bf16.hip: the weights are the A operand (rows = output channels), the
+// activations the B operand (columns = pixels), so an accumulator lane holds 4 x 4 CONSECUTIVE CHANNELS of ONE pixel -- t1 / t2 / out
+// go to LDS as 8-byte stores in the [pixel][channel] row layout the next stage reads its fragments from (one ds_read_b128 per lane).
+// Weights never touch LDS: packed in fragment order [32-channel block][k step of 16][lane][8] they are one 16-byte load per lane and
+// MFMA group from L2, prefetched one step ahead. Stages B and C have no barrier inside (their activations are resident, read-only).
+// Every intermediate is rounded exactly where the three-launch path rounds it (fp32 accumulator + bias (+ residual) + ReLU -> bf16),
+// and K is walked in the same order, so the result equals the unfused bf16 path.
+#include <stdlib.h>
+
+#include "common.h"
+#include "upsnet_hip.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bnk_bf16x8;
+typedef float bnk_floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned bnk_uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned bnk_uintx2 __attribute__((ext_vector_type(2)));
+
+struct BneckParams {
+    const void *x;            // [N,H,W,C] bf16 NHWC
+    void *out;                // [N,H,W,C] bf16 NHWC
+    const void *w1, *w2, *w3; // fragment-order packs (upsnet_amd/ops.py: pack_bottleneck_bf16)
+    const float *b1, *b2, *b3;
+    int N, H, W, tiles_x, tiles_y;
+};
+
+__device__ static inline __amdgpu_buffer_rsrc_t bnk_rsrc(const void *ptr, const unsigned bytes)
+{
+    const size_t a = reinterpret_cast<size_t>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// MFMA column l (0..31) -> pixel of a 2 x 16 block such that each fixed lane group of ds_read_b128 ({0-3,12-15,20-27} / the rest)
+// reads 16 consecutive pixels of one image row (conflict-free with a row pitch of 16 bytes mod 256; cf. conv_bf16.hip: h3_perm)
+__device__ static inline int bnk_perm(const int l)
+{
+    const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+    const int k = l < 4 ? l : l < 12 ? l - 4 : l < 16 ? l - 8 : l < 20 ? l - 8 : l < 28 ? l - 12 : l - 16;
+    return (g1 ? 16 : 0) + k;
+}
+
+__device__ static inline unsigned bnk_pack2(const float a, const float b)
+{
+    const __bf16 x = (__bf16)a, y = (__bf16)b;      // round to nearest even
+    unsigned short ux, uy;
+    __builtin_memcpy(&ux, &x, 2);
+    __builtin_memcpy(&uy, &y, 2);
+    return (unsigned)ux | ((unsigned)uy << 16);
+}
+
+template <int CM, int TH, int TW>
+struct BneckGeom {
+    static constexpr int C = 4 * CM;
+    static constexpr int NPX = TH * TW, PBO = NPX / 32;                 // output pixels / 32-pixel blocks of the tile
+    static constexpr int PWD = TW + 2, NPATCH = (TH + 2) * PWD;         // haloed patch
+    static constexpr int PBP = (NPATCH + 31) / 32, NROWS = PBP * 32;
+    static constexpr int XS_P = 80, T_P = CM * 2 + 16, O_P = 272;       // LDS row pitches in bytes (16 mod 64 / mod 256: conflict-free b128)
+    static constexpr int XS_BYTES = 2 * NROWS * XS_P;                   // x slabs (stage A), double-buffered
+    static constexpr int T2_BYTES = NPX * T_P;                          // t2 (stages B -> C); shares the x-slab region (dead by then)
+    static constexpr int R0_BYTES = XS_BYTES > T2_BYTES ? XS_BYTES : T2_BYTES;
+    static constexpr int R1_BYTES = NROWS * T_P > NPX * O_P ? NROWS * T_P : NPX * O_P;   // t1 (A -> B), later the output staging (C)
+    static constexpr int SMEM = R0_BYTES + R1_BYTES;
+};
+
+template <int CM, int TH, int TW>
+__global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams p)
+{
+    using G = BneckGeom<CM, TH, TW>;
+    constexpr int C = G::C, NPX = G::NPX, PBO = G::PBO, PWD = G::PWD, NPATCH = G::NPATCH, PBP = G::PBP, NROWS = G::NROWS;
+    constexpr int XS_P = G::XS_P, T_P = G::T_P, O_P = G::O_P;
+    constexpr int NCB = CM / 32;                                 // 32-channel blocks of t1 / t2
+    constexpr int NWC = NCB < 4 ? NCB : 4, NWP = 4 / NWC;        // waves along channels x waves along pixel blocks
+    constexpr int CBW = NCB / NWC;                               // channel blocks per wave (stages A, B)
+    constexpr int PBPW = PBP / NWP, PBOW = PBO / NWP;            // pixel blocks per wave (stage A / stage B)
+    static_assert(NCB >= 2 && PBP % NWP == 0 && PBO % NWP == 0 && NPX % 32 == 0 && (NPX * 16) % 256 == 0, "unsupported tile / width combination");
+    constexpr int K1S = C / 16, K2S = 9 * CM / 16, K3S = CM / 16; // k steps (16 channels) of the three GEMMs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *XS = smem, *T2 = smem, *T1 = smem + G::R0_BYTES, *OUTS = T1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, lhalf = lane >> 5;
+    const int wc = wave % NWC, wp = wave / NWC;
+    // tile of this workgroup
+    const int t = blockIdx.x;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int t_n = t / per_img, t_r = t - t_n * per_img;
+    const int t_y = t_r / p.tiles_x, t_x = t_r - t_y * p.tiles_x;
+    const int y0 = t_y * TH, x0 = t_x * TW;
+    const unsigned cbytes = (unsigned)C * 2u;                    // bytes of one pixel vector
+    const unsigned img_bytes = (unsigned)(p.N * p.H * p.W) * cbytes;
+    const __amdgpu_buffer_rsrc_t xrsrc = bnk_rsrc(p.x, img_bytes), orsrc = bnk_rsrc(p.out, img_bytes);
+    const char *w1 = reinterpret_cast<const char *>(p.w1), *w2 = reinterpret_cast<const char *>(p.w2), *w3 = reinterpret_cast<const char *>(p.w3);
+#define BNK_WLOAD(BASE, CB, KS_TOTAL, KS) (*reinterpret_cast<const bnk_bf16x8 *>((BASE) + (((size_t)(CB) * (KS_TOTAL) + (KS)) * 64 + lane) * 16))
+
+    // ================================================================ stage A: t1 = relu(W1 x + b1) on the haloed patch
+    // Nothing here may wait on a load it has just issued (one workgroup = one wave per SIMD, nobody else hides the latency): x slabs
+    // are XD deep in flight in registers, weight fragments WD k-steps deep.
+    constexpr int NLD = NROWS * 4 / 256;                         // 16-byte units per thread and slab
+    constexpr int NSLAB = C / 32;
+    constexpr int XD = 3, WD = CBW == 1 ? 6 : 4;
+    unsigned xoff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int u = tid + 256 * j, q = u >> 2;
+        const int py = y0 - 1 + q / PWD, px = x0 - 1 + q % PWD;
+        xoff[j] = (q < NPATCH && py >= 0 && py < p.H && px >= 0 && px < p.W) ? (unsigned)((t_n * p.H + py) * p.W + px) * cbytes + 16u * (unsigned)(u & 3)
+                                                                            : 0x80000000u;
+    }
+    bnk_floatx16 acc[CBW][PBPW];
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int j = 0; j < PBPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bnk_uintx4 rx[XD][NLD];
+#define BNK_FETCH_X(D, S) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) rx[D][j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[j], (unsigned)(S) * 64u, 0); }
+#define BNK_STASH_X(D, BUF) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) { const int u = tid + 256 * j;                \
+        *reinterpret_cast<bnk_uintx4 *>(XS + (BUF) * (NROWS * XS_P) + (u >> 2) * XS_P + (u & 3) * 16) = rx[D][j]; } }
+    {
+        bnk_bf16x8 wq[WD][CBW];
+#pragma unroll
+        for (int d = 0; d < XD; ++d)
+            if (d < NSLAB) BNK_FETCH_X(d, d)
+#pragma unroll
+        for (int d = 0; d < WD; ++d)
+#pragma unroll
+            for (int i = 0; i < CBW; ++i) wq[d][i] = BNK_WLOAD(w1, wc * CBW + i, K1S, d);
+        float4 bias[CBW][4];
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[i][g] = *reinterpret_cast<const float4 *>(p.b1 + (wc * CBW + i) * 32 + 8 * g + 4 * lhalf);
+        __builtin_amdgcn_sched_barrier(0);
+        BNK_STASH_X(0, 0)
+        if (XD < NSLAB) BNK_FETCH_X(0, XD)
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            const int buf = s & 1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kg = 2 * s + kk;
+                bnk_bf16x8 wf[CBW];
+#pragma unroll
+                for (int i = 0; i < CBW; ++i) wf[i] = wq[kg % WD][i];
+                if (kg + WD < K1S) {
+#pragma unroll
+                    for (int i = 0; i < CBW; ++i) wq[kg % WD][i] = BNK_WLOAD(w1, wc * CBW + i, K1S, kg + WD);
+                }
+#pragma unroll
+                for (int j = 0; j < PBPW; ++j) {
+                    const int row = (wp * PBPW + j) * 32 + l32;
+                    const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(XS + buf * (NROWS * XS_P) + row * XS_P + (kk * 2 + lhalf) * 16);
+#pragma unroll
+                    for (int i = 0; i < CBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf, acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (keeps the prefetches where they are issued: the scheduler sinks them otherwise)
+            }
+            if (s + 1 < NSLAB) {
+                BNK_STASH_X((s + 1) % XD, buf ^ 1)
+                if (s + 1 + XD < NSLAB) BNK_FETCH_X((s + 1) % XD, s + 1 + XD)
+            }
+            __syncthreads();
+        }
+        // epilogue A: + b1, ReLU, zero outside the image (conv2 pads t1), bf16 -> T1[patch pixel][channel]
+#pragma unroll
+        for (int j = 0; j < PBPW; ++j) {
+            const int q = (wp * PBPW + j) * 32 + l32;
+            const int py = y0 - 1 + q / PWD, px = x0 - 1 + q % PWD;
+            const bool inside = q < NPATCH && py >= 0 && py < p.H && px >= 0 && px < p.W;
+#pragma unroll
+            for (int i = 0; i < CBW; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch0 = (wc * CBW + i) * 32 + 8 * g + 4 * lhalf;
+                    const float4 b = bias[i][g];
+                    const float v0 = inside ? fmaxf(acc[i][j][4 * g + 0] + b.x, 0.f) : 0.f, v1 = inside ? fmaxf(acc[i][j][4 * g + 1] + b.y, 0.f) : 0.f;
+                    const float v2 = inside ? fmaxf(acc[i][j][4 * g + 2] + b.z, 0.f) : 0.f, v3 = inside ? fmaxf(acc[i][j][4 * g + 3] + b.w, 0.f) : 0.f;
+                    bnk_uintx2 pk;
+                    pk.x = bnk_pack2(v0, v1); pk.y = bnk_pack2(v2, v3);
+                    *reinterpret_cast<bnk_uintx2 *>(T1 + q * T_P + ch0 * 2) = pk;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ================================================================ stage B: t2 = relu(W2 * t1 + b2), 3x3 from the resident patch
+    {
+        bnk_floatx16 acc2[CBW][PBOW];
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+            for (int j = 0; j < PBOW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+        int prow[PBOW], pcan[PBOW];      // lane's pixel per block: top-left patch row of its 3x3 window / canonical tile index y TW + x
+#pragma unroll
+        for (int j = 0; j < PBOW; ++j) {
+            const int pb = wp * PBOW + j;
+            int y, x;
+            if (TW == 16) { const int pp = bnk_perm(l32); y = 2 * pb + (pp >> 4); x = pp & 15; }
+            else { const int pp = pb * 32 + l32; y = pp / TW; x = pp % TW; }
+            prow[j] = y * PWD + x;
+            pcan[j] = y * TW + x;
+        }
+        bnk_bf16x8 wq[WD][CBW];
+#pragma unroll
+        for (int d = 0; d < WD; ++d)
+#pragma unroll
+            for (int i = 0; i < CBW; ++i) wq[d][i] = BNK_WLOAD(w2, wc * CBW + i, K2S, d);
+        float4 bias[CBW][4];
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[i][g] = *reinterpret_cast<const float4 *>(p.b2 + (wc * CBW + i) * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+        for (int kg = 0; kg < K2S; ++kg) {
+            const int tap = kg / (CM / 16), ks = kg % (CM / 16);
+            const int sh = (tap / 3) * PWD + (tap % 3);
+            bnk_bf16x8 wf[CBW];
+#pragma unroll
+            for (int i = 0; i < CBW; ++i) wf[i] = wq[kg % WD][i];
+            if (kg + WD < K2S) {
+#pragma unroll
+                for (int i = 0; i < CBW; ++i) wq[kg % WD][i] = BNK_WLOAD(w2, wc * CBW + i, K2S, kg + WD);
+            }
+#pragma unroll
+            for (int j = 0; j < PBOW; ++j) {
+                const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(T1 + (prow[j] + sh) * T_P + (ks * 16 + lhalf * 8) * 2);
+#pragma unroll
+                for (int i = 0; i < CBW; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf, acc2[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < PBOW; ++j)
+#pragma unroll
+            for (int i = 0; i < CBW; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch0 = (wc * CBW + i) * 32 + 8 * g + 4 * lhalf;
+                    const float4 b = bias[i][g];
+                    bnk_uintx2 pk;
+                    pk.x = bnk_pack2(fmaxf(acc2[i][j][4 * g + 0] + b.x, 0.f), fmaxf(acc2[i][j][4 * g + 1] + b.y, 0.f));
+                    pk.y = bnk_pack2(fmaxf(acc2[i][j][4 * g + 2] + b.z, 0.f), fmaxf(acc2[i][j][4 * g + 3] + b.w, 0.f));
+                    *reinterpret_cast<bnk_uintx2 *>(T2 + pcan[j] * T_P + ch0 * 2) = pk;
+                }
+    }
+    __syncthreads();      // t2 complete; t1 is dead from here on (its region becomes the output staging)
+
+    // ================================================================ stage C: out = relu(W3 t2 + b3 + x), 128 output channels per pass
+    constexpr int NST = NPX * 16 / 256;          // 16-byte units per thread of the coalesced store of one pass
+    constexpr int WD3 = K3S < 8 ? K3S : 8;
+#pragma unroll 1
+    for (int pass = 0; pass < C / 128; ++pass) {
+        const int cb3 = pass * 4 + wave;          // 32-channel block of the output this wave computes
+        bnk_bf16x8 wq[WD3];
+#pragma unroll
+        for (int d = 0; d < WD3; ++d) wq[d] = BNK_WLOAD(w3, cb3, K3S, d);
+        // shortcut x (4 bf16 per lane, pixel block and channel group) and the bias: in flight during the K walk
+        bnk_uintx2 rs[PBO][4];
+        float4 bias[4];
+#pragma unroll
+        for (int j = 0; j < PBO; ++j) {
+            const int pc = j * 32 + l32;                         // canonical tile pixel of this lane
+            const int oy = y0 + pc / TW, ox = x0 + pc % TW;
+            const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)((t_n * p.H + oy) * p.W + ox) * cbytes : 0x80000000u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rs[j][g] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, pix, (unsigned)(cb3 * 32 + 8 * g + 4 * lhalf) * 2u, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const float4 *>(p.b3 + cb3 * 32 + 8 * g + 4 * lhalf);
+        bnk_floatx16 acc3[PBO];
+#pragma unroll
+        for (int j = 0; j < PBO; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < K3S; ++ks) {
+            const bnk_bf16x8 wf = wq[ks % WD3];
+            if (ks + WD3 < K3S) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3S, ks + WD3);
+#pragma unroll
+            for (int j = 0; j < PBO; ++j) {
+                const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(T2 + (j * 32 + l32) * T_P + (ks * 16 + lhalf * 8) * 2);
+                acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc3[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < PBO; ++j) {
+            const int pc = j * 32 + l32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = bias[g];
+                const bnk_uintx2 r = rs[j][g];
+                const float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xffff0000u);
+                const float r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xffff0000u);
+                bnk_uintx2 pk;
+                pk.x = bnk_pack2(fmaxf(acc3[j][4 * g + 0] + b.x + r0, 0.f), fmaxf(acc3[j][4 * g + 1] + b.y + r1, 0.f));
+                pk.y = bnk_pack2(fmaxf(acc3[j][4 * g + 2] + b.z + r2, 0.f), fmaxf(acc3[j][4 * g + 3] + b.w + r3, 0.f));
+                *reinterpret_cast<bnk_uintx2 *>(OUTS + pc * O_P + (wave * 32 + 8 * g + 4 * lhalf) * 2) = pk;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int u = tid + 256 * k, pc = u >> 4, o = u & 15;
+            const int oy = y0 + pc / TW, ox = x0 + pc % TW;
+            const bnk_uintx4 v = *reinterpret_cast<const bnk_uintx4 *>(OUTS + pc * O_P + o * 16);
+            const unsigned off = (oy < p.H && ox < p.W) ? (unsigned)((t_n * p.H + oy) * p.W + ox) * cbytes + (unsigned)(pass * 256 + o * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, off, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef BNK_FETCH_X
+#undef BNK_STASH_X
+#undef BNK_WLOAD
+}
+
+template <int CM, int TH, int TW>
+static int bneck_launch(hipStream_t st, BneckParams &p)
+{
+    constexpr size_t smem = BneckGeom<CM, TH, TW>::SMEM;
+    static_assert(smem <= 160 * 1024, "tile does not fit the LDS");
+    p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bottleneck_bf16_kernel<CM, TH, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((bottleneck_bf16_kernel<CM, TH, TW>), dim3((unsigned)(p.N * p.tiles_x * p.tiles_y)), dim3(256), smem, st, p);
+    UPS_CHECK_LAUNCH("bottleneck_bf16_kernel");
+    return 0;
+}
+
+/* One identity bottleneck (conv1 1x1 -> conv3x3 -> conv1x1, frozen BN folded, + x, ReLUs) of the backbone on the bf16 matrix cores:
+ * x, out [N,H,W,C] bf16 NHWC (C = 4 Cm, Cm in {64, 128, 256, 512}); w1 / w2 / w3 bf16 in fragment order ([32-channel block][k step]
+ * [64 lanes][8], k = input channel, for w2 tap-major: (ky 3 + kx) Cm + c); b1, b2 [Cm], b3 [C] fp32. Replaces three launches of
+ * upsnet_conv2d_nhwc_bf16 (upsnet/models/resnet.py:84-100). */
+extern "C" int upsnet_bottleneck_bf16(void *stream, const void *x, void *out, int batch, int height, int width, int cmid, const void *w1,
+                                      const void *w2, const void *w3, const float *b1, const float *b2, const float *b3)
+{
+    UPS_REQUIRE(x && out && w1 && w2 && w3 && b1 && b2 && b3, "bottleneck_bf16: null pointer");
+    UPS_REQUIRE(batch > 0 && height > 0 && width > 0, "bottleneck_bf16: bad shape");
+    UPS_REQUIRE((long)batch * height * width * 4 * cmid < (1L << 30), "bottleneck_bf16: feature map exceeds 2 GiB; split the batch");
+    BneckParams p;
+    p.x = x; p.out = out; p.w1 = w1; p.w2 = w2; p.w3 = w3; p.b1 = b1; p.b2 = b2; p.b3 = b3;
+    p.N = batch; p.H = height; p.W = width;
+    // tiles: 8 x 16 on the stride-4 map (two workgroups per CU), 8 x 8 at width 128 (two per CU), 4 x 8 on the small maps of
+    // res4 / res5 (as many workgroups as the map allows)
+    hipStream_t st = (hipStream_t)stream;
+    switch (cmid) {
+        case 64: return bneck_launch<64, 8, 16>(st, p);
+        case 128: return bneck_launch<128, 8, 8>(st, p);
+        case 256: return bneck_launch<256, 4, 8>(st, p);
+        case 512: return bneck_launch<512, 4, 8>(st, p);
+        default: return ups_set_error("bottleneck_bf16: Cm must be 64, 128, 256 or 512 (got %d)", cmid);
+    }
+}

@@ -171,6 +171,44 @@ def _bf16_plan(m):
     return ent[1], ent[2], ent[3]
 
 
+# bf16 mode: an identity bottleneck (three layers + shortcut) as one launch whose intermediates stay in the LDS
+# (csrc/bottleneck_bf16.hip). UPSNET_BF16_BLOCK=0: three launches (A/B runs).
+BF16_BLOCK = os.environ.get('UPSNET_BF16_BLOCK', '1') != '0'
+BF16_BLOCK_MIN_TILES = int(os.environ.get('UPSNET_BF16_BLOCK_MIN_TILES', '64'))
+
+
+def use_block(blk, x):
+    """Can `blk` (a folded, non-deformable identity bottleneck) run as one bf16 launch on x?"""
+    if not (ENABLED and BF16_BLOCK and PRECISION == 'bf16' and BF16_ACT and x.is_cuda and x.dtype == torch.bfloat16 and
+            blk.downsample is None and not blk.deformable):
+        return False
+    c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+    cm = c1.out_channels
+    plain = lambda m, k, p: (tuple(m.kernel_size) == (k, k) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (p, p) and
+                             tuple(m.dilation) == (1, 1) and m.groups == 1)
+    # (the kernel's tiles are 8x16 / 8x8 / 4x8 pixels at widths 64 / 128 / >= 256: a map with fewer tiles than a quarter of the CUs stays on the
+    # separate layers, whose split-K instances fill the chip)
+    th, tw = {64: (8, 16), 128: (8, 8)}.get(cm, (4, 8))
+    if x.shape[0] * -(-x.shape[2] // th) * -(-x.shape[3] // tw) < BF16_BLOCK_MIN_TILES:
+        return False
+    return (cm in (64, 128, 256, 512) and plain(c1, 1, 0) and plain(c2, 3, 1) and plain(c3, 1, 0) and c1.in_channels == 4 * cm and
+            c2.in_channels == cm and c2.out_channels == cm and c3.in_channels == cm and c3.out_channels == 4 * cm and
+            x.shape[0] * x.shape[2] * x.shape[3] * 4 * cm < (1 << 30))
+
+
+def block(blk, x):
+    """relu(conv3(relu(conv2(relu(conv1(x))))) + x) -- see use_block."""
+    ms = (blk.conv1, blk.conv2, blk.conv3)
+    key = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version) for m in ms)
+    ent = _plans(blk.conv1).get('block16')
+    if ent is None or ent[0] != key:
+        ent = (key, ops.pack_bottleneck_bf16(*(m.weight for m in ms), *(m.bias for m in ms)))
+        _plans(blk.conv1)['block16'] = ent
+    y = ops.bottleneck_bf16(x, ent[1])
+    _trace('block', module=blk, x=x, out=y, form='bottleneck_bf16')
+    return y
+
+
 def _winograd_plan(m):
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)

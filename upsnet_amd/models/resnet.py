@@ -70,6 +70,8 @@ class _Block(nn.Module):
         launch that never reads the block output back (hipconv.use_pair, csrc/conv1x1_pair.hip; bit-identical results)."""
         # bf16 mode: activations stay bf16 between the layers of the backbone (hipconv.act_dtype); a deformable 3x3 and its offset
         # predictor read fp32, so the 1x1 in front of them writes fp32 there
+        if y1 is None and hipconv.use_block(self, x):      # bf16 mode: the whole identity block as one launch
+            return hipconv.block(self, x), None
         ad = hipconv.act_dtype()
         y = hipconv.conv(self.conv1, x, relu=True, out_dtype=torch.float32 if self.deformable else ad) if y1 is None else y1
         if self.deformable:

@@ -1048,6 +1048,47 @@ def conv2d_nhwc_bf16_multi(xs, whi, wlo, ldw, bias, cout, ksize, stride, pad, re
     return outs
 
 
+def _bf16_fragments(w2d):
+    """[Cout, K] fp32 -> bf16 in MFMA-fragment order [Cout/32][K/16][64 lanes][8] (lane = (k half) * 32 + row; see
+    csrc/bottleneck_bf16.hip): one 16-byte load per lane and MFMA, straight from L2 into the A operand."""
+    cout, k = w2d.shape
+    return w2d.to(torch.bfloat16).view(cout // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def pack_bottleneck_bf16(w1, w2, w3, b1, b2, b3):
+    """Folded weights of an identity bottleneck ([Cm,C,1,1], [Cm,Cm,3,3], [C,Cm,1,1], biases) -> the operand pack of bottleneck_bf16."""
+    require_cuda(w1, w2, w3)
+    cm, c = w1.shape[0], w1.shape[1]
+    if not (c == 4 * cm and tuple(w2.shape) == (cm, cm, 3, 3) and tuple(w3.shape) == (c, cm, 1, 1) and cm in (64, 128, 256, 512)):
+        raise RuntimeError("pack_bottleneck_bf16: not an identity bottleneck of width 64/128/256/512")
+    zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=w1.device)
+    return (_bf16_fragments(w1.detach().float().reshape(cm, c)),
+            _bf16_fragments(w2.detach().float().permute(0, 2, 3, 1).reshape(cm, 9 * cm)),
+            _bf16_fragments(w3.detach().float().reshape(c, cm)),
+            zeros(cm) if b1 is None else f32c(b1.detach()), zeros(cm) if b2 is None else f32c(b2.detach()),
+            zeros(c) if b3 is None else f32c(b3.detach()), cm)
+
+
+def bottleneck_bf16(x, pack):
+    """relu(conv3(relu(conv2(relu(conv1(x))))) + x) of an identity bottleneck in one launch; x, result: bf16 NHWC-strided NCHW."""
+    w1, w2, w3, b1, b2, b3, cm = pack
+    require_cuda(x, w1)
+    if x.dtype != torch.bfloat16 or x.shape[1] != 4 * cm:
+        raise RuntimeError("bottleneck_bf16: expects a bf16 map of %d channels" % (4 * cm))
+    x = nhwc(x)
+    N, C, H, W = x.shape
+    out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_bottleneck_bf16(stream(), ptr(x), ptr(out), N, H, W, cm, ptr(w1), ptr(w2), ptr(w3), ptr(b1), ptr(b2), ptr(b3)),
+          "bottleneck_bf16")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('bottleneck_bf16', ev0, ev1, 2.0 * 17 * cm * cm * N * H * W, 2.0 * 2 * C * N * H * W + 2.0 * 17 * cm * cm))
+    return out
+
+
 def conv2d_nhwc_splitk(x, wpack, ldw, bias, cout, ksize, stride, pad, ksplit, relu=False, residual=None):
     """conv2d_nhwc for one small map with the K walk split over `ksplit` workgroups per tile (+ a reduce/epilogue kernel)."""
     require_cuda(x, wpack)
