@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
     // are XD deep in flight in registers, weight fragments WD k-steps deep.
     constexpr int NLD = NROWS * 4 / 256;                         // 16-byte units per thread and slab
     constexpr int NSLAB = C / 32;
-    constexpr int XD = 3, WD = CBW == 1 ? 6 : 4;
+    constexpr int XD = 3, WD = CBW == 1 ? 8 : 6;
     unsigned xoff[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -154,6 +154,12 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
             const int buf = s & 1;
+            bnk_bf16x8 xf[2][PBPW];          // both k-steps of the slab: the LDS latency is paid once per slab, not per MFMA group
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < PBPW; ++j)
+                    xf[kk][j] = *reinterpret_cast<const bnk_bf16x8 *>(XS + buf * (NROWS * XS_P) + ((wp * PBPW + j) * 32 + l32) * XS_P + (kk * 2 + lhalf) * 16);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int kg = 2 * s + kk;
@@ -165,12 +171,9 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
                     for (int i = 0; i < CBW; ++i) wq[kg % WD][i] = BNK_WLOAD(w1, wc * CBW + i, K1S, kg + WD);
                 }
 #pragma unroll
-                for (int j = 0; j < PBPW; ++j) {
-                    const int row = (wp * PBPW + j) * 32 + l32;
-                    const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(XS + buf * (NROWS * XS_P) + row * XS_P + (kk * 2 + lhalf) * 16);
+                for (int j = 0; j < PBPW; ++j)
 #pragma unroll
-                    for (int i = 0; i < CBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf, acc[i][j], 0, 0, 0);
-                }
+                    for (int i = 0; i < CBW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[kk][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);      // (keeps the prefetches where they are issued: the scheduler sinks them otherwise)
             }
             if (s + 1 < NSLAB) {
@@ -230,10 +233,12 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
         for (int i = 0; i < CBW; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias[i][g] = *reinterpret_cast<const float4 *>(p.b2 + (wc * CBW + i) * 32 + 8 * g + 4 * lhalf);
+#define BNK_T1_FRAG(J, KG) (*reinterpret_cast<const bnk_bf16x8 *>(T1 + (prow[J] + ((KG) / (CM / 16) / 3) * PWD + ((KG) / (CM / 16) % 3)) * T_P + (((KG) % (CM / 16)) * 16 + lhalf * 8) * 2))
+        bnk_bf16x8 xf[PBOW], xn[PBOW];   // activation fragments one k-step ahead as well
+#pragma unroll
+        for (int j = 0; j < PBOW; ++j) xf[j] = BNK_T1_FRAG(j, 0);
 #pragma unroll
         for (int kg = 0; kg < K2S; ++kg) {
-            const int tap = kg / (CM / 16), ks = kg % (CM / 16);
-            const int sh = (tap / 3) * PWD + (tap % 3);
             bnk_bf16x8 wf[CBW];
 #pragma unroll
             for (int i = 0; i < CBW; ++i) wf[i] = wq[kg % WD][i];
@@ -241,14 +246,19 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #pragma unroll
                 for (int i = 0; i < CBW; ++i) wq[kg % WD][i] = BNK_WLOAD(w2, wc * CBW + i, K2S, kg + WD);
             }
+            if (kg + 1 < K2S) {
 #pragma unroll
-            for (int j = 0; j < PBOW; ++j) {
-                const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(T1 + (prow[j] + sh) * T_P + (ks * 16 + lhalf * 8) * 2);
-#pragma unroll
-                for (int i = 0; i < CBW; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf, acc2[i][j], 0, 0, 0);
+                for (int j = 0; j < PBOW; ++j) xn[j] = BNK_T1_FRAG(j, kg + 1);
             }
+#pragma unroll
+            for (int j = 0; j < PBOW; ++j)
+#pragma unroll
+                for (int i = 0; i < CBW; ++i) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc2[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < PBOW; ++j) xf[j] = xn[j];
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef BNK_T1_FRAG
 #pragma unroll
         for (int j = 0; j < PBOW; ++j)
 #pragma unroll
@@ -292,17 +302,25 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
         for (int j = 0; j < PBO; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#define BNK_T2_FRAG(J, KS) (*reinterpret_cast<const bnk_bf16x8 *>(T2 + ((J) * 32 + l32) * T_P + ((KS) * 16 + lhalf * 8) * 2))
+        bnk_bf16x8 xf[PBO], xn[PBO];
+#pragma unroll
+        for (int j = 0; j < PBO; ++j) xf[j] = BNK_T2_FRAG(j, 0);
 #pragma unroll
         for (int ks = 0; ks < K3S; ++ks) {
             const bnk_bf16x8 wf = wq[ks % WD3];
             if (ks + WD3 < K3S) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3S, ks + WD3);
+            if (ks + 1 < K3S) {
 #pragma unroll
-            for (int j = 0; j < PBO; ++j) {
-                const bnk_bf16x8 xf = *reinterpret_cast<const bnk_bf16x8 *>(T2 + (j * 32 + l32) * T_P + (ks * 16 + lhalf * 8) * 2);
-                acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc3[j], 0, 0, 0);
+                for (int j = 0; j < PBO; ++j) xn[j] = BNK_T2_FRAG(j, ks + 1);
             }
+#pragma unroll
+            for (int j = 0; j < PBO; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[j], acc3[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < PBO; ++j) xf[j] = xn[j];
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef BNK_T2_FRAG
 #pragma unroll
         for (int j = 0; j < PBO; ++j) {
             const int pc = j * 32 + l32;

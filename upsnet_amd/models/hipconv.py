@@ -174,7 +174,7 @@ def _bf16_plan(m):
 # bf16 mode: an identity bottleneck (three layers + shortcut) as one launch whose intermediates stay in the LDS
 # (csrc/bottleneck_bf16.hip). UPSNET_BF16_BLOCK=0: three launches (A/B runs).
 BF16_BLOCK = os.environ.get('UPSNET_BF16_BLOCK', '1') != '0'
-BF16_BLOCK_MIN_TILES = int(os.environ.get('UPSNET_BF16_BLOCK_MIN_TILES', '64'))
+BF16_BLOCK_MIN_TILES = int(os.environ.get('UPSNET_BF16_BLOCK_MIN_TILES', '128'))
 
 
 def use_block(blk, x):
@@ -186,8 +186,8 @@ def use_block(blk, x):
     cm = c1.out_channels
     plain = lambda m, k, p: (tuple(m.kernel_size) == (k, k) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (p, p) and
                              tuple(m.dilation) == (1, 1) and m.groups == 1)
-    # (the kernel's tiles are 8x16 / 8x8 / 4x8 pixels at widths 64 / 128 / >= 256: a map with fewer tiles than a quarter of the CUs stays on the
-    # separate layers, whose split-K instances fill the chip)
+    # (the kernel's tiles are 8x16 / 8x8 / 4x8 pixels at widths 64 / 128 / >= 256: a map with fewer tiles than half the CUs -- res5 at
+    # 1024x2048, 64 tiles, 9 MB of weights per block -- stays on the separate layers: measured 156 us fused vs 130 us)
     th, tw = {64: (8, 16), 128: (8, 8)}.get(cm, (4, 8))
     if x.shape[0] * -(-x.shape[2] // th) * -(-x.shape[3] // tw) < BF16_BLOCK_MIN_TILES:
         return False
