@@ -255,6 +255,10 @@ int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], cons
                             int relu);
 int upsnet_conv_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, void *wpack_hi,
                                  void *wpack_lo);
+/* A/B switch of the 3x3 / stride 1 / 256 -> 256 layers in the plain bf16 mode (csrc/conv3x3_wreg_bf16.hip: weights fed to the MFMA
+ * from L2, one barrier per 32-channel slab): enable 0 = the general haloed-patch kernel, 1 = default; tile_rows 0 = automatic,
+ * 8 / 16 = forced tile height. Same products and K order either way. */
+int upsnet_conv_bf16_tuning(int enable, int tile_rows);
 
 /* One identity bottleneck of the backbone (upsnet/models/resnet.py:84-100: conv1 1x1 C -> Cm, conv2 3x3 Cm -> Cm, conv3 1x1 Cm -> C,
  * C = 4 Cm, stride 1, no projection; frozen BN folded; out = relu(conv3(relu(conv2(relu(conv1(x))))) + x)) as ONE launch on the bf16

@@ -50,9 +50,12 @@ class FPN(nn.Module):
         # top-down pathway: the lateral 1x1 and the "+ upsampled" add are one kernel (residual epilogue)
         # (and for nearest upsampling the x2 upsample is folded into the residual read: nothing is materialised)
         if self.upsample_method == 'nearest' and all(t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0 for t in (res2, res3, res4)):
+            # (bf16 mode: the two large top-down maps are only read by bf16 kernels -- the next lateral's shortcut and the 3x3 output
+            # convolution, which rounds its input to bf16 anyway -- and are stored as bf16)
+            ad = hipconv.act_dtype()
             p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=p5_1x1, residual_up=True)
-            p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=p4_plus, residual_up=True)
-            p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=p3_plus, residual_up=True)
+            p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=p4_plus, residual_up=True, out_dtype=ad)
+            p2_plus = hipconv.conv(self.fpn_p2_1x1, res2, residual=p3_plus, residual_up=True, out_dtype=ad)
         else:
             p4_plus = hipconv.conv(self.fpn_p4_1x1, res4, residual=self.fpn_upsample(p5_1x1))
             p3_plus = hipconv.conv(self.fpn_p3_1x1, res3, residual=self.fpn_upsample(p4_plus))
