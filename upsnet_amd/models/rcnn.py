@@ -4,6 +4,7 @@ MI355X notes: FPNRoIAlign delivers channels-last pooled features straight from t
 consumes them without a transpose by using fc6's weight re-laid-out once to the (ph, pw, c) flatten
 order (same dot products, different summation order); the mask head's convolutions take channels-last.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -70,18 +71,24 @@ class RCNN(nn.Module):
         nn.init.normal_(self.bbox_pred.weight.data, 0, 0.001)
         self.bbox_pred.bias.data.fill_(0)
 
-    def _fc6_weight_nhwc(self):
+    def _fc6_weight_nhwc(self, dtype=torch.float32):
         w = self.fc6[0].weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, dtype)
         if self._fc6_nhwc is None or self._fc6_nhwc[0] != key:
             p = self.pool_size
-            wp = w.detach().view(-1, self.dim_in, p, p).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+            wp = w.detach().view(-1, self.dim_in, p, p).permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
             self._fc6_nhwc = (key, wp)
         return self._fc6_nhwc[1]
 
     def forward(self, feat, rois, num_rois_dev=None):
         pool_feat = self.roi_pooling(feat, rois, num_rois_dev)            # channels_last [N,C,7,7]
         flat = pool_feat.permute(0, 2, 3, 1).reshape(pool_feat.size(0), -1)  # a view: physical (ph,pw,c) order
-        fc6 = F.relu(F.linear(flat, self._fc6_weight_nhwc(), self.fc6[0].bias), inplace=True)
+        if hipconv.PRECISION == 'bf16' and flat.is_cuda:
+            # BASELINE configs[2]: the one large GEMM of the box head (1000 x 12544 x 1024, 26 GFLOP: 190 us as an fp32 library
+            # GEMM) with bf16 operands, fp32 accumulation; bias + ReLU in fp32
+            fc6 = F.linear(flat.to(torch.bfloat16), self._fc6_weight_nhwc(torch.bfloat16)).float()
+            fc6 = F.relu_(fc6.add_(self.fc6[0].bias))
+        else:
+            fc6 = F.relu(F.linear(flat, self._fc6_weight_nhwc(), self.fc6[0].bias), inplace=True)
         fc7 = self.fc7(fc6)
         return {'cls_score': self.cls_score(fc7), 'bbox_pred': self.bbox_pred(fc7), 'fc_feat': fc7}
