@@ -488,30 +488,31 @@ def test_conv_splitk_vs_unsplit(N, Cin, Cout, H, W, k, stride, ksplit, relu, res
     assert torch.equal(out, ops.conv2d_nhwc_splitk(x, wp, ldw, b, Cout, k, stride, k // 2, ksplit, relu=relu, residual=r))
 
 
-@pytest.mark.parametrize("shapes,Cin,relu,bias", [
-    ([(2, 14, 14)], 256, True, True),                                          # mask-head layer: two 8-row tiles per ROI
-    ([(1, 37, 53)], 256, False, True),                                         # ragged in both directions
-    ([(1, 64, 96), (1, 32, 48), (1, 16, 24), (1, 8, 12), (1, 4, 6)], 256, True, True),   # RPN: five levels in one launch
-    ([(1, 40, 24)], 96, True, False),                                          # three K slabs, no bias
+@pytest.mark.parametrize("shapes,Cin,Cout,relu,bias", [
+    ([(2, 14, 14)], 256, 256, True, True),                                     # mask-head layer: two 8-row tiles per ROI
+    ([(1, 37, 53)], 256, 256, False, True),                                    # ragged in both directions
+    ([(1, 64, 96), (1, 32, 48), (1, 16, 24), (1, 8, 12), (1, 4, 6)], 256, 256, True, True),   # RPN: five levels in one launch
+    ([(1, 40, 24)], 96, 256, True, False),                                     # three K slabs, no bias
+    ([(1, 16, 32)], 512, 512, True, True),                                     # res5 conv2: two 256-channel blocks, 2-row tiles
 ])
 @pytest.mark.parametrize("io", [0, 1, 2, 3])
-def test_conv3x3_wreg_bf16_kernel(shapes, Cin, relu, bias, io):
-    """csrc/conv3x3_wreg_bf16.hip (3x3 / 1 / 1, 256 output channels, plain bf16: weights straight from L2 into the MFMA, one barrier
-    per slab) vs float64 on the bf16-rounded operands; both tile heights and the general haloed-patch kernel give the same bits
-    (same products, same K order); io = bf16 inputs (bit 0) / outputs (bit 1)."""
+def test_conv3x3_wreg_bf16_kernel(shapes, Cin, Cout, relu, bias, io):
+    """csrc/conv3x3_wreg_bf16.hip (3x3 / 1 / 1, output channels in blocks of 256, plain bf16: weights straight from L2 into the MFMA,
+    one barrier per slab) vs float64 on the bf16-rounded operands; every tile height and the general haloed-patch kernel give the
+    same bits (same products, same K order); io = bf16 inputs (bit 0) / outputs (bit 1)."""
     from upsnet_amd import ops
     from upsnet_amd._lib import lib
     torch.manual_seed(Cin + len(shapes) + io)
     in16, out16 = bool(io & 1), bool(io & 2)
     xs = [torch.randn(n, Cin, h, w, device='cuda') for n, h, w in shapes]
     xin = [x.bfloat16() if in16 else x for x in xs]
-    w = torch.randn(256, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
-    b = torch.randn(256, device='cuda') if bias else None
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
     hi, _, ldw = ops.pack_conv_weight_bf16(w, split=False)
-    run = lambda: ops.conv2d_nhwc_bf16_multi(xin, hi, None, ldw, b, 256, 3, 1, 1, relu=relu, out_dtype=torch.bfloat16 if out16 else torch.float32)
+    run = lambda: ops.conv2d_nhwc_bf16_multi(xin, hi, None, ldw, b, Cout, 3, 1, 1, relu=relu, out_dtype=torch.bfloat16 if out16 else torch.float32)
     outs = {}
     try:
-        for name, (en, th) in {'halo': (0, 0), 'wreg8': (1, 8), 'wreg16': (1, 16), 'auto': (1, 0)}.items():
+        for name, (en, th) in {'halo': (0, 0), 'wreg2': (1, 2), 'wreg8': (1, 8), 'wreg16': (1, 16), 'auto': (1, 0)}.items():
             assert lib().upsnet_conv_bf16_tuning(en, th) == 0
             outs[name] = run()
     finally:
@@ -523,6 +524,6 @@ def test_conv3x3_wreg_bf16_kernel(shapes, Cin, relu, bias, io):
         assert o.shape == ref.shape and o.dtype == (torch.bfloat16 if out16 else torch.float32) and o.permute(0, 2, 3, 1).is_contiguous()
         tol = 2.0 ** -8 if out16 else 1e-4
         np.testing.assert_allclose(o.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
-    for name in ('halo', 'wreg8', 'wreg16'):
+    for name in ('halo', 'wreg2', 'wreg8', 'wreg16'):
         for a, o in zip(outs[name], outs['auto']):
             assert torch.equal(a, o), name

@@ -22,31 +22,34 @@ def timeit(fn, n=20):
 
 
 def main():
-    w = (torch.randn(256, 256, 3, 3) / 48.0).cuda()
-    b = torch.randn(256).cuda()
-    hi, _, ldw = ops.pack_conv_weight_bf16(w, split=False)
     cases = {
         'FPN out P2-P5': [(1, 256, 512), (1, 128, 256), (1, 64, 128), (1, 32, 64)],
         'FPN out P2': [(1, 256, 512)],
         'RPN P2-P6': [(1, 256, 512), (1, 128, 256), (1, 64, 128), (1, 32, 64), (1, 16, 32)],
         'mask head 100 ROIs': [(100, 14, 14)],
         'mask head 40 ROIs': [(40, 14, 14)],
+        'res4 conv2': [(1, 64, 128)],
+        'res5 conv2 (512)': [(1, 32, 64)],
     }
     for name, shapes in cases.items():
+        C = 512 if '512' in name else 256
+        w = (torch.randn(C, C, 3, 3) / (9 * C) ** 0.5).cuda()
+        b = torch.randn(C).cuda()
+        hi, _, ldw = ops.pack_conv_weight_bf16(w, split=False)
         for in16 in (False, True):
-            xs = [torch.randn(n, 256, h, w_, device='cuda').contiguous(memory_format=torch.channels_last) for n, h, w_ in shapes]
+            xs = [torch.randn(n, C, h, w_, device='cuda').contiguous(memory_format=torch.channels_last) for n, h, w_ in shapes]
             if in16:
                 xs = [x.bfloat16() for x in xs]
             px = sum(n * h * w_ for n, h, w_ in shapes)
             row = []
-            for en, th in ((0, 0), (1, 8), (1, 16), (1, 0)):
+            for en, th in ((0, 0), (1, 2), (1, 8), (1, 16), (1, 0)):
                 lib().upsnet_conv_bf16_tuning(en, th)
-                t = timeit(lambda: ops.conv2d_nhwc_bf16_multi(xs, hi, None, ldw, b, 256, 3, 1, 1, relu=True))
+                t = timeit(lambda: ops.conv2d_nhwc_bf16_multi(xs, hi, None, ldw, b, C, 3, 1, 1, relu=True))
                 row.append(t)
             lib().upsnet_conv_bf16_tuning(1, 0)
-            fl = 2.0 * 9 * 256 * 256 * px
-            print("%-20s %s in   halo %7.1f us   wreg8 %7.1f   wreg16 %7.1f   auto %7.1f us (%5.0f TFLOP/s)"
-                  % (name, 'bf16' if in16 else 'fp32', row[0], row[1], row[2], row[3], fl / row[3] * 1e-6), flush=True)
+            fl = 2.0 * 9 * C * C * px
+            print("%-20s %s in   halo %7.1f us   wreg2 %7.1f   wreg8 %7.1f   wreg16 %7.1f   auto %7.1f us (%5.0f TFLOP/s)"
+                  % (name, 'bf16' if in16 else 'fp32', row[0], row[1], row[2], row[3], row[4], fl / row[4] * 1e-6), flush=True)
 
 
 if __name__ == '__main__':

@@ -61,10 +61,11 @@ __device__ static inline unsigned w3_pack2(const float a, const float b)
 }
 
 template <int TH, int IO>
-__global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_kernel(const ConvParams p, const char *__restrict__ wpk)
+__global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x3_wreg_bf16_kernel(const ConvParams p, const char *__restrict__ wpk)
 {
     constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
-    constexpr int NT = 32 * TH;                                     // threads: 4 waves per 8 tile rows
+    constexpr int NT = TH == 16 ? 512 : 256;                        // threads: 4 waves per 8 tile rows
+    constexpr int NPB = TH >= 8 ? 4 : TH / 2;                       // 2 x 16 pixel blocks per wave
     constexpr int NPATCH = (TH + 2) * W3_PW, NROWS = (NPATCH + 31) / 32 * 32;
     constexpr int UPR = IN16 ? 4 : 8;                               // 16-byte units per patch pixel and slab
     constexpr int NLD = (NROWS * UPR + NT - 1) / NT;
@@ -74,12 +75,13 @@ __global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_ke
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, lhalf = lane >> 5;
     const int wc = wave & 3, wp = wave >> 2;
-    int m_t;
+    int m_t, n_t;
     {   // XCD-aware tile order: consecutive tiles of a map share an XCD's L2 (block b runs on XCD b % 8)
         const int bid = blockIdx.x;
         const int per = (p.m_tiles + 7) >> 3;
-        const int local = bid >> 3;
-        m_t = (bid & 7) * per + local;
+        const int q = bid >> 3;
+        n_t = q % p.n_tiles;                      // 256-channel block of the output
+        m_t = (bid & 7) * per + q / p.n_tiles;
         if (m_t >= p.m_tiles) return;
     }
     int si = 0;
@@ -121,20 +123,20 @@ __global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_ke
     // weight fragment of this wave's 32-column block I, slab S (= tap * cslabs + cs), k-step T: 16 bytes per lane; the lane part of
     // the address is one register, the slab / k-step part wave-uniform (SGPR offset of the buffer load)
     const __amdgpu_buffer_rsrc_t wrsrc = w3_rsrc(wpk, 9u * (unsigned)p.Cin * (unsigned)p.ldw * 2u);
-    const unsigned wvo = (unsigned)((2 * wc) * 32 + l32) * 64u + 16u * (unsigned)lhalf;
+    const unsigned wvo = (unsigned)((8 * n_t + 2 * wc) * 32 + l32) * 64u + 16u * (unsigned)lhalf;
     const unsigned slab_bytes = (unsigned)p.ldw * 64u;
 #define W3_WLOAD(I, S, T) w3_as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo + (I) * 2048u, (unsigned)(S) * slab_bytes + 32u * (unsigned)(T), 0))
 
-    floatx16 acc[2][4];
+    floatx16 acc[2][NPB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NPB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int prow[4];                     // lane's pixel in block j: byte offset of the top-left patch pixel of its 3x3 window
+    int prow[NPB];                   // lane's pixel in block j: byte offset of the top-left patch pixel of its 3x3 window
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPB; ++j) {
         const int pp = w3_perm(l32), y = 2 * (wp * 4 + j) + (pp >> 4), x = pp & 15;
         prow[j] = (y * W3_PW + x) * W3_XP + lhalf * 16;
     }
@@ -169,11 +171,11 @@ __global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_ke
                     for (int i = 0; i < 2; ++i) wq[kk % WD][i] = W3_WLOAD(i, ntap * cslabs + ncs, nt);
                 }
             }
-            w3_bf16x8 xf[4];
+            w3_bf16x8 xf[NPB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const w3_bf16x8 *>(&XS[buf][prow[j] + sh]);
+            for (int j = 0; j < NPB; ++j) xf[j] = *reinterpret_cast<const w3_bf16x8 *>(&XS[buf][prow[j] + sh]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NPB; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -193,9 +195,9 @@ __global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_ke
         float4 b[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            b[g] = has_bias ? *reinterpret_cast<const float4 *>(p.bias + (2 * wc + i) * 32 + 8 * g + 4 * lhalf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[g] = has_bias ? *reinterpret_cast<const float4 *>(p.bias + (8 * n_t + 2 * wc + i) * 32 + 8 * g + 4 * lhalf) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NPB; ++j) {
             const int pp = w3_perm(l32);
             const int oy = y0 + 2 * (wp * 4 + j) + (pp >> 4), ox = x0 + (pp & 15);
             const unsigned pix = (oy < sg.Ho && ox < sg.Wo) ? (unsigned)((t_n * sg.Ho + oy) * sg.Wo + ox) * (unsigned)p.Cout : 0x20000000u;
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) conv3x3_wreg_bf16_ke
                 float v0 = acc[i][j][4 * g + 0] + b[g].x, v1 = acc[i][j][4 * g + 1] + b[g].y;
                 float v2 = acc[i][j][4 * g + 2] + b[g].z, v3 = acc[i][j][4 * g + 3] + b[g].w;
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                const unsigned e = pix + (unsigned)((2 * wc + i) * 32 + 8 * g + 4 * lhalf);
+                const unsigned e = pix + (unsigned)((8 * n_t + 2 * wc + i) * 32 + 8 * g + 4 * lhalf);
                 if (OUT16) {
                     w3_uintx2 pk;
                     pk.x = w3_pack2(v0, v1); pk.y = w3_pack2(v2, v3);
@@ -225,19 +227,20 @@ static int g_wreg_on = -1, g_wreg_th = -1;     // -1: from the environment on fi
  * (default); tile_rows 0 = automatic, 8 or 16 = force the tile height. Results do not depend on either. */
 extern "C" int upsnet_conv_bf16_tuning(int enable, int tile_rows)
 {
-    UPS_REQUIRE((enable == 0 || enable == 1) && (tile_rows == 0 || tile_rows == 8 || tile_rows == 16), "conv_bf16_tuning: enable 0/1, tile_rows 0/8/16");
+    UPS_REQUIRE((enable == 0 || enable == 1) && (tile_rows == 0 || tile_rows == 2 || tile_rows == 8 || tile_rows == 16), "conv_bf16_tuning: enable 0/1, tile_rows 0/2/8/16");
     g_wreg_on = enable; g_wreg_th = tile_rows;
     return 0;
 }
 
-// Does this launch fit the kernel? (3x3 / 1 / 1 is checked by the caller.) 256 output channels, no residual, plain bf16 products.
+// Does this launch fit the kernel? (3x3 / 1 / 1 is checked by the caller.) Output channels in blocks of 256, no residual, plain bf16
+// products.
 bool conv3x3_wreg_bf16_supported(const ConvParams &p)
 {
     if (g_wreg_on < 0) {
         g_wreg_on = !(getenv("UPSNET_BF16_WREG") != nullptr && getenv("UPSNET_BF16_WREG")[0] == '0');
         g_wreg_th = getenv("UPSNET_BF16_WREG_TH") ? atoi(getenv("UPSNET_BF16_WREG_TH")) : 0;
     }
-    if (!g_wreg_on || p.Cout != 256 || p.ldw != 256 || p.Cin % 32 != 0 || p.res_up) return false;
+    if (!g_wreg_on || p.Cout % 256 != 0 || p.ldw != p.Cout || p.Cin % 32 != 0 || p.res_up) return false;
     for (int i = 0; i < p.nseg; ++i)
         if (p.seg[i].res) return false;
     return true;
@@ -245,22 +248,32 @@ bool conv3x3_wreg_bf16_supported(const ConvParams &p)
 
 int conv3x3_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi)
 {
-    // 8 x 16 tiles, two workgroups per CU. (16 x 16 tiles -- 8 waves, the patch halo and the weight fragments shared by twice the
-    // pixels, one workgroup per CU -- measured 3-7 % slower on the FPN / RPN maps and 50 % slower on the mask head's 14 x 14 ROIs:
-    // tools/microbench_conv3x3_bf16.py; kept behind upsnet_conv_bf16_tuning.)
-    const int th = g_wreg_th == 16 ? 16 : 8;
+    // 8 x 16 pixel tiles, two workgroups per CU. (16 x 16 tiles -- 8 waves, the patch halo and the weight fragments shared by twice
+    // the pixels, one workgroup per CU -- measured 3-7 % slower on the FPN / RPN maps and 50 % slower on the mask head's 14 x 14
+    // ROIs: tools/microbench_conv3x3_bf16.py; kept behind upsnet_conv_bf16_tuning.) Small maps (res4 / res5 at 1024x2048: 64 / 16
+    // tiles of 8 x 16): 2 x 16 tiles, four times the workgroups (each streams the whole weight block for 32 pixels: only where
+    // the chip would otherwise idle).
+    p.n_tiles = p.Cout / 256;
+    auto count = [&](int th) {
+        int t = 0;
+        for (int i = 0; i < p.nseg; ++i) t += p.seg[i].N * ((p.seg[i].Ho + th - 1) / th) * ((p.seg[i].Wo + W3_TW - 1) / W3_TW);
+        return t;
+    };
+    const int th = (g_wreg_th == 2 || g_wreg_th == 8 || g_wreg_th == 16) ? g_wreg_th : (count(8) * p.n_tiles < 72 ? 2 : 8);
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) {
         p.seg[i].tile_start = tiles;
         tiles += p.seg[i].N * ((p.seg[i].Ho + th - 1) / th) * ((p.seg[i].Wo + W3_TW - 1) / W3_TW);
     }
     p.m_tiles = tiles;
-    p.n_tiles = 1;
-    const int grid = 8 * ((tiles + 7) / 8);
+    const int grid = 8 * ((tiles + 7) / 8) * p.n_tiles;
     const char *w = reinterpret_cast<const char *>(wpack_hi);
-#define W3_GO(TH_, IO_) hipLaunchKernelGGL((conv3x3_wreg_bf16_kernel<TH_, IO_>), dim3(grid), dim3(32 * TH_), 0, st, p, w)
-    if (th == 16) switch (p.io & 3) { case 0: W3_GO(16, 0); break; case 1: W3_GO(16, 1); break; case 2: W3_GO(16, 2); break; default: W3_GO(16, 3); break; }
-    else switch (p.io & 3) { case 0: W3_GO(8, 0); break; case 1: W3_GO(8, 1); break; case 2: W3_GO(8, 2); break; default: W3_GO(8, 3); break; }
+#define W3_GO(TH_, IO_) hipLaunchKernelGGL((conv3x3_wreg_bf16_kernel<TH_, IO_>), dim3(grid), dim3(TH_ == 16 ? 512 : 256), 0, st, p, w)
+#define W3_GO_IO(TH_) switch (p.io & 3) { case 0: W3_GO(TH_, 0); break; case 1: W3_GO(TH_, 1); break; case 2: W3_GO(TH_, 2); break; default: W3_GO(TH_, 3); break; }
+    if (th == 16) W3_GO_IO(16)
+    else if (th == 8) W3_GO_IO(8)
+    else W3_GO_IO(2)
+#undef W3_GO_IO
 #undef W3_GO
     UPS_CHECK_LAUNCH("conv3x3_wreg_bf16_kernel");
     return 0;
