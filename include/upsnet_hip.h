@@ -259,6 +259,10 @@ int upsnet_conv_pack_weight_bf16(void *stream, const float *weight, int cout, in
  * from L2, one barrier per 32-channel slab): enable 0 = the general haloed-patch kernel, 1 = default; tile_rows 0 = automatic,
  * 8 / 16 = forced tile height. Same products and K order either way. */
 int upsnet_conv_bf16_tuning(int enable, int tile_rows);
+/* A/B switch of the 1x1 layers with bf16 activations in the plain bf16 mode (csrc/conv1x1_wreg_bf16.hip: both MFMA operands loaded
+ * from global memory in fragment order, no LDS, no barrier): enable 0 = conv_bf16_kernel, 1 = default (the layers it is faster on:
+ * shortcut epilogue, Cin <= 256), 2 = every layer it can compute. Same products and K order. */
+int upsnet_conv1x1_bf16_tuning(int enable);
 
 /* One identity bottleneck of the backbone (upsnet/models/resnet.py:84-100: conv1 1x1 C -> Cm, conv2 3x3 Cm -> Cm, conv3 1x1 Cm -> C,
  * C = 4 Cm, stride 1, no projection; frozen BN folded; out = relu(conv3(relu(conv2(relu(conv1(x))))) + x)) as ONE launch on the bf16

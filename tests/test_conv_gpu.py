@@ -527,3 +527,50 @@ def test_conv3x3_wreg_bf16_kernel(shapes, Cin, Cout, relu, bias, io):
     for name in ('halo', 'wreg2', 'wreg8', 'wreg16'):
         for a, o in zip(outs[name], outs['auto']):
             assert torch.equal(a, o), name
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride,relu,res,bias", [
+    (1, 64, 256, 40, 56, 1, True, 'bf16', True),        # res2 conv3 + bf16 shortcut
+    (1, 64, 256, 40, 56, 1, False, None, True),         # res2 projection
+    (2, 256, 128, 41, 57, 2, True, None, True),         # res3 conv1: stride 2, odd map, 128 channels (128 x 128 tiles)
+    (1, 256, 512, 41, 57, 2, False, None, False),       # res3 projection, no bias
+    (1, 1024, 256, 16, 24, 1, False, 'up32', True),     # FPN lateral: fp32 top-down map through the nearest x2 upsampling
+    (1, 512, 256, 32, 48, 1, False, 'up16', True),      # the same with a bf16 top-down map
+    (1, 2048, 512, 7, 9, 1, True, 'fp32', True),        # K of 128 k-steps, map smaller than a tile
+    (3, 128, 384, 5, 5, 1, True, None, True),           # 384 channels: 128-channel blocks
+])
+@pytest.mark.parametrize("out16", [True, False])
+def test_conv1x1_wreg_bf16_kernel(N, Cin, Cout, H, W, stride, relu, res, bias, out16):
+    """csrc/conv1x1_wreg_bf16.hip (1x1 layers with bf16 activations in the bf16 mode: both MFMA operands from global memory, no LDS)
+    vs float64 on the bf16-rounded operands, and bit for bit against conv_bf16_kernel (same products, same K order)."""
+    from upsnet_amd import ops
+    from upsnet_amd._lib import lib
+    torch.manual_seed(N + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device='cuda').bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r, up = None, res in ('up32', 'up16')
+    if res is not None:
+        r = torch.randn(N, Cout, Ho // 2, Wo // 2, device='cuda') if up else torch.randn(N, Cout, Ho, Wo, device='cuda')
+        if res in ('bf16', 'up16'):
+            r = r.bfloat16()
+    ref = F.conv2d(x.double(), w.bfloat16().double(), None if b is None else b.double(), stride=stride)
+    if r is not None:
+        ref = ref + (F.interpolate(r.double(), scale_factor=2, mode='nearest') if up else r.double())
+    if relu:
+        ref = ref.clamp_min(0)
+    hi, _, ldw = ops.pack_conv_weight_bf16(w, split=False)
+    run = lambda: ops.conv2d_nhwc_bf16_multi([x], hi, None, ldw, b, Cout, 1, stride, 0, relu=relu, residuals=None if r is None else [r],
+                                             residual_up=up, out_dtype=torch.bfloat16 if out16 else torch.float32)[0]
+    try:
+        assert lib().upsnet_conv1x1_bf16_tuning(0) == 0
+        old = run()
+        assert lib().upsnet_conv1x1_bf16_tuning(2) == 0      # (2: every layer the kernel can compute, not only those it is faster on)
+        out = run()
+    finally:
+        lib().upsnet_conv1x1_bf16_tuning(1)
+    assert out.shape == ref.shape and out.dtype == (torch.bfloat16 if out16 else torch.float32) and out.permute(0, 2, 3, 1).is_contiguous()
+    tol = 2.0 ** -8 if out16 else 1e-4
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
+    assert torch.equal(out, old)

@@ -559,6 +559,9 @@ conv3x3_bf16_halo_kernel(const ConvParams p, const __bf16 *__restrict__ whi, con
     }
 }
 
+// conv1x1_wreg_bf16.hip
+bool conv1x1_wreg_bf16_supported(const ConvParams &p);
+int conv1x1_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi);
 // conv3x3_wreg_bf16.hip
 bool conv3x3_wreg_bf16_supported(const ConvParams &p);
 int conv3x3_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi);
@@ -592,6 +595,8 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * Cin < (1L << 29), "conv2d_nhwc_bf16: feature map %d exceeds 2 GiB; split the batch", i);
     const __bf16 *hi = reinterpret_cast<const __bf16 *>(wpack_hi), *lo = reinterpret_cast<const __bf16 *>(wpack_lo);
     static const bool no_halo = getenv("UPSNET_BF16_HALO") != nullptr && getenv("UPSNET_BF16_HALO")[0] == '0';
+    if (!lo && KH == 1 && KW == 1 && pad == 0 && conv1x1_wreg_bf16_supported(p))   // bf16 activations: both operands from global memory
+        return conv1x1_wreg_bf16_launch((hipStream_t)stream, p, wpack_hi);
     if (!lo && KH == 3 && KW == 3 && stride == 1 && pad == 1 && conv3x3_wreg_bf16_supported(p))   // 256 -> 256 layers: weights from L2
         return conv3x3_wreg_bf16_launch((hipStream_t)stream, p, wpack_hi);
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && !no_halo) {   // haloed-patch kernel: 8 x 16 pixel tiles
