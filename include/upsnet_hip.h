@@ -263,6 +263,12 @@ int upsnet_conv_bf16_tuning(int enable, int tile_rows);
  * from global memory in fragment order, no LDS, no barrier): enable 0 = conv_bf16_kernel, 1 = default (the layers it is faster on:
  * shortcut epilogue, Cin <= 256), 2 = every layer it can compute. Same products and K order. */
 int upsnet_conv1x1_bf16_tuning(int enable);
+/* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) of a bf16 NHWC map on the bf16 matrix cores (the mask head's
+ * upsampling layer, upsnet/models/rcnn.py:132-133, in the bf16 mode): one GEMM [N H W, Cin] x [Cin, 4 Cout] with a scatter epilogue.
+ * x [N,H,W,Cin] bf16; wpack_hi = upsnet_conv_pack_weight_bf16 of the [4 Cout, Cin, 1, 1] matrix whose rows are ordered (ky, kx, c),
+ * ldw = 4 Cout; bias [Cout] or NULL; out [N,2H,2W,Cout] fp32 (out_bf16 = 0) or bf16. Cin % 64 == 0, Cout % 32 == 0. */
+int upsnet_deconv2x2_nhwc_bf16(void *stream, const void *x, int batch, int height, int width, int Cin, const void *wpack_hi, int ldw,
+                               const float *bias, int Cout, int relu, void *out, int out_bf16);
 
 /* One identity bottleneck of the backbone (upsnet/models/resnet.py:84-100: conv1 1x1 C -> Cm, conv2 3x3 Cm -> Cm, conv3 1x1 Cm -> C,
  * C = 4 Cm, stride 1, no projection; frozen BN folded; out = relu(conv3(relu(conv2(relu(conv1(x))))) + x)) as ONE launch on the bf16

@@ -574,3 +574,26 @@ def test_conv1x1_wreg_bf16_kernel(N, Cin, Cout, H, W, stride, relu, res, bias, o
     tol = 2.0 ** -8 if out16 else 1e-4
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
     assert torch.equal(out, old)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,relu,bias,out16", [
+    (7, 256, 256, 14, 14, True, True, False),     # the mask head's upsampling layer
+    (1, 64, 32, 5, 9, False, False, True),        # one K slab, narrow output, bf16 result
+    (3, 128, 96, 6, 6, True, True, False),
+])
+def test_deconv2x2_bf16_vs_torch(N, Cin, Cout, H, W, relu, bias, out16):
+    """upsnet_deconv2x2_nhwc_bf16 (ConvTranspose2d 2x2 / stride 2 as one bf16 GEMM with a scatter epilogue; rcnn.py:132-133 in the
+    bf16 mode) vs torch's conv_transpose2d in float64 on the bf16-rounded operands."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, device='cuda').bfloat16()
+    w = torch.randn(Cin, Cout, 2, 2, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    ref = F.conv_transpose2d(x.double(), w.bfloat16().double(), None if b is None else b.double(), stride=2)
+    if relu:
+        ref = ref.clamp_min(0)
+    hi, ldw = ops.pack_deconv2x2_weight_bf16(w)
+    out = ops.deconv2x2_bf16(x, hi, ldw, b, Cout, relu=relu, out_dtype=torch.bfloat16 if out16 else torch.float32)
+    assert out.shape == ref.shape and out.permute(0, 2, 3, 1).is_contiguous()
+    tol = 2.0 ** -8 if out16 else 1e-4
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)

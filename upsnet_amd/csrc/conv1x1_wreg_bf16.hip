@@ -86,7 +86,9 @@ __global__ void __launch_bounds__(256, 2) conv1x1_wreg_bf16_kernel(const ConvPar
             const int oy = r / sg.Wo, ox = r - oy * sg.Wo;
             xoff[j] = (unsigned)((n * sg.H + oy * p.stride) * sg.W + ox * p.stride) * (unsigned)p.Cin * 2u + 16u * (unsigned)lhalf;
             ooff[j] = (unsigned)m * (unsigned)p.Cout;
-            roff[j] = p.res_up ? (unsigned)((n * (sg.Ho >> 1) + (oy >> 1)) * (sg.Wo >> 1) + (ox >> 1)) * (unsigned)p.Cout : ooff[j];
+            if (p.res_up == 2)   // transposed 2x2 / stride 2: element offset of output pixel (2 oy, 2 ox) of the [N, 2 Ho, 2 Wo, Cout / 4] map
+                ooff[j] = (unsigned)((n * 2 * sg.Ho + 2 * oy) * 2 * sg.Wo + 2 * ox) * (unsigned)(p.Cout >> 2);
+            roff[j] = p.res_up == 1 ? (unsigned)((n * (sg.Ho >> 1) + (oy >> 1)) * (sg.Wo >> 1) + (ox >> 1)) * (unsigned)p.Cout : ooff[j];
         }
     }
     const int cb0 = (n_t * NWC + wc) * 2;         // first of this wave's two 32-channel blocks
@@ -158,7 +160,9 @@ __global__ void __launch_bounds__(256, 2) conv1x1_wreg_bf16_kernel(const ConvPar
     }
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr, res16 = (p.io & 4) != 0;
     const unsigned oelems = (unsigned)sg.M * (unsigned)p.Cout;
-    const unsigned relems = p.res_up ? (unsigned)(sg.N * (sg.Ho >> 1) * (sg.Wo >> 1)) * (unsigned)p.Cout : oelems;
+    const unsigned relems = p.res_up == 1 ? (unsigned)(sg.N * (sg.Ho >> 1) * (sg.Wo >> 1)) * (unsigned)p.Cout : oelems;
+    const bool scatter = p.res_up == 2;          // GEMM column (ky, kx, c) -> output pixel (2 oy + ky, 2 ox + kx), channel c
+    const int c4 = p.Cout >> 2;
     const __amdgpu_buffer_rsrc_t orsrc = c1_rsrc(sg.out, oelems * (OUT16 ? 2u : 4u));
     const __amdgpu_buffer_rsrc_t rrsrc = c1_rsrc(has_res ? sg.res : sg.out, has_res ? relems * (res16 ? 2u : 4u) : 0u);
     constexpr int CPL = OUT16 ? 8 : 4;            // channels per lane and pass (16-byte stores)
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_wreg_bf16_kernel(const ConvPar
         if (has_bias) {
 #pragma unroll
             for (int c = 0; c < CPL; c += 4) {
-                const float4 b = *reinterpret_cast<const float4 *>(p.bias + ch + c);
+                const float4 b = *reinterpret_cast<const float4 *>(p.bias + (scatter ? ch % c4 : ch) + c);
                 v[c] = v[c] + b.x; v[c + 1] = v[c + 1] + b.y; v[c + 2] = v[c + 2] + b.z; v[c + 3] = v[c + 3] + b.w;
             }
         }
@@ -209,7 +213,9 @@ __global__ void __launch_bounds__(256, 2) conv1x1_wreg_bf16_kernel(const ConvPar
         c1_uintx4 pk;
         if (OUT16) { pk.x = c1_pack2(v[0], v[1]); pk.y = c1_pack2(v[2], v[3]); pk.z = c1_pack2(v[CPL - 4], v[CPL - 3]); pk.w = c1_pack2(v[CPL - 2], v[CPL - 1]); }
         else { pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]); pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]); }
-        __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (oo + (unsigned)ch) * (OUT16 ? 2u : 4u), 0, 0);
+        unsigned oe = oo + (unsigned)ch;
+        if (scatter) { const int q = ch / c4; oe = oo + (unsigned)(((q >> 1) * 2 * sg.Wo + (q & 1)) * c4 + (ch - q * c4)); }
+        __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, oe * (OUT16 ? 2u : 4u), 0, 0);
     }
 }
 
@@ -261,4 +267,25 @@ int conv1x1_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi
     }
     UPS_CHECK_LAUNCH("conv1x1_wreg_bf16_kernel");
     return 0;
+}
+
+/* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) of a bf16 NHWC map on the bf16 matrix cores: one GEMM
+ * [N H W, Cin] x [Cin, 4 Cout] whose epilogue scatters column (ky, kx, c) of pixel (y, x) to output pixel (2 y + ky, 2 x + kx) -- the
+ * mask head's upsampling layer (upsnet/models/rcnn.py:132-133) in the bf16 mode of BASELINE.json configs[2].
+ * x [N,H,W,Cin] bf16; wpack_hi: upsnet_conv_pack_weight_bf16 of the [4 Cout, Cin, 1, 1] matrix with rows (ky, kx, c), ldw = 4 Cout;
+ * bias [Cout] fp32 or NULL; out [N,2H,2W,Cout] fp32 (out_bf16 = 0) or bf16. Cin % 64 == 0, Cout % 32 == 0. */
+extern "C" int upsnet_deconv2x2_nhwc_bf16(void *stream, const void *x, int batch, int height, int width, int Cin, const void *wpack_hi,
+                                          int ldw, const float *bias, int Cout, int relu, void *out, int out_bf16)
+{
+    UPS_REQUIRE(x && wpack_hi && out, "deconv2x2_nhwc_bf16: null pointer");
+    UPS_REQUIRE(Cin % 64 == 0 && Cout % 32 == 0 && ldw == 4 * Cout, "deconv2x2_nhwc_bf16: Cin %% 64 == 0, Cout %% 32 == 0, ldw == 4 Cout");
+    ConvParams p;
+    const float *xs[1] = {reinterpret_cast<const float *>(x)};
+    float *outs[1] = {reinterpret_cast<float *>(out)};
+    int rc = conv_fill(p, "deconv2x2_nhwc_bf16", 1, xs, nullptr, nullptr, nullptr, outs, &batch, &height, &width, Cin, 4 * Cout,
+                       reinterpret_cast<const float *>(wpack_hi), ldw, bias, 1, 1, 1, 0, 1, relu != 0);
+    if (rc) return rc;
+    p.res_up = 2;
+    p.io = 1 | (out_bf16 ? 2 : 0);
+    return conv1x1_wreg_bf16_launch((hipStream_t)stream, p, wpack_hi);
 }

@@ -364,9 +364,22 @@ def conv_stem(m, x, relu=False):
 
 def deconv2x2(m, x, relu=False):
     """nn.ConvTranspose2d(k=2, s=2, p=0) (+ ReLU) as one MFMA GEMM with a scatter epilogue."""
-    ok = (ENABLED and isinstance(m, nn.ConvTranspose2d) and x.is_cuda and x.dtype == torch.float32 and tuple(m.kernel_size) == (2, 2) and
-          tuple(m.stride) == (2, 2) and tuple(m.padding) == (0, 0) and tuple(m.output_padding) == (0, 0) and m.groups == 1 and
-          tuple(m.dilation) == (1, 1) and m.in_channels % 32 == 0)
+    geom = (ENABLED and isinstance(m, nn.ConvTranspose2d) and x.is_cuda and tuple(m.kernel_size) == (2, 2) and
+            tuple(m.stride) == (2, 2) and tuple(m.padding) == (0, 0) and tuple(m.output_padding) == (0, 0) and m.groups == 1 and
+            tuple(m.dilation) == (1, 1) and m.in_channels % 32 == 0)
+    if geom and x.dtype == torch.bfloat16 and PRECISION == 'bf16' and m.in_channels % 64 == 0 and m.out_channels % 32 == 0:
+        w = m.weight       # bf16 mode, bf16 activations (the mask head): bf16 MFMA GEMM with the same scatter epilogue
+        key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+        ent = _plans(m).get('deconv16')
+        if ent is None or ent[0] != key:
+            ent = (key,) + ops.pack_deconv2x2_weight_bf16(w.detach())
+            _plans(m)['deconv16'] = ent
+        y = ops.deconv2x2_bf16(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
+        _trace('deconv', module=m, x=x, out=y, relu=relu, form='deconv2x2 bf16')
+        return y
+    if x.dtype == torch.bfloat16:
+        x = x.float()
+    ok = geom and x.dtype == torch.float32
     if not ok:
         _library(m, x, 'not a 2x2 / stride-2 transposed convolution with Cin % 32 == 0')
         y = m(x)
@@ -400,7 +413,9 @@ def conv_multi_cat(ms, xs, return_flat=False):
                m.dilation == m0.dilation and m.in_channels == m0.in_channels and (m.bias is None) == (m0.bias is None) for m in ms)
     couts = [m.out_channels for m in ms]
     # (the instance is chosen by ldw: the concatenation must stay on the one the separate heads would use)
-    if (not same or PRECISION != 'fp32' or len(xs) > 5 or not all(supported(m0, x) for x in xs) or
+    # (bf16 modes: heads narrower than 64 channels stay on the fp32 kernel -- _use_bf16 -- and are concatenated all the same)
+    if (not same or any(_use_bf16(m, xs) for m in ms) or xs[0].dtype != torch.float32 or len(xs) > 5 or
+            not all(supported(m0, x) for x in xs) or
             (sum(couts) + 31) // 32 != 1 or _use_winograd(m0, xs)):
         res = [conv_multi(m, xs) for m in ms]
         return (res, None, None) if return_flat else res

@@ -41,7 +41,8 @@ class MaskBranch(nn.Module):
             # Winograd form pinned whatever the ROI count: it varies per image and per pass, and the logits of a ROI must not
             # depend on how many other ROIs share the launch (the fused pipeline's single pass == the reference's two passes,
             # bit for bit) -- every 2x2 output tile is computed independently of the others, in a fixed K order
-            x = hipconv.conv(blk[0], x, relu=True, winograd='always')
+            # (bf16 mode: bf16 activations between the layers of the head, as in the backbone)
+            x = hipconv.conv(blk[0], x, relu=True, winograd='always', out_dtype=hipconv.act_dtype())
         return hipconv.conv(self.mask_score, hipconv.deconv2x2(self.mask_deconv1[0], x, relu=True), pin=True)
 
 

@@ -854,6 +854,39 @@ def deconv2x2(x, wpack, ldw, bias, cout, relu=False):
     return out
 
 
+def pack_deconv2x2_weight_bf16(weight):
+    """ConvTranspose2d weight [Cin,Cout,2,2] -> (bf16 pack, ldw) of the [4 Cout, Cin] matrix with rows (ky, kx, co) for deconv2x2_bf16."""
+    require_cuda(weight)
+    Cin, Cout, kh, kw = weight.shape
+    if (kh, kw) != (2, 2) or Cin % 64 or Cout % 32:
+        raise RuntimeError("pack_deconv2x2_weight_bf16: kernel 2x2, Cin % 64 == 0, Cout % 32 == 0")
+    w = weight.detach().float().permute(2, 3, 1, 0).reshape(4 * Cout, Cin, 1, 1).contiguous()
+    hi, _, ldw = pack_conv_weight_bf16(w, split=False)
+    return hi, ldw
+
+
+def deconv2x2_bf16(x, whi, ldw, bias, cout, relu=False, out_dtype=torch.float32):
+    """ConvTranspose2d(k=2, s=2, p=0) (+bias, +ReLU) of a bf16 map on the bf16 matrix cores; channels_last [N,Cout,2H,2W]."""
+    require_cuda(x, whi)
+    if x.dtype != torch.bfloat16:
+        raise RuntimeError("deconv2x2_bf16: expects a bf16 map")
+    x = nhwc(x)
+    N, C, H, W = x.shape
+    out16 = out_dtype == torch.bfloat16
+    out = (torch.empty((N, 2 * H, 2 * W, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2) if out16
+           else _nhwc_out(N, cout, 2 * H, 2 * W, x.device))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_deconv2x2_nhwc_bf16(stream(), ptr(x), N, H, W, C, ptr(whi), int(ldw), ptr(None if bias is None else f32c(bias)),
+                                           int(cout), int(bool(relu)), ptr(out), int(out16)), "deconv2x2_nhwc_bf16")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('conv_bf16', ev0, ev1, 2.0 * 4 * cout * C * N * H * W,
+                                  2.0 * C * N * H * W + (2.0 if out16 else 4.0) * 4 * cout * N * H * W + 2.0 * 4 * cout * C))
+    return out
+
+
 def prep_image_u8(image_hwc, pixel_means, im_scale, resized_hw, padded_hw, nhwc4=True):
     """uint8 [H,W,3] device image -> padded fp32 blob: logical [1,4,Hp,Wp] channels_last (nhwc4) or [1,3,Hp,Wp] NCHW."""
     import ctypes
