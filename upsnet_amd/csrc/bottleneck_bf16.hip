@@ -387,7 +387,7 @@ extern "C" int upsnet_bottleneck_bf16(void *stream, const void *x, void *out, in
     switch (cmid) {
         case 64: return bneck_launch<64, 8, 16>(st, p);
         case 128: return bneck_launch<128, 8, 8>(st, p);
-        case 256: return bneck_launch<256, 4, 8>(st, p);
+        case 256: return bneck_launch<256, 4, 8>(st, p);   // (8 x 8 tiles: half the weight traffic, half the workgroups -- measured 53 vs 43 us)
         case 512: return bneck_launch<512, 4, 8>(st, p);
         default: return ups_set_error("bottleneck_bf16: Cm must be 64, 128, 256 or 512 (got %d)", cmid);
     }

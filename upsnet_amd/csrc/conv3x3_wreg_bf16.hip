@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
     constexpr int NPATCH = (TH + 2) * W3_PW, NROWS = (NPATCH + 31) / 32 * 32;
     constexpr int UPR = IN16 ? 4 : 8;                               // 16-byte units per patch pixel and slab
     constexpr int NLD = (NROWS * UPR + NT - 1) / NT;
-    constexpr int WD = 6;                                           // weight k-steps in flight (18 per slab)
+    constexpr int WD = 3;                                           // weight k-steps in flight (18 per slab, a multiple of WD)
     __shared__ __attribute__((aligned(16))) unsigned char XS[2][NROWS * W3_XP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,10 +155,12 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
         const bool more = cs + 1 < cslabs;
         if (more) W3_FETCH_X(cs + 1)
         __builtin_amdgcn_sched_barrier(0);
+#define W3_XFRAG(J, KK) (*reinterpret_cast<const w3_bf16x8 *>(&XS[buf][prow[J] + ((((KK) >> 1) / 3) * W3_PW + (((KK) >> 1) % 3)) * W3_XP + ((KK) & 1) * 32]))
+        w3_bf16x8 xf[NPB], xn[NPB];                  // activation fragments one k-step ahead (inside a slab)
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) xf[j] = W3_XFRAG(j, 0);
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {            // k-step kk = (tap, t) of this slab
-            const int tap = kk >> 1, t = kk & 1;
-            const int sh = ((tap / 3) * W3_PW + (tap % 3)) * W3_XP + t * 32;
             w3_bf16x8 wf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) wf[i] = wq[kk % WD][i];
@@ -171,15 +173,19 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
                     for (int i = 0; i < 2; ++i) wq[kk % WD][i] = W3_WLOAD(i, ntap * cslabs + ncs, nt);
                 }
             }
-            w3_bf16x8 xf[NPB];
+            if (kk + 1 < 18) {
 #pragma unroll
-            for (int j = 0; j < NPB; ++j) xf[j] = *reinterpret_cast<const w3_bf16x8 *>(&XS[buf][prow[j] + sh]);
+                for (int j = 0; j < NPB; ++j) xn[j] = W3_XFRAG(j, kk + 1);
+            }
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) xf[j] = xn[j];
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef W3_XFRAG
         if (more) W3_STASH_X(buf ^ 1)
         __syncthreads();
     }
