@@ -263,6 +263,13 @@ int upsnet_conv_bf16_tuning(int enable, int tile_rows);
  * from global memory in fragment order, no LDS, no barrier): enable 0 = conv_bf16_kernel, 1 = default (the layers it is faster on:
  * shortcut epilogue, Cin <= 256), 2 = every layer it can compute. Same products and K order. */
 int upsnet_conv1x1_bf16_tuning(int enable);
+/* The backbone stem in one launch on the bf16 matrix cores (upsnet/models/resnet.py:347-356 in the bf16 mode): convolution 7x7 /
+ * stride 2 / pad 3 (Cin <= 4 -> 64, frozen BN folded: + bias) + ReLU + max-pool 3x3 / stride 2 / pad 1. x4 [N,H,W,4] fp32 (RGB + a zero
+ * channel: upsnet_image_to_nhwc4 / upsnet_prep_image_u8), wpack = upsnet_stem_pool_pack_weight_bf16(weight [64,Cin,7,7]) (28 KiB),
+ * bias [64] or NULL, out [N,Hp,Wp,64] bf16, Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (likewise the width). The convolution result
+ * is rounded to bf16 before the pool; the image is rounded to bf16 on the way into LDS. */
+int upsnet_stem_pool_pack_weight_bf16(void *stream, const float *weight, int cin, void *wpack);
+int upsnet_stem_pool_bf16(void *stream, const float *x4, int batch, int height, int width, const void *wpack, const float *bias, void *out);
 /* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) of a bf16 NHWC map on the bf16 matrix cores (the mask head's
  * upsampling layer, upsnet/models/rcnn.py:132-133, in the bf16 mode): one GEMM [N H W, Cin] x [Cin, 4 Cout] with a scatter epilogue.
  * x [N,H,W,Cin] bf16; wpack_hi = upsnet_conv_pack_weight_bf16 of the [4 Cout, Cin, 1, 1] matrix whose rows are ordered (ky, kx, c),

@@ -362,6 +362,31 @@ def conv_stem(m, x, relu=False):
     return y
 
 
+# bf16 mode: stem convolution + ReLU + max-pool as one launch on the bf16 cores (csrc/stem_pool_bf16.hip). UPSNET_BF16_STEM=0: the
+# fp32 stem kernel and the library max-pool (A/B runs).
+BF16_STEM = os.environ.get('UPSNET_BF16_STEM', '1') != '0'
+
+
+def use_stem_pool(m, x):
+    return (ENABLED and BF16_STEM and PRECISION == 'bf16' and BF16_ACT and stem_supported(m, x) and m.out_channels == 64 and
+            tuple(m.kernel_size) == (7, 7) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (3, 3))
+
+
+def stem_pool(m, x):
+    """max_pool2d(relu(m(x)), 3, 2, 1) of the 7x7/2 stem -- see use_stem_pool. Returns bf16."""
+    w = m.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('stem16')
+    if ent is None or ent[0] != key:
+        ent = (key, ops.pack_stem_pool_weight_bf16(w.detach()))
+        _plans(m)['stem16'] = ent
+    is_nhwc4 = x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    x4 = x if is_nhwc4 else ops.image_to_nhwc4(x)
+    y = ops.stem_pool_bf16(x4, ent[1], m.bias)
+    _trace('stem_pool', module=m, x=x4[:, :m.in_channels], out=y, form='stem + pool bf16')
+    return y
+
+
 def deconv2x2(m, x, relu=False):
     """nn.ConvTranspose2d(k=2, s=2, p=0) (+ ReLU) as one MFMA GEMM with a scatter epilogue."""
     geom = (ENABLED and isinstance(m, nn.ConvTranspose2d) and x.is_cuda and tuple(m.kernel_size) == (2, 2) and
