@@ -27,6 +27,13 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (32x32x16), 2495 measured
+DENSE_BF16 = ('bf16 mode (BASELINE configs[2]): hand-written bf16 MFMA kernels (fp32 accumulate), NHWC, frozen BN folded: stem 7x7 + ReLU + max-pool '
+              'in one launch (csrc/stem_pool_bf16.hip); every identity bottleneck of res2-res4 in one launch, intermediates in LDS '
+              '(csrc/bottleneck_bf16.hip); 3x3 layers with output channels in blocks of 256 (FPN out, RPN, mask head, res4 / res5 conv2) and the 1x1 '
+              'layers with a shortcut and K <= 256 on kernels that feed the weights to the MFMA from L2 (csrc/conv3x3_wreg_bf16.hip, '
+              'csrc/conv1x1_wreg_bf16.hip, incl. the 2x2 transposed convolution); the other dense layers on csrc/conv_bf16.hip; bf16 activations in '
+              'the backbone and the mask head; deformable 3x3 on csrc/deform_fused_bf16.hip; narrow heads, offset predictors and the small FPN maps on '
+              'the fp32 kernels; fc6 as a bf16 library GEMM, the other FC GEMMs fp32 (PyTorch-ROCm)')
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable per the same guide)
 
 
@@ -229,18 +236,24 @@ def main():
             'frac_of_peak_whole_image': round((f_exec + f_d) / n_sampled / (p50_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             'note': 'fp32 MFMA flops issued by the convolution kernels of one image / (157.3 TFLOP/s x steady-state time per image); the '
                     'FC GEMMs (hipBLASLt) are not counted'}
-        n_b, t_b, f_b, b_b = agg('conv_bf16')
+        n_b, t_b, f_b, b_b = [a + b for a, b in zip(agg('conv_bf16'), agg('bottleneck_bf16'))]
         if n_b and t_b > 0:   # --conv-precision bf16 / bf16x3 (BASELINE configs[2]): the layers that ran on the bf16 matrix cores
             mult = 3.0 if args.conv_precision == 'bf16x3' else 1.0
             roofline['bf16_matrix_cores'] = {
-                'kernel': 'conv_bf16_kernel (csrc/conv_bf16.hip, v_mfma_f32_32x32x16_bf16, fp32 accumulate; %s)' %
-                          ('3 MFMAs per product: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi' if mult == 3.0 else 'one MFMA per product'),
+                'kernel': 'bf16 MFMA family (v_mfma_f32_32x32x16_bf16, fp32 accumulate; %s): conv_bf16_kernel / conv3x3_bf16_halo_kernel '
+                          '(csrc/conv_bf16.hip)%s' %
+                          ('3 MFMAs per product: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi' if mult == 3.0 else 'one MFMA per product',
+                           '' if mult == 3.0 else ' + bottleneck_bf16_kernel (identity bottlenecks in one launch, csrc/bottleneck_bf16.hip) + '
+                           'conv3x3_wreg_bf16_kernel / conv1x1_wreg_bf16_kernel (weights from L2 into the MFMA, csrc/conv3x3_wreg_bf16.hip, '
+                           'csrc/conv1x1_wreg_bf16.hip; incl. the 2x2 transposed convolution) + stem_pool_bf16_kernel (csrc/stem_pool_bf16.hip)'),
                 'bound': 'mfma', 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'achieved': round(mult * f_b / t_b / 1e12, 3), 'frac': round(mult * f_b / t_b / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 'achieved_algorithmic': round(f_b / t_b / 1e12, 3), 'launches_timed': n_b, 'ms_per_image': round(1000.0 * t_b / n_sampled, 3),
-                'note': 'layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem and the deconvolution '
-                        'stay on the fp32 kernels (they are in the fp32 family above); in the bf16 mode the deformable '
-                        'convolutions run on csrc/deform_fused_bf16.hip (deformable_bf16 below), in the bf16x3 mode on the fp32 kernel'}
+                'note': 'bf16x3: layers with fewer than hipconv.BF16_MIN_WG 128x128 tiles, the stem and the deconvolution stay on the fp32 '
+                        'kernels (the fp32 family above), the deformable convolutions on the fp32 kernel. bf16: the backbone (stem + pool fused, '
+                        'identity bottlenecks fused) and the mask head keep bf16 activations; the narrow heads (< 64 channels), the offset '
+                        'predictors of the deformable layers and the small FPN maps stay on the fp32 kernels; the deformable convolutions '
+                        'run on csrc/deform_fused_bf16.hip (deformable_bf16 below)'}
         if n_d and t_d > 0:
             roofline['deformable'] = {'kernel': 'dcn_fused_f32_kernel (csrc/deform_fused.hip: fused deformable convolution v1, fp32 MFMA)', 'bound': 'mfma',
                                       'achieved': round(f_d / t_d / 1e12, 3), 'frac': round(f_d / t_d / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -332,9 +345,10 @@ def main():
             r2 = upsnet_test(args.workload, steps=30, warmup=6, input_mode=args.input, post=args.post, in_flight=args.in_flight)
             torch.cuda.synchronize()
             net2 = sorted(r2['net_times'])
-            configs2 = {'what': 'BASELINE.json configs[2]: same workload, dense convolutions with >= %d 128x128 tiles on the bf16 matrix cores '
-                                '(bf16 products, fp32 accumulation; csrc/conv_bf16.hip), everything else as in the headline run; '
-                                'own run: python bench.py --conv-precision bf16' % hipconv.BF16_MIN_WG,
+            configs2 = {'what': 'BASELINE.json configs[2]: same workload in the bf16 mode -- dense convolutions, stem, transposed convolution and '
+                                'fc6 with bf16 products and fp32 accumulation, bf16 activations in the backbone and the mask head (identity '
+                                'bottlenecks and stem + pool as single launches), everything else as in the headline run; '
+                                'own run: python bench.py --conv-precision bf16',
                         'conv_precision': 'bf16', 'value': round(30 / r2['elapsed'], 4), 'unit': 'images/sec', 'steps': 30, 'warmup': 6,
                         'ms_per_img_p50': round(1000.0 * net2[len(net2) // 2], 3),
                         'n_det': int(r2['last_out']['cls_inds'].numel()), 'n_inst': int(r2['last_out']['panoptic_cls_inds'].numel())}
@@ -351,11 +365,11 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
         'ms_per_img_p50': round(p50_ms, 3), 'ms_per_img_serial': round(serial_ms, 3), 'latency_ms_p50': round(lat_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (3-term bf16 split of fp32 operands, fp32 accumulate; dense convs only)',
-                  'bf16': 'bf16 (dense convs: bf16 products, fp32 accumulate; rest f32)'}[args.conv_precision], 'data': 'synthetic',
+                  'bf16': 'bf16 (dense convs, stem, transposed conv, fc6: bf16 products, fp32 accumulate; bf16 activations in backbone + mask head; rest f32)'}[args.conv_precision], 'data': 'synthetic',
         'config': {'workload': args.workload, 'image': '1x3x%dx%d' % (H, W), 'images_per_rank_per_step': 1,
                    'input': 'fp32 blob resident in HBM' if args.input == 'f32' else 'uint8 image resident in HBM + input kernel in the step',
                    'post': 'get_unified_pan_result in the step' if args.post else 'none (label maps are the output)',
-                   'dense_convs': 'hand-written fp32 MFMA kernels for every convolution, NHWC, frozen BN folded, bias/residual/ReLU fused: 1x1 layers on the '
+                   'dense_convs': DENSE_BF16 if args.conv_precision == 'bf16' else 'hand-written fp32 MFMA kernels for every convolution, NHWC, frozen BN folded, bias/residual/ReLU fused: 1x1 layers on the '
                                   'lean GEMM kernel (csrc/conv1x1.hip; the conv3 / next conv1 pairs of res2 in one launch, csrc/conv1x1_pair.hip), 3x3 / stride-1 layers with >= 128 workgroups of tiles (FPN, RPN, res2-res5 conv2, '
                                   'DCN offset convs, mask head) on the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip, split-K below 160 workgroups), '
                                   'the rest (7x7 stem, strided 3x3, 2x2 deconvolution, narrow heads) on the implicit-GEMM kernel (csrc/conv.hip); '

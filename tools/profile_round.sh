@@ -6,6 +6,7 @@
 #   4. per-launch table of the convolution kernels (algorithmic TFLOP/s and GB/s from the bench's own events)
 #   5. the default bench line (graph replay, overlapped streams, cpu_baseline, configs2) + the other workloads + the bf16 mode's own line
 #   6. the parity summary: worst error / bound of the strict fp64 tests at full size
+#   7. bf16 mode (configs[2]): eager serial kernel stats + timeline, micro-benchmarks of its kernels, its bench line on configs[1] and configs[3]
 TAG=${1:-r08}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$REPO/gpurun_out
@@ -27,7 +28,13 @@ $EAGER rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -
 python $REPO/tools/mfma_util.py $(db /tmp/p_mfma) > $OUT/${TAG}_mfma_util_serial.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma2 -o t -- $B --steps 20 --warmup 6 > $OUT/${TAG}_pmc_mfma_graph.log 2>&1
 python $REPO/tools/mfma_util.py $(db /tmp/p_mfma2) --total > $OUT/${TAG}_mfma_util_graph.txt 2>&1
+# bf16 mode (BASELINE configs[2]): eager serial trace -> kernel stats + timeline; the micro-benchmarks of its kernels against the paths they replace
+B16="python $REPO/bench.py --no-cpu-baseline --no-configs2 --conv-precision bf16"
+$EAGER rocprofv3 --kernel-trace -d /tmp/p_trace16 -o t -- $B16 --steps 10 --warmup 5 > $OUT/${TAG}_bf16_trace_bench.log 2>&1
+python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace16) 45 > $OUT/${TAG}_bf16_kernel_stats.txt 2>&1
+python $REPO/tools/rocpd_timeline.py $(db /tmp/p_trace16) > $OUT/${TAG}_bf16_timeline_serial.txt 2>&1
 cd $REPO
+(python tools/microbench_bottleneck.py; python tools/microbench_conv3x3_bf16.py; python tools/microbench_conv1x1_bf16.py) > $OUT/${TAG}_bf16_micro.txt 2>&1
 python tools/make_pmc_json.py $TAG $OUT/${TAG}_pmc_FETCH_SIZE.txt $OUT/${TAG}_pmc_WRITE_SIZE.txt > $OUT/${TAG}_conv_pmc.json 2> $OUT/${TAG}_conv_pmc.err
 cp $OUT/${TAG}_conv_pmc.json profiles/${TAG}_conv_pmc.json   # (so that the bench line of this very run can report roofline.traffic)
 python tools/layer_table.py > $OUT/${TAG}_layer_table.txt 2>&1
@@ -37,6 +44,7 @@ python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --in-fligh
 python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 > $OUT/${TAG}_bench_bf16.log 2>&1
 python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16x3 > $OUT/${TAG}_bench_bf16x3.log 2>&1
 python bench.py --steps 40 --warmup 8 --no-configs2 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3.log 2>&1
+python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3_bf16.log 2>&1
 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-configs2 --workload upsnet101dcn_mixed_1024x2048_800x1333 > $OUT/${TAG}_bench_c4.log 2>&1
 python bench.py --gpus 1 --dry-run > $OUT/${TAG}_dry_run.log 2>&1
 timeout 900 python -m pytest tests/test_trunk_gpu.py tests/test_layerwise_gpu.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep -E "worst|launches|passed|failed" > $OUT/${TAG}_parity.txt
