@@ -31,6 +31,9 @@ def _replay(rec):
             r = rec['residual'].to(D)
             y = y + (F.interpolate(r, scale_factor=2, mode='nearest') if rec['residual_up'] else r)
         return [F.relu(y) if rec['relu'] else y], [rec['out']]
+    if rec['kind'] == 'stem_pool':     # stem convolution + ReLU + 3x3 / 2 max-pool in one launch (resnet.py:347-356)
+        y = F.relu(F.conv2d(rec['x'].to(D), w, b, m.stride, m.padding))
+        return [F.max_pool2d(y, 3, stride=2, padding=1)], [rec['out']]
     if rec['kind'] == 'deconv':
         y = F.conv_transpose2d(rec['x'].to(D), w, b, m.stride, m.padding)
         return [F.relu(y) if rec['relu'] else y], [rec['out']]

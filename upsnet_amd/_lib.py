@@ -84,6 +84,8 @@ _SIGNATURES = {
     "upsnet_conv2d_nhwc_bf16": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv_bf16_tuning": (c_int, [c_int, c_int]),
     "upsnet_conv1x1_bf16_tuning": (c_int, [c_int]),
+    "upsnet_stem_pool_pack_weight_f32": (c_int, [P, P, c_int, P]),
+    "upsnet_stem_pool_f32": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
     "upsnet_stem_pool_pack_weight_bf16": (c_int, [P, P, c_int, P]),
     "upsnet_stem_pool_bf16": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
     "upsnet_deconv2x2_nhwc_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int]),

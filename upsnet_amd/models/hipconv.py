@@ -362,28 +362,39 @@ def conv_stem(m, x, relu=False):
     return y
 
 
-# bf16 mode: stem convolution + ReLU + max-pool as one launch on the bf16 cores (csrc/stem_pool_bf16.hip). UPSNET_BF16_STEM=0: the
-# fp32 stem kernel and the library max-pool (A/B runs).
+# Stem convolution + ReLU + max-pool as one launch: csrc/stem_pool.hip (fp32 MFMA; the headline path) / csrc/stem_pool_bf16.hip (bf16
+# mode). UPSNET_STEM_POOL=0 / UPSNET_BF16_STEM=0: stem kernel + library max-pool (A/B runs).
+STEM_POOL = os.environ.get('UPSNET_STEM_POOL', '1') != '0'
 BF16_STEM = os.environ.get('UPSNET_BF16_STEM', '1') != '0'
 
 
+def _stem_geometry(m, x):
+    return (ENABLED and stem_supported(m, x) and m.out_channels == 64 and m.in_channels <= 3 and tuple(m.kernel_size) == (7, 7) and
+            tuple(m.stride) == (2, 2) and tuple(m.padding) == (3, 3))
+
+
 def use_stem_pool(m, x):
-    return (ENABLED and BF16_STEM and PRECISION == 'bf16' and BF16_ACT and stem_supported(m, x) and m.out_channels == 64 and
-            tuple(m.kernel_size) == (7, 7) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (3, 3))
+    """'bf16' / 'f32' = the fused stem + pool kernel the stem runs on, None = separate launches."""
+    if not _stem_geometry(m, x):
+        return None
+    if PRECISION == 'bf16' and BF16_ACT and BF16_STEM:
+        return 'bf16'
+    return 'f32' if STEM_POOL else None
 
 
 def stem_pool(m, x):
-    """max_pool2d(relu(m(x)), 3, 2, 1) of the 7x7/2 stem -- see use_stem_pool. Returns bf16."""
+    """max_pool2d(relu(m(x)), 3, 2, 1) of the 7x7/2 stem in one launch -- see use_stem_pool. bf16 mode: returns bf16."""
+    kind = use_stem_pool(m, x)
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
-    ent = _plans(m).get('stem16')
+    ent = _plans(m).get('stem_pool_' + kind)
     if ent is None or ent[0] != key:
-        ent = (key, ops.pack_stem_pool_weight_bf16(w.detach()))
-        _plans(m)['stem16'] = ent
+        ent = (key, ops.pack_stem_pool_weight_bf16(w.detach()) if kind == 'bf16' else ops.pack_stem_pool_weight_f32(w.detach()))
+        _plans(m)['stem_pool_' + kind] = ent
     is_nhwc4 = x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last)
     x4 = x if is_nhwc4 else ops.image_to_nhwc4(x)
-    y = ops.stem_pool_bf16(x4, ent[1], m.bias)
-    _trace('stem_pool', module=m, x=x4[:, :m.in_channels], out=y, form='stem + pool bf16')
+    y = ops.stem_pool_bf16(x4, ent[1], m.bias) if kind == 'bf16' else ops.stem_pool_f32(x4, ent[1], m.bias)
+    _trace('stem_pool', module=m, x=x4[:, :m.in_channels], out=y, form='stem + pool bf16' if kind == 'bf16' else 'stem + pool')
     return y
 
 

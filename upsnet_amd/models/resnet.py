@@ -107,7 +107,7 @@ class conv1(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        if isinstance(self.bn1, nn.Identity) and hipconv.use_stem_pool(self.conv1, x):   # bf16 mode: conv + ReLU + pool, one launch
+        if isinstance(self.bn1, nn.Identity) and hipconv.use_stem_pool(self.conv1, x):   # BN folded: conv + bias + ReLU + pool, one launch
             return hipconv.stem_pool(self.conv1, x)
         if isinstance(self.bn1, nn.Identity):  # BN folded: 7x7 conv + bias + ReLU on the MFMA kernel (NHWC4 image)
             return nn.functional.max_pool2d(hipconv.conv_stem(self.conv1, x, relu=True), 3, stride=2, padding=1)

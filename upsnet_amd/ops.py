@@ -793,6 +793,38 @@ def pack_stem_weight(weight):
     return wp, ldw
 
 
+def pack_stem_pool_weight_f32(weight):
+    """[64, Cin <= 3, 7, 7] fp32 -> the operand pack of stem_pool_f32 (2 x 84 x 64 floats)."""
+    require_cuda(weight)
+    weight = f32c(weight)
+    if tuple(weight.shape[0:1] + weight.shape[2:]) != (64, 7, 7) or weight.shape[1] > 3:
+        raise RuntimeError("pack_stem_pool_weight_f32: weight must be [64, Cin <= 3, 7, 7]")
+    wp = torch.empty(2 * 84 * 64, dtype=torch.float32, device=weight.device)
+    check(lib().upsnet_stem_pool_pack_weight_f32(stream(), ptr(weight), int(weight.shape[1]), ptr(wp)), "stem_pool_pack_weight_f32")
+    return wp
+
+
+def stem_pool_f32(x4, wpack, bias):
+    """max_pool2d(relu(conv7x7/2/3(x) + bias), 3, 2, 1) in one launch; x4: logical [N,4,H,W] channels_last fp32 (image_to_nhwc4 /
+    prep_image_u8). Returns channels_last fp32 [N,64,Hp,Wp]."""
+    require_cuda(x4, wpack)
+    x4 = nhwc(x4.float())
+    N, C, H, W = x4.shape
+    if C != 4:
+        raise RuntimeError("stem_pool_f32: input must have 4 channels (RGB + zero), got %d" % C)
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = _nhwc_out(N, 64, Hp, Wp, x4.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_stem_pool_f32(stream(), ptr(x4), N, H, W, ptr(wpack), ptr(None if bias is None else f32c(bias)), ptr(out)), "stem_pool_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * 64 * 147 * N * Hc * Wc, 16.0 * N * H * W + 4.0 * 64 * N * Hp * Wp + 4.0 * 64 * 147, 'stem + pool'))
+    return out
+
+
 def pack_stem_pool_weight_bf16(weight):
     """[64, Cin <= 4, 7, 7] fp32 -> the bf16 fragment pack of stem_pool_bf16 (2 x 14 x 64 x 8 elements)."""
     require_cuda(weight)
