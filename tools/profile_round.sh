@@ -35,6 +35,7 @@ python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace16) 45 > $OUT/${TAG}_bf16_ker
 python $REPO/tools/rocpd_timeline.py $(db /tmp/p_trace16) > $OUT/${TAG}_bf16_timeline_serial.txt 2>&1
 cd $REPO
 (python tools/microbench_bottleneck.py; python tools/microbench_conv3x3_bf16.py; python tools/microbench_conv1x1_bf16.py) > $OUT/${TAG}_bf16_micro.txt 2>&1
+python tools/microbench_stem.py > $OUT/${TAG}_stem_micro.txt 2>&1
 python tools/make_pmc_json.py $TAG $OUT/${TAG}_pmc_FETCH_SIZE.txt $OUT/${TAG}_pmc_WRITE_SIZE.txt > $OUT/${TAG}_conv_pmc.json 2> $OUT/${TAG}_conv_pmc.err
 cp $OUT/${TAG}_conv_pmc.json profiles/${TAG}_conv_pmc.json   # (so that the bench line of this very run can report roofline.traffic)
 python tools/layer_table.py > $OUT/${TAG}_layer_table.txt 2>&1
