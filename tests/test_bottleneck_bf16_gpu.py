@@ -1,6 +1,5 @@
 """GPU: the one-launch identity bottleneck of the bf16 mode (csrc/bottleneck_bf16.hip) vs (a) a float64 restatement of the block
 (upsnet/models/resnet.py:84-100) that rounds to bf16 where the kernel rounds, and (b) the three-launch bf16 path it replaces."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
