@@ -255,6 +255,13 @@ int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *const x[], cons
                             int relu);
 int upsnet_conv_pack_weight_bf16(void *stream, const float *weight, int cout, int cin, int kh, int kw, int ldw, void *wpack_hi,
                                  void *wpack_lo);
+/* The FIRST bottleneck of a stage (projection shortcut; upsnet/models/resnet.py:84-100) as ONE launch on the bf16 matrix cores:
+ *   out = relu(conv3(relu(conv2(relu(conv1_s(x))))) + proj_s(x)),  conv1_s / proj_s: 1x1 with stride s (1 or 2), conv2: 3x3 / 1 / 1.
+ * x [N,Hin,Win,Cin] bf16, out [N,H,W,4 Cm] bf16, H = (Hin - 1) / s + 1; (Cm, Cin) in {(64, 64), (128, 256), (256, 512)}. w1: fragments
+ * of [Cm, Cin]; w2: of [Cm, 9 Cm] (tap-major k); w3d: of [4 Cm, Cm + Cin] = [W3 | Wd] -- conv3 and the projection are one GEMM over
+ * K = [t2 ; x], the shortcut is accumulated in fp32; b1, b2 [Cm]; b3d = b3 + bd [4 Cm]. Fragment order as upsnet_bottleneck_bf16. */
+int upsnet_bottleneck_proj_bf16(void *stream, const void *x, void *out, int batch, int height_in, int width_in, int cin, int cmid, int stride,
+                                const void *w1, const void *w2, const void *w3d, const float *b1, const float *b2, const float *b3d);
 /* A/B switch of the 3x3 / stride 1 / 256 -> 256 layers in the plain bf16 mode (csrc/conv3x3_wreg_bf16.hip: weights fed to the MFMA
  * from L2, one barrier per 32-channel slab): enable 0 = the general haloed-patch kernel, 1 = default; tile_rows 0 = automatic,
  * 8 / 16 = forced tile height. Same products and K order either way. */

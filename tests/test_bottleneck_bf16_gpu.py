@@ -79,9 +79,50 @@ def test_bottleneck_bf16_equals_the_three_launch_path(cm, N, H, W):
     assert float(diff.max()) <= 2.0 ** -6 * float(y.float().abs().max())
 
 
-def test_backbone_stage_takes_the_block_kernel_in_bf16_mode():
-    """models/resnet.py: in the bf16 mode the identity blocks of a stage run as ONE launch each (hipconv.block), the projection
-    block as separate layers; UPSNET_BF16_BLOCK=0 (hipconv.BF16_BLOCK) restores three launches with the same result."""
+def _proj_weights(cm, cin, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    c = 4 * cm
+    w1 = torch.randn(cm, cin, 1, 1, generator=g) / cin ** 0.5
+    w2 = torch.randn(cm, cm, 3, 3, generator=g) / (9 * cm) ** 0.5
+    w3 = torch.randn(c, cm, 1, 1, generator=g) / cm ** 0.5
+    wd = torch.randn(c, cin, 1, 1, generator=g) / cin ** 0.5
+    bs = [torch.randn(n, generator=g) * 0.1 for n in (cm, cm, c, c)]
+    return [t.cuda() for t in (w1, w2, w3, wd)] + [t.cuda() for t in bs]
+
+
+@pytest.mark.parametrize("cm,cin,stride,N,H,W", [
+    (64, 64, 1, 1, 32, 48),        # res2: stride 1
+    (64, 64, 1, 2, 19, 37),        # ragged tiles, two images
+    (128, 256, 2, 1, 48, 64),      # res3: stride 2
+    (128, 256, 2, 1, 37, 53),      # odd input size: H = (Hin - 1) / 2 + 1
+    (256, 512, 2, 1, 24, 40),      # res4
+    (256, 512, 2, 2, 9, 15),
+])
+def test_bottleneck_proj_bf16_vs_float64(cm, cin, stride, N, H, W):
+    """First bottleneck of a stage (projection shortcut, resnet.py:84-100) in one launch: conv3 and the projection are one GEMM over
+    [t2 ; x], so the shortcut is accumulated in fp32. Reference: float64 on the bf16-rounded operands, t1 / t2 rounded to bf16."""
+    from upsnet_amd import ops
+    torch.manual_seed(cm + H)
+    w1, w2, w3, wd, b1, b2, b3, bd = _proj_weights(cm, cin, cm + W)
+    x = _bf(torch.randn(N, cin, H, W, device='cuda')).contiguous(memory_format=torch.channels_last)
+    out = ops.bottleneck_proj_bf16(x, ops.pack_bottleneck_proj_bf16(w1, w2, w3, wd, b1, b2, b3, bd), stride)
+    d = lambda t: _bf(t).double()
+    t1 = _bf(F.relu(F.conv2d(x.double(), d(w1), b1.double(), stride=stride)))
+    t2 = _bf(F.relu(F.conv2d(t1.double(), d(w2), b2.double(), padding=1)))
+    ref = F.relu(F.conv2d(t2.double(), d(w3), b3.double()) + F.conv2d(x.double(), d(wd), bd.double(), stride=stride))
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape and out.permute(0, 2, 3, 1).is_contiguous()
+    err = (out.double() - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(err.max()) <= 0.02 * scale, (float(err.max()), scale)
+    assert float(err.mean()) <= 2e-3 * scale
+    near = err <= ref.abs() * 2.0 ** -7 + 1e-2 * scale * 2.0 ** -4
+    assert float(near.double().mean()) > 0.99
+
+
+def test_backbone_stage_takes_the_block_kernels_in_bf16_mode():
+    """models/resnet.py: in the bf16 mode every bottleneck of a stage runs as ONE launch (hipconv.block: the projection block and the
+    identity blocks); hipconv.BF16_BLOCK = False restores the separate layers, which round the shortcut of the projection block to bf16
+    before the add (the fused block accumulates it in fp32): the two agree within bf16 steps of the output."""
     from upsnet_amd.models import hipconv
     from upsnet_amd.models.resnet import res_block, fold_frozen_bn
     torch.manual_seed(5)
@@ -93,22 +134,28 @@ def test_backbone_stage_takes_the_block_kernel_in_bf16_mode():
                 m.weight.fill_(0.7)
     fold_frozen_bn(stage)
     stage = stage.to(memory_format=torch.channels_last)
-    x = torch.randn(1, 256, 48, 64, device='cuda').contiguous(memory_format=torch.channels_last)
-    saved = (hipconv.PRECISION, hipconv.BF16_MIN_WG, hipconv.BF16_BLOCK, hipconv.BF16_BLOCK_MIN_TILES)
+    x = torch.randn(1, 256, 48, 64, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+    saved = (hipconv.PRECISION, hipconv.BF16_MIN_WG, hipconv.BF16_BLOCK, hipconv.BF16_BLOCK_MIN_TILES, hipconv.BF16_PROJ)
     try:
         hipconv.PRECISION, hipconv.BF16_MIN_WG, hipconv.BF16_BLOCK_MIN_TILES = 'bf16', 0, 0   # (a test-size map has few tiles)
         with torch.no_grad():
             hipconv.BF16_BLOCK, hipconv.TRACE = True, []
             out = stage(x)
             trace, hipconv.TRACE = hipconv.TRACE, None
+            hipconv.BF16_PROJ, hipconv.TRACE = False, []
+            mid = stage(x)
+            trace_mid, hipconv.TRACE = hipconv.TRACE, None
             hipconv.BF16_BLOCK = False
             sep = stage(x)
     finally:
-        hipconv.PRECISION, hipconv.BF16_MIN_WG, hipconv.BF16_BLOCK, hipconv.BF16_BLOCK_MIN_TILES = saved
+        hipconv.PRECISION, hipconv.BF16_MIN_WG, hipconv.BF16_BLOCK, hipconv.BF16_BLOCK_MIN_TILES, hipconv.BF16_PROJ = saved
         hipconv.TRACE = None
-    kinds = [r['form'] for r in trace]
+    assert [r['form'] for r in trace] == ['bottleneck_proj_bf16', 'bottleneck_bf16', 'bottleneck_bf16']
+    kinds = [r['form'] for r in trace_mid]
     assert kinds.count('bottleneck_bf16') == 2 and len(kinds) == 4 + 2, kinds
-    assert out.dtype == torch.bfloat16 and sep.dtype == torch.bfloat16
-    diff = (out.float() - sep.float()).abs()
-    assert float((diff > 0).float().mean()) < 1e-3
-    assert float(diff.max()) <= 2.0 ** -5 * float(sep.float().abs().max())
+    assert out.dtype == torch.bfloat16 and sep.dtype == torch.bfloat16 and mid.dtype == torch.bfloat16
+    top = float(sep.float().abs().max())
+    for a in (out, mid):
+        diff = (a.float() - sep.float()).abs()
+        assert float(diff.max()) <= 2.0 ** -5 * top
+        assert float(diff.mean()) <= 2.0 ** -9 * top

@@ -37,6 +37,7 @@ struct BneckParams {
     const void *w1, *w2, *w3; // fragment-order packs (upsnet_amd/ops.py: pack_bottleneck_bf16)
     const float *b1, *b2, *b3;
     int N, H, W, tiles_x, tiles_y;
+    int Hin, Win, stride;     // projection block: size of x and the stride of conv1 / the projection (H, W = the block's output size)
 };
 
 __device__ static inline __amdgpu_buffer_rsrc_t bnk_rsrc(const void *ptr, const unsigned bytes)
@@ -53,6 +54,13 @@ __device__ static inline int bnk_perm(const int l)
     const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
     const int k = l < 4 ? l : l < 12 ? l - 4 : l < 16 ? l - 8 : l < 20 ? l - 8 : l < 28 ? l - 12 : l - 16;
     return (g1 ? 16 : 0) + k;
+}
+
+__device__ static inline bnk_bf16x8 bnk_as_bf16x8(const bnk_uintx4 v)
+{
+    bnk_bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
 }
 
 __device__ static inline unsigned bnk_pack2(const float a, const float b)
@@ -78,10 +86,16 @@ struct BneckGeom {
     static constexpr int SMEM = R0_BYTES + R1_BYTES;
 };
 
-template <int CM, int TH, int TW>
+// CIN = 0: identity block (x has 4 CM channels and is the shortcut). CIN > 0: PROJECTION block -- x has CIN channels at stride p.stride,
+// the shortcut is Wd x (the 1x1 projection, same stride): conv3 and the projection are ONE GEMM over K = [t2 ; x] with the weight rows
+// [W3 | Wd] (w3 pack, K = CM + CIN) and the bias b3 + bd; the x operand of that part comes straight from global memory (lane = its
+// pixel's 16 bytes of a k-step, as in conv1x1_wreg_bf16.hip).
+template <int CM, int TH, int TW, int CIN>
 __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams p)
 {
     using G = BneckGeom<CM, TH, TW>;
+    constexpr bool PROJ = CIN > 0;
+    constexpr int CX = PROJ ? CIN : 4 * CM;                      // channels of x
     constexpr int C = G::C, NPX = G::NPX, PBO = G::PBO, PWD = G::PWD, NPATCH = G::NPATCH, PBP = G::PBP, NROWS = G::NROWS;
     constexpr int XS_P = G::XS_P, T_P = G::T_P, O_P = G::O_P;
     constexpr int NCB = CM / 32;                                 // 32-channel blocks of t1 / t2
@@ -89,7 +103,8 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
     constexpr int CBW = NCB / NWC;                               // channel blocks per wave (stages A, B)
     constexpr int PBPW = PBP / NWP, PBOW = PBO / NWP;            // pixel blocks per wave (stage A / stage B)
     static_assert(NCB >= 2 && PBP % NWP == 0 && PBO % NWP == 0 && NPX % 32 == 0 && (NPX * 16) % 256 == 0, "unsupported tile / width combination");
-    constexpr int K1S = C / 16, K2S = 9 * CM / 16, K3S = CM / 16; // k steps (16 channels) of the three GEMMs
+    constexpr int K1S = CX / 16, K2S = 9 * CM / 16, K3S = CM / 16; // k steps (16 channels) of the three GEMMs
+    constexpr int KPS = PROJ ? CIN / 16 : 0, K3T = K3S + KPS;    // projection part of the last GEMM
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *XS = smem, *T2 = smem, *T1 = smem + G::R0_BYTES, *OUTS = T1;
 
@@ -102,9 +117,10 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
     const int t_n = t / per_img, t_r = t - t_n * per_img;
     const int t_y = t_r / p.tiles_x, t_x = t_r - t_y * p.tiles_x;
     const int y0 = t_y * TH, x0 = t_x * TW;
-    const unsigned cbytes = (unsigned)C * 2u;                    // bytes of one pixel vector
-    const unsigned img_bytes = (unsigned)(p.N * p.H * p.W) * cbytes;
-    const __amdgpu_buffer_rsrc_t xrsrc = bnk_rsrc(p.x, img_bytes), orsrc = bnk_rsrc(p.out, img_bytes);
+    const unsigned cbytes = (unsigned)C * 2u;                    // bytes of one pixel vector of the output
+    const unsigned xbytes = (unsigned)CX * 2u;                   // ... of x
+    const int Hx = PROJ ? p.Hin : p.H, Wx = PROJ ? p.Win : p.W, sx = PROJ ? p.stride : 1;
+    const __amdgpu_buffer_rsrc_t xrsrc = bnk_rsrc(p.x, (unsigned)(p.N * Hx * Wx) * xbytes), orsrc = bnk_rsrc(p.out, (unsigned)(p.N * p.H * p.W) * cbytes);
     const char *w1 = reinterpret_cast<const char *>(p.w1), *w2 = reinterpret_cast<const char *>(p.w2), *w3 = reinterpret_cast<const char *>(p.w3);
 #define BNK_WLOAD(BASE, CB, KS_TOTAL, KS) (*reinterpret_cast<const bnk_bf16x8 *>((BASE) + (((size_t)(CB) * (KS_TOTAL) + (KS)) * 64 + lane) * 16))
 
@@ -112,14 +128,14 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
     // Nothing here may wait on a load it has just issued (one workgroup = one wave per SIMD, nobody else hides the latency): x slabs
     // are XD deep in flight in registers, weight fragments WD k-steps deep.
     constexpr int NLD = NROWS * 4 / 256;                         // 16-byte units per thread and slab
-    constexpr int NSLAB = C / 32;
+    constexpr int NSLAB = CX / 32;
     constexpr int XD = 3, WD = CBW == 1 ? 8 : 6;
     unsigned xoff[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int u = tid + 256 * j, q = u >> 2;
         const int py = y0 - 1 + q / PWD, px = x0 - 1 + q % PWD;
-        xoff[j] = (q < NPATCH && py >= 0 && py < p.H && px >= 0 && px < p.W) ? (unsigned)((t_n * p.H + py) * p.W + px) * cbytes + 16u * (unsigned)(u & 3)
+        xoff[j] = (q < NPATCH && py >= 0 && py < p.H && px >= 0 && px < p.W) ? (unsigned)((t_n * Hx + py * sx) * Wx + px * sx) * xbytes + 16u * (unsigned)(u & 3)
                                                                             : 0x80000000u;
     }
     bnk_floatx16 acc[CBW][PBPW];
@@ -141,7 +157,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #pragma unroll
         for (int d = 0; d < WD; ++d)
 #pragma unroll
-            for (int i = 0; i < CBW; ++i) wq[d][i] = BNK_WLOAD(w1, wc * CBW + i, K1S, d);
+            for (int i = 0; i < CBW; ++i) wq[d][i] = BNK_WLOAD(w1, wc * CBW + i, K1S, d < K1S ? d : K1S - 1);
         float4 bias[CBW][4];
 #pragma unroll
         for (int i = 0; i < CBW; ++i)
@@ -277,23 +293,39 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 
     // ================================================================ stage C: out = relu(W3 t2 + b3 + x), 128 output channels per pass
     constexpr int NST = NPX * 16 / 256;          // 16-byte units per thread of the coalesced store of one pass
-    constexpr int WD3 = K3S < 8 ? K3S : 8;
+    constexpr int WD3 = K3T < 8 ? K3T : 8;
+    constexpr int XD3 = PBO >= 4 ? 4 : 8;        // projection part: k-steps of the x operand in flight (PBO fragments each)
 #pragma unroll 1
     for (int pass = 0; pass < C / 128; ++pass) {
         const int cb3 = pass * 4 + wave;          // 32-channel block of the output this wave computes
         bnk_bf16x8 wq[WD3];
 #pragma unroll
-        for (int d = 0; d < WD3; ++d) wq[d] = BNK_WLOAD(w3, cb3, K3S, d);
-        // shortcut x (4 bf16 per lane, pixel block and channel group) and the bias: in flight during the K walk
+        for (int d = 0; d < WD3; ++d) wq[d] = BNK_WLOAD(w3, cb3, K3T, d);
+        // identity block: shortcut x (4 bf16 per lane, pixel block and channel group); the bias: in flight during the K walk
         bnk_uintx2 rs[PBO][4];
+        unsigned pxo[PBO];                        // projection block: byte offset of this lane's pixel of block j in x (+ its k half)
         float4 bias[4];
 #pragma unroll
         for (int j = 0; j < PBO; ++j) {
             const int pc = j * 32 + l32;                         // canonical tile pixel of this lane
             const int oy = y0 + pc / TW, ox = x0 + pc % TW;
-            const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)((t_n * p.H + oy) * p.W + ox) * cbytes : 0x80000000u;
+            const bool in = oy < p.H && ox < p.W;
+            if (PROJ) pxo[j] = in ? (unsigned)((t_n * Hx + oy * sx) * Wx + ox * sx) * xbytes + 16u * (unsigned)lhalf : 0x80000000u;
+            else {
+                const unsigned pix = in ? (unsigned)((t_n * p.H + oy) * p.W + ox) * cbytes : 0x80000000u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rs[j][g] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, pix, (unsigned)(cb3 * 32 + 8 * g + 4 * lhalf) * 2u, 0);
+                for (int g = 0; g < 4; ++g) rs[j][g] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, pix, (unsigned)(cb3 * 32 + 8 * g + 4 * lhalf) * 2u, 0);
+            }
+        }
+#define BNK_XC_FRAG(J, KP) bnk_as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, pxo[J], 32u * (unsigned)(KP), 0))
+        bnk_bf16x8 xq[PROJ ? XD3 : 1][PBO];
+        if (PROJ) {
+#pragma unroll
+            for (int d = 0; d < XD3; ++d)
+                if (d < KPS) {
+#pragma unroll
+                    for (int j = 0; j < PBO; ++j) xq[d][j] = BNK_XC_FRAG(j, d);
+                }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const float4 *>(p.b3 + cb3 * 32 + 8 * g + 4 * lhalf);
@@ -309,7 +341,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #pragma unroll
         for (int ks = 0; ks < K3S; ++ks) {
             const bnk_bf16x8 wf = wq[ks % WD3];
-            if (ks + WD3 < K3S) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3S, ks + WD3);
+            if (ks + WD3 < K3T) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3T, ks + WD3);
             if (ks + 1 < K3S) {
 #pragma unroll
                 for (int j = 0; j < PBO; ++j) xn[j] = BNK_T2_FRAG(j, ks + 1);
@@ -321,15 +353,37 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef BNK_T2_FRAG
+        if (PROJ) {       // ... + Wd x: the second part of the K walk, x fragments from global memory
+#pragma unroll
+            for (int kp = 0; kp < KPS; ++kp) {
+                const int ks = K3S + kp;
+                const bnk_bf16x8 wf = wq[ks % WD3];
+                if (ks + WD3 < K3T) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3T, ks + WD3);
+                bnk_bf16x8 xc[PBO];
+#pragma unroll
+                for (int j = 0; j < PBO; ++j) xc[j] = xq[kp % XD3][j];
+                if (kp + XD3 < KPS) {
+#pragma unroll
+                    for (int j = 0; j < PBO; ++j) xq[kp % XD3][j] = BNK_XC_FRAG(j, kp + XD3);
+                }
+#pragma unroll
+                for (int j = 0; j < PBO; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xc[j], acc3[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef BNK_XC_FRAG
 #pragma unroll
         for (int j = 0; j < PBO; ++j) {
             const int pc = j * 32 + l32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 b = bias[g];
-                const bnk_uintx2 r = rs[j][g];
-                const float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xffff0000u);
-                const float r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xffff0000u);
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+                if (!PROJ) {
+                    const bnk_uintx2 r = rs[j][g];
+                    r0 = __uint_as_float(r.x << 16); r1 = __uint_as_float(r.x & 0xffff0000u);
+                    r2 = __uint_as_float(r.y << 16); r3 = __uint_as_float(r.y & 0xffff0000u);
+                }
                 bnk_uintx2 pk;
                 pk.x = bnk_pack2(fmaxf(acc3[j][4 * g + 0] + b.x + r0, 0.f), fmaxf(acc3[j][4 * g + 1] + b.y + r1, 0.f));
                 pk.y = bnk_pack2(fmaxf(acc3[j][4 * g + 2] + b.z + r2, 0.f), fmaxf(acc3[j][4 * g + 3] + b.w + r3, 0.f));
@@ -352,7 +406,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #undef BNK_WLOAD
 }
 
-template <int CM, int TH, int TW>
+template <int CM, int TH, int TW, int CIN = 0>
 static int bneck_launch(hipStream_t st, BneckParams &p)
 {
     constexpr size_t smem = BneckGeom<CM, TH, TW>::SMEM;
@@ -360,10 +414,10 @@ static int bneck_launch(hipStream_t st, BneckParams &p)
     p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) {
-        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bottleneck_bf16_kernel<CM, TH, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bottleneck_bf16_kernel<CM, TH, TW, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((bottleneck_bf16_kernel<CM, TH, TW>), dim3((unsigned)(p.N * p.tiles_x * p.tiles_y)), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((bottleneck_bf16_kernel<CM, TH, TW, CIN>), dim3((unsigned)(p.N * p.tiles_x * p.tiles_y)), dim3(256), smem, st, p);
     UPS_CHECK_LAUNCH("bottleneck_bf16_kernel");
     return 0;
 }
@@ -380,7 +434,7 @@ extern "C" int upsnet_bottleneck_bf16(void *stream, const void *x, void *out, in
     UPS_REQUIRE((long)batch * height * width * 4 * cmid < (1L << 30), "bottleneck_bf16: feature map exceeds 2 GiB; split the batch");
     BneckParams p;
     p.x = x; p.out = out; p.w1 = w1; p.w2 = w2; p.w3 = w3; p.b1 = b1; p.b2 = b2; p.b3 = b3;
-    p.N = batch; p.H = height; p.W = width;
+    p.N = batch; p.H = height; p.W = width; p.Hin = height; p.Win = width; p.stride = 1;
     // tiles: 8 x 16 on the stride-4 map (two workgroups per CU), 8 x 8 at width 128 (two per CU), 4 x 8 on the small maps of
     // res4 / res5 (as many workgroups as the map allows)
     hipStream_t st = (hipStream_t)stream;
@@ -391,4 +445,29 @@ extern "C" int upsnet_bottleneck_bf16(void *stream, const void *x, void *out, in
         case 512: return bneck_launch<512, 4, 8>(st, p);
         default: return ups_set_error("bottleneck_bf16: Cm must be 64, 128, 256 or 512 (got %d)", cmid);
     }
+}
+
+/* The FIRST bottleneck of a stage (upsnet/models/resnet.py:84-100 with a projection shortcut) as one launch on the bf16 matrix cores:
+ *   out = relu(conv3(relu(conv2(relu(conv1_s(x))))) + proj_s(x)),   conv1_s / proj_s: 1x1 with stride s (1 or 2), conv2: 3x3 / 1 / 1.
+ * x [N,Hin,Win,Cin] bf16, out [N,H,W,4 Cm] bf16 with H = (Hin - 1) / s + 1 (likewise W). (Cm, Cin) in {(64, 64), (128, 256), (256, 512)}
+ * = res2 / res3 / res4 of a ResNet-50/101. w1: fragments of [Cm, Cin]; w2: of [Cm, 9 Cm] (tap-major k); w3d: of [4 Cm, Cm + Cin] =
+ * [W3 | Wd] (conv3 and the projection as ONE GEMM over K = [t2 ; x]); b1, b2 [Cm]; b3d = b3 + bd [4 Cm]. The shortcut is accumulated in
+ * fp32 (the separate launches round it to bf16 first). */
+extern "C" int upsnet_bottleneck_proj_bf16(void *stream, const void *x, void *out, int batch, int height_in, int width_in, int cin, int cmid,
+                                           int stride, const void *w1, const void *w2, const void *w3d, const float *b1, const float *b2,
+                                           const float *b3d)
+{
+    UPS_REQUIRE(x && out && w1 && w2 && w3d && b1 && b2 && b3d, "bottleneck_proj_bf16: null pointer");
+    UPS_REQUIRE(batch > 0 && height_in > 0 && width_in > 0 && (stride == 1 || stride == 2), "bottleneck_proj_bf16: bad shape / stride");
+    const int H = (height_in - 1) / stride + 1, W = (width_in - 1) / stride + 1;
+    UPS_REQUIRE((long)batch * H * W * 4 * cmid < (1L << 30) && (long)batch * height_in * width_in * cin < (1L << 30),
+                "bottleneck_proj_bf16: feature map exceeds 2 GiB; split the batch");
+    BneckParams p;
+    p.x = x; p.out = out; p.w1 = w1; p.w2 = w2; p.w3 = w3d; p.b1 = b1; p.b2 = b2; p.b3 = b3d;
+    p.N = batch; p.H = H; p.W = W; p.Hin = height_in; p.Win = width_in; p.stride = stride;
+    hipStream_t st = (hipStream_t)stream;
+    if (cmid == 64 && cin == 64) return bneck_launch<64, 8, 16, 64>(st, p);
+    if (cmid == 128 && cin == 256) return bneck_launch<128, 8, 8, 256>(st, p);
+    if (cmid == 256 && cin == 512) return bneck_launch<256, 4, 8, 512>(st, p);
+    return ups_set_error("bottleneck_proj_bf16: (Cm, Cin) must be (64, 64), (128, 256) or (256, 512) (got %d, %d)", cmid, cin);
 }

@@ -175,37 +175,49 @@ def _bf16_plan(m):
 # (csrc/bottleneck_bf16.hip). UPSNET_BF16_BLOCK=0: three launches (A/B runs).
 BF16_BLOCK = os.environ.get('UPSNET_BF16_BLOCK', '1') != '0'
 BF16_BLOCK_MIN_TILES = int(os.environ.get('UPSNET_BF16_BLOCK_MIN_TILES', '128'))
+BF16_PROJ = os.environ.get('UPSNET_BF16_PROJ', '1') != '0'   # the projection (first) bottleneck of res2-res4 as one launch too
 
 
 def use_block(blk, x):
-    """Can `blk` (a folded, non-deformable identity bottleneck) run as one bf16 launch on x?"""
-    if not (ENABLED and BF16_BLOCK and PRECISION == 'bf16' and BF16_ACT and x.is_cuda and x.dtype == torch.bfloat16 and
-            blk.downsample is None and not blk.deformable):
+    """Can `blk` (a folded, non-deformable bottleneck: identity, or the projection block of res2 / res3 / res4) run as one bf16 launch
+    on x?"""
+    if not (ENABLED and BF16_BLOCK and PRECISION == 'bf16' and BF16_ACT and x.is_cuda and x.dtype == torch.bfloat16 and not blk.deformable):
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-    cm = c1.out_channels
-    plain = lambda m, k, p: (tuple(m.kernel_size) == (k, k) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (p, p) and
-                             tuple(m.dilation) == (1, 1) and m.groups == 1)
+    cm, cin, st = c1.out_channels, c1.in_channels, c1.stride[0]
+    plain = lambda m, k, p, s=1: (tuple(m.kernel_size) == (k, k) and tuple(m.stride) == (s, s) and tuple(m.padding) == (p, p) and
+                                  tuple(m.dilation) == (1, 1) and m.groups == 1)
+    if not (plain(c2, 3, 1) and plain(c3, 1, 0) and c2.in_channels == cm and c2.out_channels == cm and c3.in_channels == cm and
+            c3.out_channels == 4 * cm):
+        return False
+    ho, wo = (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1
     # (the kernel's tiles are 8x16 / 8x8 / 4x8 pixels at widths 64 / 128 / >= 256: a map with fewer tiles than half the CUs -- res5 at
     # 1024x2048, 64 tiles, 9 MB of weights per block -- stays on the separate layers: measured 156 us fused vs 130 us)
     th, tw = {64: (8, 16), 128: (8, 8)}.get(cm, (4, 8))
-    if x.shape[0] * -(-x.shape[2] // th) * -(-x.shape[3] // tw) < BF16_BLOCK_MIN_TILES:
+    if x.shape[0] * -(-ho // th) * -(-wo // tw) < BF16_BLOCK_MIN_TILES or x.shape[0] * ho * wo * 4 * cm >= (1 << 30):
         return False
-    return (cm in (64, 128, 256, 512) and plain(c1, 1, 0) and plain(c2, 3, 1) and plain(c3, 1, 0) and c1.in_channels == 4 * cm and
-            c2.in_channels == cm and c2.out_channels == cm and c3.in_channels == cm and c3.out_channels == 4 * cm and
-            x.shape[0] * x.shape[2] * x.shape[3] * 4 * cm < (1 << 30))
+    if blk.downsample is None:
+        return cm in (64, 128, 256, 512) and plain(c1, 1, 0) and cin == 4 * cm
+    pr = blk.downsample[0]
+    return (BF16_PROJ and isinstance(pr, nn.Conv2d) and len(blk.downsample) == 2 and isinstance(blk.downsample[1], nn.Identity) and
+            st in (1, 2) and plain(c1, 1, 0, st) and plain(pr, 1, 0, st) and pr.in_channels == cin and pr.out_channels == 4 * cm and
+            (cm, cin) in ((64, 64), (128, 256), (256, 512)))
 
 
 def block(blk, x):
-    """relu(conv3(relu(conv2(relu(conv1(x))))) + x) -- see use_block."""
-    ms = (blk.conv1, blk.conv2, blk.conv3)
+    """relu(conv3(relu(conv2(relu(conv1(x))))) + shortcut(x)) -- see use_block."""
+    ms = (blk.conv1, blk.conv2, blk.conv3) + (() if blk.downsample is None else (blk.downsample[0],))
     key = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version) for m in ms)
     ent = _plans(blk.conv1).get('block16')
     if ent is None or ent[0] != key:
-        ent = (key, ops.pack_bottleneck_bf16(*(m.weight for m in ms), *(m.bias for m in ms)))
+        pack = ops.pack_bottleneck_bf16 if blk.downsample is None else ops.pack_bottleneck_proj_bf16
+        ent = (key, pack(*(m.weight for m in ms), *(m.bias for m in ms)))
         _plans(blk.conv1)['block16'] = ent
-    y = ops.bottleneck_bf16(x, ent[1])
-    _trace('block', module=blk, x=x, out=y, form='bottleneck_bf16')
+    if blk.downsample is None:
+        y = ops.bottleneck_bf16(x, ent[1])
+    else:
+        y = ops.bottleneck_proj_bf16(x, ent[1], blk.conv1.stride[0])
+    _trace('block', module=blk, x=x, out=y, form='bottleneck_bf16' if blk.downsample is None else 'bottleneck_proj_bf16')
     return y
 
 

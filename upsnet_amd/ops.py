@@ -1166,6 +1166,44 @@ def pack_bottleneck_bf16(w1, w2, w3, b1, b2, b3):
             zeros(c) if b3 is None else f32c(b3.detach()), cm)
 
 
+def pack_bottleneck_proj_bf16(w1, w2, w3, wd, b1, b2, b3, bd):
+    """Folded weights of a projection bottleneck ([Cm,Cin,1,1], [Cm,Cm,3,3], [C,Cm,1,1], projection [C,Cin,1,1], biases) -> the operand
+    pack of bottleneck_proj_bf16: conv3 and the projection as one weight matrix [C, Cm + Cin], one bias b3 + bd."""
+    require_cuda(w1, w2, w3, wd)
+    cm, cin = w1.shape[0], w1.shape[1]
+    c = 4 * cm
+    if not (tuple(w2.shape) == (cm, cm, 3, 3) and tuple(w3.shape) == (c, cm, 1, 1) and tuple(wd.shape) == (c, cin, 1, 1) and
+            (cm, cin) in ((64, 64), (128, 256), (256, 512))):
+        raise RuntimeError("pack_bottleneck_proj_bf16: not the first bottleneck of res2 / res3 / res4")
+    z = lambda b, n: torch.zeros(n, dtype=torch.float32, device=w1.device) if b is None else f32c(b.detach())
+    w3d = torch.cat([w3.detach().float().reshape(c, cm), wd.detach().float().reshape(c, cin)], 1)
+    return (_bf16_fragments(w1.detach().float().reshape(cm, cin)),
+            _bf16_fragments(w2.detach().float().permute(0, 2, 3, 1).reshape(cm, 9 * cm)),
+            _bf16_fragments(w3d), z(b1, cm), z(b2, cm), (z(b3, c) + z(bd, c)).contiguous(), cm, cin)
+
+
+def bottleneck_proj_bf16(x, pack, stride):
+    """relu(conv3(relu(conv2(relu(conv1_s(x))))) + proj_s(x)) of a stage's first bottleneck in one launch; x, result: bf16 channels_last."""
+    w1, w2, w3d, b1, b2, b3d, cm, cin = pack
+    require_cuda(x, w1)
+    if x.dtype != torch.bfloat16 or x.shape[1] != cin:
+        raise RuntimeError("bottleneck_proj_bf16: expects a bf16 map of %d channels" % cin)
+    x = nhwc(x)
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, Ho, Wo, 4 * cm), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_bottleneck_proj_bf16(stream(), ptr(x), ptr(out), N, H, W, int(cin), int(cm), int(stride), ptr(w1), ptr(w2), ptr(w3d),
+                                            ptr(b1), ptr(b2), ptr(b3d)), "bottleneck_proj_bf16")
+    if PROFILE['enabled']:
+        ev1.record()
+        k = cm * cin + 9 * cm * cm + 4 * cm * (cm + cin)
+        PROFILE['events'].append(('bottleneck_bf16', ev0, ev1, 2.0 * k * N * Ho * Wo, 2.0 * C * N * Ho * Wo + 2.0 * 4 * cm * N * Ho * Wo + 2.0 * k))
+    return out
+
+
 def bottleneck_bf16(x, pack):
     """relu(conv3(relu(conv2(relu(conv1(x))))) + x) of an identity bottleneck in one launch; x, result: bf16 NHWC-strided NCHW."""
     w1, w2, w3, b1, b2, b3, cm = pack
