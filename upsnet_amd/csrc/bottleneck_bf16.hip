@@ -72,7 +72,7 @@ __device__ static inline unsigned bnk_pack2(const float a, const float b)
     return (unsigned)ux | ((unsigned)uy << 16);
 }
 
-template <int CM, int TH, int TW>
+template <int CM, int TH, int TW, int CIN = 0>
 struct BneckGeom {
     static constexpr int C = 4 * CM;
     static constexpr int NPX = TH * TW, PBO = NPX / 32;                 // output pixels / 32-pixel blocks of the tile
@@ -83,7 +83,11 @@ struct BneckGeom {
     static constexpr int T2_BYTES = NPX * T_P;                          // t2 (stages B -> C); shares the x-slab region (dead by then)
     static constexpr int R0_BYTES = XS_BYTES > T2_BYTES ? XS_BYTES : T2_BYTES;
     static constexpr int R1_BYTES = NROWS * T_P > NPX * O_P ? NROWS * T_P : NPX * O_P;   // t1 (A -> B), later the output staging (C)
-    static constexpr int SMEM = R0_BYTES + R1_BYTES;
+    // projection block with a long K (CIN >= 256): the tile's own pixels of x stay in LDS for the conv3 | projection GEMM
+    static constexpr bool XCL = CIN >= 256;
+    static constexpr int XC_P = CIN * 2 + 16;
+    static constexpr int XC_BYTES = XCL ? NPX * XC_P : 0;
+    static constexpr int SMEM = R0_BYTES + R1_BYTES + XC_BYTES;
 };
 
 // CIN = 0: identity block (x has 4 CM channels and is the shortcut). CIN > 0: PROJECTION block -- x has CIN channels at stride p.stride,
@@ -93,8 +97,8 @@ struct BneckGeom {
 template <int CM, int TH, int TW, int CIN>
 __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams p)
 {
-    using G = BneckGeom<CM, TH, TW>;
-    constexpr bool PROJ = CIN > 0;
+    using G = BneckGeom<CM, TH, TW, CIN>;
+    constexpr bool PROJ = CIN > 0, XCL = G::XCL;
     constexpr int CX = PROJ ? CIN : 4 * CM;                      // channels of x
     constexpr int C = G::C, NPX = G::NPX, PBO = G::PBO, PWD = G::PWD, NPATCH = G::NPATCH, PBP = G::PBP, NROWS = G::NROWS;
     constexpr int XS_P = G::XS_P, T_P = G::T_P, O_P = G::O_P;
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
     constexpr int K1S = CX / 16, K2S = 9 * CM / 16, K3S = CM / 16; // k steps (16 channels) of the three GEMMs
     constexpr int KPS = PROJ ? CIN / 16 : 0, K3T = K3S + KPS;    // projection part of the last GEMM
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *XS = smem, *T2 = smem, *T1 = smem + G::R0_BYTES, *OUTS = T1;
+    unsigned char *XS = smem, *T2 = smem, *T1 = smem + G::R0_BYTES, *OUTS = T1, *XC = smem + G::R0_BYTES + G::R1_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, lhalf = lane >> 5;
@@ -147,8 +151,16 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bnk_uintx4 rx[XD][NLD];
 #define BNK_FETCH_X(D, S) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) rx[D][j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[j], (unsigned)(S) * 64u, 0); }
-#define BNK_STASH_X(D, BUF) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) { const int u = tid + 256 * j;                \
-        *reinterpret_cast<bnk_uintx4 *>(XS + (BUF) * (NROWS * XS_P) + (u >> 2) * XS_P + (u & 3) * 16) = rx[D][j]; } }
+    // (XCL: patch pixel -> its canonical index inside the tile, -1 for the halo; the slab's 64 bytes of a centre pixel are also kept in XC)
+    int xcrow[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int q = (tid + 256 * j) >> 2, qy = q / PWD - 1, qx = q % PWD - 1;
+        xcrow[j] = (XCL && q < NPATCH && qy >= 0 && qy < TH && qx >= 0 && qx < TW) ? qy * TW + qx : -1;
+    }
+#define BNK_STASH_X(D, BUF, S) { _Pragma("unroll") for (int j = 0; j < NLD; ++j) { const int u = tid + 256 * j;              \
+        *reinterpret_cast<bnk_uintx4 *>(XS + (BUF) * (NROWS * XS_P) + (u >> 2) * XS_P + (u & 3) * 16) = rx[D][j];              \
+        if (XCL && xcrow[j] >= 0) *reinterpret_cast<bnk_uintx4 *>(XC + xcrow[j] * G::XC_P + (S) * 64 + (u & 3) * 16) = rx[D][j]; } }
     {
         bnk_bf16x8 wq[WD][CBW];
 #pragma unroll
@@ -164,7 +176,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias[i][g] = *reinterpret_cast<const float4 *>(p.b1 + (wc * CBW + i) * 32 + 8 * g + 4 * lhalf);
         __builtin_amdgcn_sched_barrier(0);
-        BNK_STASH_X(0, 0)
+        BNK_STASH_X(0, 0, 0)
         if (XD < NSLAB) BNK_FETCH_X(0, XD)
         __syncthreads();
 #pragma unroll
@@ -193,7 +205,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
                 __builtin_amdgcn_sched_barrier(0);      // (keeps the prefetches where they are issued: the scheduler sinks them otherwise)
             }
             if (s + 1 < NSLAB) {
-                BNK_STASH_X((s + 1) % XD, buf ^ 1)
+                BNK_STASH_X((s + 1) % XD, buf ^ 1, s + 1)
                 if (s + 1 + XD < NSLAB) BNK_FETCH_X((s + 1) % XD, s + 1 + XD)
             }
             __syncthreads();
@@ -318,8 +330,8 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
             }
         }
 #define BNK_XC_FRAG(J, KP) bnk_as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, pxo[J], 32u * (unsigned)(KP), 0))
-        bnk_bf16x8 xq[PROJ ? XD3 : 1][PBO];
-        if (PROJ) {
+        bnk_bf16x8 xq[(PROJ && !XCL) ? XD3 : 1][PBO];
+        if (PROJ && !XCL) {
 #pragma unroll
             for (int d = 0; d < XD3; ++d)
                 if (d < KPS) {
@@ -353,7 +365,27 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef BNK_T2_FRAG
-        if (PROJ) {       // ... + Wd x: the second part of the K walk, x fragments from global memory
+        if (PROJ && XCL) {   // ... + Wd x: the second part of the K walk, x fragments from the resident centre pixels
+#define BNK_XL_FRAG(J, KP) (*reinterpret_cast<const bnk_bf16x8 *>(XC + ((J) * 32 + l32) * G::XC_P + ((KP) * 16 + lhalf * 8) * 2))
+#pragma unroll
+            for (int j = 0; j < PBO; ++j) xf[j] = BNK_XL_FRAG(j, 0);
+#pragma unroll
+            for (int kp = 0; kp < KPS; ++kp) {
+                const int ks = K3S + kp;
+                const bnk_bf16x8 wf = wq[ks % WD3];
+                if (ks + WD3 < K3T) wq[ks % WD3] = BNK_WLOAD(w3, cb3, K3T, ks + WD3);
+                if (kp + 1 < KPS) {
+#pragma unroll
+                    for (int j = 0; j < PBO; ++j) xn[j] = BNK_XL_FRAG(j, kp + 1);
+                }
+#pragma unroll
+                for (int j = 0; j < PBO; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[j], acc3[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < PBO; ++j) xf[j] = xn[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef BNK_XL_FRAG
+        } else if (PROJ) {   // short K: x fragments straight from global memory
 #pragma unroll
             for (int kp = 0; kp < KPS; ++kp) {
                 const int ks = K3S + kp;
@@ -409,7 +441,7 @@ __global__ void __launch_bounds__(256) bottleneck_bf16_kernel(const BneckParams 
 template <int CM, int TH, int TW, int CIN = 0>
 static int bneck_launch(hipStream_t st, BneckParams &p)
 {
-    constexpr size_t smem = BneckGeom<CM, TH, TW>::SMEM;
+    constexpr size_t smem = BneckGeom<CM, TH, TW, CIN>::SMEM;
     static_assert(smem <= 160 * 1024, "tile does not fit the LDS");
     p.tiles_x = (p.W + TW - 1) / TW; p.tiles_y = (p.H + TH - 1) / TH;
     static bool attr_set = false;
