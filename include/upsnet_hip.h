@@ -264,7 +264,8 @@ int upsnet_bottleneck_proj_bf16(void *stream, const void *x, void *out, int batc
                                 const void *w1, const void *w2, const void *w3d, const float *b1, const float *b2, const float *b3d);
 /* A/B switch of the 3x3 / stride 1 / 256 -> 256 layers in the plain bf16 mode (csrc/conv3x3_wreg_bf16.hip: weights fed to the MFMA
  * from L2, one barrier per 32-channel slab): enable 0 = the general haloed-patch kernel, 1 = default; tile_rows 0 = automatic,
- * 8 / 16 = forced tile height. Same products and K order either way. */
+ * 8 / 16 = forced tile height, 2 = 2-row tiles (256-channel workgroups), 1 = 2-row tiles with 128-channel workgroups. Same products
+ * and K order either way. */
 int upsnet_conv_bf16_tuning(int enable, int tile_rows);
 /* A/B switch of the 1x1 layers with bf16 activations in the plain bf16 mode (csrc/conv1x1_wreg_bf16.hip: both MFMA operands loaded
  * from global memory in fragment order, no LDS, no barrier): enable 0 = conv_bf16_kernel, 1 = default (the layers it is faster on:

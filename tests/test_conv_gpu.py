@@ -512,7 +512,7 @@ def test_conv3x3_wreg_bf16_kernel(shapes, Cin, Cout, relu, bias, io):
     run = lambda: ops.conv2d_nhwc_bf16_multi(xin, hi, None, ldw, b, Cout, 3, 1, 1, relu=relu, out_dtype=torch.bfloat16 if out16 else torch.float32)
     outs = {}
     try:
-        for name, (en, th) in {'halo': (0, 0), 'wreg2': (1, 2), 'wreg8': (1, 8), 'wreg16': (1, 16), 'auto': (1, 0)}.items():
+        for name, (en, th) in {'halo': (0, 0), 'wreg2n': (1, 1), 'wreg2': (1, 2), 'wreg8': (1, 8), 'wreg16': (1, 16), 'auto': (1, 0)}.items():
             assert lib().upsnet_conv_bf16_tuning(en, th) == 0
             outs[name] = run()
     finally:
@@ -524,7 +524,7 @@ def test_conv3x3_wreg_bf16_kernel(shapes, Cin, Cout, relu, bias, io):
         assert o.shape == ref.shape and o.dtype == (torch.bfloat16 if out16 else torch.float32) and o.permute(0, 2, 3, 1).is_contiguous()
         tol = 2.0 ** -8 if out16 else 1e-4
         np.testing.assert_allclose(o.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
-    for name in ('halo', 'wreg2', 'wreg8', 'wreg16'):
+    for name in ('halo', 'wreg2n', 'wreg2', 'wreg8', 'wreg16'):
         for a, o in zip(outs[name], outs['auto']):
             assert torch.equal(a, o), name
 

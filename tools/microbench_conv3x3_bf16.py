@@ -42,14 +42,14 @@ def main():
                 xs = [x.bfloat16() for x in xs]
             px = sum(n * h * w_ for n, h, w_ in shapes)
             row = []
-            for en, th in ((0, 0), (1, 2), (1, 8), (1, 16), (1, 0)):
+            for en, th in ((0, 0), (1, 1), (1, 2), (1, 8), (1, 16), (1, 0)):
                 lib().upsnet_conv_bf16_tuning(en, th)
                 t = timeit(lambda: ops.conv2d_nhwc_bf16_multi(xs, hi, None, ldw, b, C, 3, 1, 1, relu=True))
                 row.append(t)
             lib().upsnet_conv_bf16_tuning(1, 0)
             fl = 2.0 * 9 * C * C * px
-            print("%-20s %s in   halo %7.1f us   wreg2 %7.1f   wreg8 %7.1f   wreg16 %7.1f   auto %7.1f us (%5.0f TFLOP/s)"
-                  % (name, 'bf16' if in16 else 'fp32', row[0], row[1], row[2], row[3], row[4], fl / row[4] * 1e-6), flush=True)
+            print("%-20s %s in   halo %7.1f us   wreg2/128 %7.1f   wreg2 %7.1f   wreg8 %7.1f   wreg16 %7.1f   auto %7.1f us (%5.0f TFLOP/s)"
+                  % (name, 'bf16' if in16 else 'fp32', row[0], row[1], row[2], row[3], row[4], row[5], fl / row[5] * 1e-6), flush=True)
 
 
 if __name__ == '__main__':

@@ -60,7 +60,8 @@ __device__ static inline unsigned w3_pack2(const float a, const float b)
     return (unsigned)ux | ((unsigned)uy << 16);
 }
 
-template <int TH, int IO>
+// NCB: 32-channel blocks per wave: 2 (256 output channels per workgroup) or 1 (128: twice the workgroups, for maps with few tiles)
+template <int TH, int IO, int NCB = 2>
 __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x3_wreg_bf16_kernel(const ConvParams p, const char *__restrict__ wpk)
 {
     constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
@@ -123,13 +124,14 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
     // weight fragment of this wave's 32-column block I, slab S (= tap * cslabs + cs), k-step T: 16 bytes per lane; the lane part of
     // the address is one register, the slab / k-step part wave-uniform (SGPR offset of the buffer load)
     const __amdgpu_buffer_rsrc_t wrsrc = w3_rsrc(wpk, 9u * (unsigned)p.Cin * (unsigned)p.ldw * 2u);
-    const unsigned wvo = (unsigned)((8 * n_t + 2 * wc) * 32 + l32) * 64u + 16u * (unsigned)lhalf;
+    const int cb0 = (4 * n_t + wc) * NCB;       // first 32-channel block of this wave
+    const unsigned wvo = (unsigned)(cb0 * 32 + l32) * 64u + 16u * (unsigned)lhalf;
     const unsigned slab_bytes = (unsigned)p.ldw * 64u;
 #define W3_WLOAD(I, S, T) w3_as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo + (I) * 2048u, (unsigned)(S) * slab_bytes + 32u * (unsigned)(T), 0))
 
-    floatx16 acc[2][NPB];
+    floatx16 acc[NCB][NPB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NCB; ++i)
 #pragma unroll
         for (int j = 0; j < NPB; ++j)
 #pragma unroll
@@ -141,12 +143,12 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
         prow[j] = (y * W3_PW + x) * W3_XP + lhalf * 16;
     }
 
-    w3_bf16x8 wq[WD][2];
+    w3_bf16x8 wq[WD][NCB];
     W3_FETCH_X(0)
 #pragma unroll
     for (int d = 0; d < WD; ++d)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wq[d][i] = W3_WLOAD(i, (d >> 1) * cslabs, d & 1);
+        for (int i = 0; i < NCB; ++i) wq[d][i] = W3_WLOAD(i, (d >> 1) * cslabs, d & 1);
     __builtin_amdgcn_sched_barrier(0);
     W3_STASH_X(0)
     __syncthreads();
@@ -161,16 +163,16 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
         for (int j = 0; j < NPB; ++j) xf[j] = W3_XFRAG(j, 0);
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {            // k-step kk = (tap, t) of this slab
-            w3_bf16x8 wf[2];
+            w3_bf16x8 wf[NCB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i] = wq[kk % WD][i];
+            for (int i = 0; i < NCB; ++i) wf[i] = wq[kk % WD][i];
             {   // k-step kk + WD: same slab of channels while it lasts, then the first steps of the next one
                 const int kn = kk + WD;
                 const int ntap = (kn % 18) >> 1, nt = kn & 1;
                 const int ncs = kn < 18 ? cs : cs + 1;
                 if (kn < 18 || more) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) wq[kk % WD][i] = W3_WLOAD(i, ntap * cslabs + ncs, nt);
+                    for (int i = 0; i < NCB; ++i) wq[kk % WD][i] = W3_WLOAD(i, ntap * cslabs + ncs, nt);
                 }
             }
             if (kk + 1 < 18) {
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NCB; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NPB; ++j) xf[j] = xn[j];
             __builtin_amdgcn_sched_barrier(0);
@@ -197,11 +199,11 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
     const __amdgpu_buffer_rsrc_t orsrc = w3_rsrc(sg.out, (unsigned)sg.M * (unsigned)p.Cout * (OUT16 ? 2u : 4u));
     const bool has_bias = p.bias != nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCB; ++i) {
         float4 b[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            b[g] = has_bias ? *reinterpret_cast<const float4 *>(p.bias + (8 * n_t + 2 * wc + i) * 32 + 8 * g + 4 * lhalf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[g] = has_bias ? *reinterpret_cast<const float4 *>(p.bias + (cb0 + i) * 32 + 8 * g + 4 * lhalf) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
             const int pp = w3_perm(l32);
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
                 float v0 = acc[i][j][4 * g + 0] + b[g].x, v1 = acc[i][j][4 * g + 1] + b[g].y;
                 float v2 = acc[i][j][4 * g + 2] + b[g].z, v3 = acc[i][j][4 * g + 3] + b[g].w;
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                const unsigned e = pix + (unsigned)((8 * n_t + 2 * wc + i) * 32 + 8 * g + 4 * lhalf);
+                const unsigned e = pix + (unsigned)((cb0 + i) * 32 + 8 * g + 4 * lhalf);
                 if (OUT16) {
                     w3_uintx2 pk;
                     pk.x = w3_pack2(v0, v1); pk.y = w3_pack2(v2, v3);
@@ -229,11 +231,13 @@ __global__ void __launch_bounds__(TH == 16 ? 512 : 256, TH == 16 ? 1 : 2) conv3x
 
 static int g_wreg_on = -1, g_wreg_th = -1;     // -1: from the environment on first use (UPSNET_BF16_WREG, UPSNET_BF16_WREG_TH)
 
-/* A/B switch of the 3x3 256 -> 256 bf16 kernel: enable 0 = the layers stay on conv3x3_bf16_halo_kernel, 1 = this file's kernel
- * (default); tile_rows 0 = automatic, 8 or 16 = force the tile height. Results do not depend on either. */
+/* A/B switch of the 3x3 bf16 kernel of this file: enable 0 = the layers stay on conv3x3_bf16_halo_kernel, 1 = this file's kernel
+ * (default); tile_rows 0 = automatic, 8 or 16 = force the tile height, 2 = 2-row tiles with 256-channel workgroups, 1 = 2-row tiles
+ * with 128-channel workgroups. Results do not depend on either. */
 extern "C" int upsnet_conv_bf16_tuning(int enable, int tile_rows)
 {
-    UPS_REQUIRE((enable == 0 || enable == 1) && (tile_rows == 0 || tile_rows == 2 || tile_rows == 8 || tile_rows == 16), "conv_bf16_tuning: enable 0/1, tile_rows 0/2/8/16");
+    UPS_REQUIRE((enable == 0 || enable == 1) && (tile_rows == 0 || tile_rows == 1 || tile_rows == 2 || tile_rows == 8 || tile_rows == 16),
+                "conv_bf16_tuning: enable 0/1, tile_rows 0/1/2/8/16");
     g_wreg_on = enable; g_wreg_th = tile_rows;
     return 0;
 }
@@ -259,13 +263,17 @@ int conv3x3_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi
     // ROIs: tools/microbench_conv3x3_bf16.py; kept behind upsnet_conv_bf16_tuning.) Small maps (res4 / res5 at 1024x2048: 64 / 16
     // tiles of 8 x 16): 2 x 16 tiles, four times the workgroups (each streams the whole weight block for 32 pixels: only where
     // the chip would otherwise idle).
-    p.n_tiles = p.Cout / 256;
     auto count = [&](int th) {
         int t = 0;
         for (int i = 0; i < p.nseg; ++i) t += p.seg[i].N * ((p.seg[i].Ho + th - 1) / th) * ((p.seg[i].Wo + W3_TW - 1) / W3_TW);
         return t;
     };
-    const int th = (g_wreg_th == 2 || g_wreg_th == 8 || g_wreg_th == 16) ? g_wreg_th : (count(8) * p.n_tiles < 72 ? 2 : 8);
+    const int n256 = p.Cout / 256;
+    const int th = (g_wreg_th == 8 || g_wreg_th == 16) ? g_wreg_th : (g_wreg_th == 1 || g_wreg_th == 2) ? 2 : (count(8) * n256 < 72 ? 2 : 8);
+    // 128-channel workgroups (one 32-channel block per wave) where 2 x 16 tiles x 256-channel blocks still leave half the CUs idle
+    // (res5 at 1024x2048: 64 tiles x 2)
+    const bool narrow = th == 2 && (g_wreg_th == 1 || (g_wreg_th == 0 && count(2) * n256 <= 128));
+    p.n_tiles = narrow ? p.Cout / 128 : n256;
     int tiles = 0;
     for (int i = 0; i < p.nseg; ++i) {
         p.seg[i].tile_start = tiles;
@@ -274,11 +282,12 @@ int conv3x3_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi
     p.m_tiles = tiles;
     const int grid = 8 * ((tiles + 7) / 8) * p.n_tiles;
     const char *w = reinterpret_cast<const char *>(wpack_hi);
-#define W3_GO(TH_, IO_) hipLaunchKernelGGL((conv3x3_wreg_bf16_kernel<TH_, IO_>), dim3(grid), dim3(TH_ == 16 ? 512 : 256), 0, st, p, w)
-#define W3_GO_IO(TH_) switch (p.io & 3) { case 0: W3_GO(TH_, 0); break; case 1: W3_GO(TH_, 1); break; case 2: W3_GO(TH_, 2); break; default: W3_GO(TH_, 3); break; }
-    if (th == 16) W3_GO_IO(16)
-    else if (th == 8) W3_GO_IO(8)
-    else W3_GO_IO(2)
+#define W3_GO(TH_, IO_, NCB_) hipLaunchKernelGGL((conv3x3_wreg_bf16_kernel<TH_, IO_, NCB_>), dim3(grid), dim3(TH_ == 16 ? 512 : 256), 0, st, p, w)
+#define W3_GO_IO(TH_, NCB_) switch (p.io & 3) { case 0: W3_GO(TH_, 0, NCB_); break; case 1: W3_GO(TH_, 1, NCB_); break; case 2: W3_GO(TH_, 2, NCB_); break; default: W3_GO(TH_, 3, NCB_); break; }
+    if (th == 16) W3_GO_IO(16, 2)
+    else if (th == 8) W3_GO_IO(8, 2)
+    else if (narrow) W3_GO_IO(2, 1)
+    else W3_GO_IO(2, 2)
 #undef W3_GO_IO
 #undef W3_GO
     UPS_CHECK_LAUNCH("conv3x3_wreg_bf16_kernel");
