@@ -1,21 +1,25 @@
-// conv3x3_wreg_bf16.hip -- 3x3 / stride 1 / pad 1 convolution with 256 output channels on the bf16 matrix cores, weights fed to the
-// MFMA straight from L2 (gfx950). The FPN output convolutions (upsnet/models/fpn.py:38-41,98-101), the RPN's shared 3x3
-// (upsnet/models/rpn.py:29,45) and the four 3x3 layers of the mask head (upsnet/models/rcnn.py:122-131) in the bf16 mode of
-// BASELINE.json configs[2]: all 256 -> 256.
+// conv3x3_wreg_bf16.hip -- 3x3 / stride 1 / pad 1 convolution with output channels in blocks of 256 on the bf16 matrix cores, weights
+// fed to the MFMA straight from L2 (gfx950). The FPN output convolutions (upsnet/models/fpn.py:38-41,98-101), the RPN's shared 3x3
+// (upsnet/models/rpn.py:29,45), the four 3x3 layers of the mask head (upsnet/models/rcnn.py:122-131) -- all 256 -> 256 -- and conv2 of
+// the res5 bottlenecks (512 -> 512) in the bf16 mode of BASELINE.json configs[2].
 //
 // conv3x3_bf16_halo_kernel (conv_bf16.hip) stages BOTH operands through LDS and synchronises once per tap: 8 MFMAs per wave and
 // barrier, matrix pipe 31 % busy (profiles/r06). Here
 //   * the MFMA operands are swapped: A = weights (rows = 32 output channels), B = activations (columns = 32 pixels). The packed
 //     weights [tap * Cin/32 + c/32][column][32 k] (upsnet_conv_pack_weight_bf16) already hold, for a lane (column l, k half h) of a
-//     k-step t, its eight k values in 16 consecutive bytes -- one global_load_dwordx4 per lane and MFMA operand, WD k-steps ahead,
-//     no LDS, no barrier;
-//   * a workgroup owns a TH x 16 pixel tile and ALL 256 output channels (the haloed activation patch is read once, not once per
+//     k-step t, its eight k values in 16 consecutive bytes -- one buffer_load_dwordx4 per lane and MFMA operand (lane address in one
+//     register, slab / k-step as the scalar offset), three k-steps ahead, no LDS, no barrier;
+//   * a workgroup owns a TH x 16 pixel tile and 256 output channels (the haloed activation patch is read once, not once per
 //     128-channel half): wave = 64 channels x 4 blocks of 2 x 16 pixels, 128 accumulator registers; TH = 8 (4 waves, two workgroups
-//     per CU) by default, TH = 16 (8 waves, one per CU) behind upsnet_conv_bf16_tuning;
+//     per CU) by default; TH = 2 (one pixel block per wave) on maps with few tiles, there with 128-channel workgroups (NCB = 1) when
+//     256-channel ones still leave half the CUs idle; TH = 16 (8 waves, one workgroup per CU) behind upsnet_conv_bf16_tuning;
 //   * only the activations go through LDS, one 32-channel slab of the haloed patch at a time (double-buffered, fp32 -> bf16 on the
-//     way in): ONE barrier per slab = per 144 MFMAs of a wave;
+//     way in): ONE barrier per slab = per 144 MFMAs of a wave; activation fragments are read one k-step ahead;
 //   * an accumulator lane holds 4 x 4 consecutive channels of one pixel: 16-byte stores.
-// Same K order (slab, tap, k-step) and the same products as the halo kernel.
+// Same K order (slab, tap, k-step) and the same products as the halo kernel: bit-identical results for every tile form.
+// Measured (tools/microbench_conv3x3_bf16.py, profiles/r09_bf16_micro.txt): FPN out 335 -> 212 us, RPN 299 -> 211 us (0.95-1.2
+// PFLOP/s); PMC on those launches: matrix pipe 47 % busy, LDS bank conflicts 7 % of the LDS cycles, SQ_WAIT_INST_ANY 56 % of the wave
+// cycles -- at two waves per SIMD the kernel waits on operand delivery (LDS and L1 each at about half their peak), not on the MFMAs.
 #include <stdlib.h>
 
 #include "conv_params.h"
