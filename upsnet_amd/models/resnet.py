@@ -9,7 +9,8 @@ the res3..res5 blocks. Parameter names are the reference's (`resnet_backbone.res
 How it is built here is table-driven: one block class covers both bottleneck kinds, and because
 every BN is frozen the whole backbone can be re-parameterised for inference (`fold_frozen_bn`): the BN
 affine is folded into the preceding convolution, removing one read+write of every activation.
-Every convolution runs on the hand-written MFMA kernels (models/hipconv.py); only the 3x3/2 max-pool is a library op.
+Every convolution runs on the hand-written MFMA kernels (models/hipconv.py); the stem convolution, its ReLU and the 3x3/2 max-pool are
+one launch (csrc/stem_pool.hip, csrc/stem_pool_bf16.hip).
 """
 import warnings
 
