@@ -274,7 +274,7 @@ int upsnet_conv1x1_bf16_tuning(int enable);
 /* The backbone stem in one launch on the fp32 matrix cores (upsnet/models/resnet.py:347-356; the headline path): convolution 7x7 /
  * stride 2 / pad 3 (Cin <= 3 -> 64, frozen BN folded: + bias) + ReLU + max-pool 3x3 / stride 2 / pad 1 -- the 134 MB convolution output
  * of a 1024x2048 image never reaches HBM. x4 [N,H,W,4] fp32 (RGB + a zero channel), wpack = upsnet_stem_pool_pack_weight_f32(weight
- * [64,Cin,7,7]) (2 x 84 x 64 floats), bias [64] or NULL, out [N,Hp,Wp,64] fp32, Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (likewise the
+ * [64,Cin,7,7]) (2 x 75 x 64 floats), bias [64] or NULL, out [N,Hp,Wp,64] fp32, Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (likewise the
  * width). Exact fp32 products (v_mfma_f32_32x32x2_f32), fixed summation order. */
 int upsnet_stem_pool_pack_weight_f32(void *stream, const float *weight, int cin, float *wpack);
 int upsnet_stem_pool_f32(void *stream, const float *x4, int batch, int height, int width, const float *wpack, const float *bias, float *out);

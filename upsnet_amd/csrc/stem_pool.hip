@@ -8,14 +8,15 @@
 //     odd columns in separate half rows (the stride-2 convolution reads every other column: 16 consecutive lanes then read 16
 //     consecutive 16-byte slots);
 //   * the 9 x 33 convolution outputs the pool windows touch are computed as 10 blocks of 32 pixels with v_mfma_f32_32x32x2_f32, operands
-//     swapped (A = weights, rows = 32 output channels; B = activations, columns = pixels): a k-pair = the two columns (2p, 2p + 1) of a
-//     kernel row for ONE input channel, so a lane's ONE 16-byte LDS read (its pixel, 4 channels) feeds three MFMAs (the fourth
-//     channel is zero and skipped): K = 7 rows x 4 column pairs x 3 channels = 84 MFMAs per block and 32-channel half. The 84 weight
-//     values of a lane stay in registers for a whole half;
+//     swapped (A = weights, rows = 32 output channels; B = activations, columns = pixels): a k-pair = two CONSECUTIVE TAPS (2t, 2t + 1) of
+//     the 49 in raster order (the 50th is a zero weight) for ONE input channel -- lane half 0 reads the pixel of tap 2t, half 1 the pixel
+//     of tap 2t + 1 --, so a lane's ONE 16-byte LDS read (its pixel, 4 channels) feeds three MFMAs (the fourth channel is zero and
+//     skipped): K = 25 tap pairs x 3 channels = 75 MFMAs per block and 32-channel half. The 2 x 75 weight values of a lane stay in
+//     registers for the whole kernel;
 //   * per 32-channel half: bias + ReLU into an LDS tile [pixel][32 channels] fp32 (outside the map: 0 -- the pool pads with -inf and every
 //     window holds a real, non-negative value, so 0 never changes a maximum), then the pool: nine 16-byte reads per (pooled pixel,
 //     4 channels), one 16-byte store.
-// Exact fp32 products, fp32 sums in a fixed order (kernel row, column pair, channel).
+// Exact fp32 products, fp32 sums in a fixed order (tap pair in raster order, channel).
 #include <stdlib.h>
 
 #include "common.h"
@@ -28,10 +29,10 @@ typedef float spf_floatx16 __attribute__((ext_vector_type(16)));
 #define SPF_PW (2 * (SPF_CTW - 1) + 8)      // input patch: (4 TPH + 7) rows x 72 columns (one column beyond the 7 taps: the zero eighth tap)
 #define SPF_PWH (SPF_PW / 2)                // columns per parity
 #define SPF_CTP 144                         // bytes per convolution pixel in LDS: 32 fp32 + 16
-#define SPF_NW 84                           // weight values per lane and 32-channel half
+#define SPF_NW 75                           // weight values per lane and 32-channel half: 25 tap pairs x 3 channels
 
-// weight [64, Cin <= 4, 7, 7] fp32 -> [half 2][ky 7][p 4][c 3][lane 64]: lane (row l, k = lane / 32) holds W[32 half + l][c][ky][2 p + k]
-// (0 for kx = 7 and c >= Cin)
+// weight [64, Cin <= 3, 7, 7] fp32 -> [half 2][tap pair 25][c 3][lane 64]: lane (row l, k = lane / 32) holds W[32 half + l][c][tap 2 t + k]
+// with tap = ky 7 + kx (0 for tap 49 and c >= Cin)
 __global__ void stem_pool_pack_weight_f32_kernel(const float *__restrict__ w, int cin, float *__restrict__ wp)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,10 +40,9 @@ __global__ void stem_pool_pack_weight_f32_kernel(const float *__restrict__ w, in
     const int lane = idx & 63;
     int r = idx >> 6;
     const int c = r % 3; r /= 3;
-    const int p = r & 3; r >>= 2;
-    const int ky = r % 7, cb = r / 7;
-    const int co = 32 * cb + (lane & 31), kx = 2 * p + (lane >> 5);
-    wp[idx] = (kx < 7 && c < cin) ? w[((co * cin + c) * 7 + ky) * 7 + kx] : 0.f;
+    const int t = r % 25, cb = r / 25;
+    const int co = 32 * cb + (lane & 31), tap = 2 * t + (lane >> 5);
+    wp[idx] = (tap < 49 && c < cin) ? w[(co * cin + c) * 49 + tap] : 0.f;
 }
 
 extern "C" int upsnet_stem_pool_pack_weight_f32(void *stream, const float *weight, int cin, float *wpack)
@@ -70,6 +70,12 @@ stem_pool_f32_kernel(const float *__restrict__ x4, const int N, const int H, con
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;          // convolution pixel of tile position (0, 0)
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // input pixel of patch position (0, 0)
 
+    // ---- the weights: 2 x 75 values per lane, resident for the whole kernel (issued first: in flight while the patch is staged)
+    float wf[2][SPF_NW];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k = 0; k < SPF_NW; ++k) wf[cb][k] = wpk[(cb * SPF_NW + k) * 64 + lane];
     // ---- input patch, zero outside the image; column c of row r at [(r, c & 1)][c >> 1]
     const float4 *xin = reinterpret_cast<const float4 *>(x4) + (size_t)t_n * H * W;
     for (int i = tid; i < SPF_PH * SPF_PW; i += 256) {
@@ -81,12 +87,8 @@ stem_pool_f32_kernel(const float *__restrict__ x4, const int N, const int H, con
     }
     __syncthreads();
 
-#pragma unroll 1
-    for (int cb = 0; cb < 2; ++cb) {
-        // ---- the weights of this half: 84 values per lane, resident
-        float wf[SPF_NW];
 #pragma unroll
-        for (int k = 0; k < SPF_NW; ++k) wf[k] = wpk[(cb * SPF_NW + k) * 64 + lane];
+    for (int cb = 0; cb < 2; ++cb) {
         float4 bv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bv[g] = bias ? *reinterpret_cast<const float4 *>(bias + cb * 32 + 8 * g + 4 * lhalf) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -95,20 +97,22 @@ stem_pool_f32_kernel(const float *__restrict__ x4, const int N, const int H, con
             const int q = blk * 32 + l32;
             const int qq = q < SPF_NCT ? q : 0;
             const int cyl = qq / SPF_CTW, cxl = qq - cyl * SPF_CTW;
-            // input column 2 cxl + 2 p + lhalf: parity lhalf, slot cxl + p
-            const unsigned char *base = PT + (((2 * cyl) * 2 + lhalf) * SPF_PWH + cxl) * 16;
+            // tap (ky, kx) of this pixel: patch row 2 cyl + ky, column 2 cxl + kx = parity kx & 1, slot cxl + (kx >> 1)
+            const unsigned char *base = PT + ((2 * cyl) * 2 * SPF_PWH + cxl) * 16;
             spf_floatx16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float4 xv = *reinterpret_cast<const float4 *>(base + (ky * 2 * SPF_PWH + p) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(ky * 4 + p) * 3 + 0], xv.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(ky * 4 + p) * 3 + 1], xv.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(ky * 4 + p) * 3 + 2], xv.z, acc, 0, 0, 0);
-                }
+            for (int t = 0; t < 25; ++t) {
+                // lane half 0: tap 2 t, half 1: tap 2 t + 1 (tap 49 has zero weights: any valid address)
+                const int ta = 2 * t, tb = 2 * t + 1 < 49 ? 2 * t + 1 : 48;
+                const int offa = (((ta / 7) * 2 + ((ta % 7) & 1)) * SPF_PWH + ((ta % 7) >> 1)) * 16;
+                const int offb = (((tb / 7) * 2 + ((tb % 7) & 1)) * SPF_PWH + ((tb % 7) >> 1)) * 16;
+                const float4 xv = *reinterpret_cast<const float4 *>(base + (lhalf ? offb : offa));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][t * 3 + 0], xv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][t * 3 + 1], xv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][t * 3 + 2], xv.z, acc, 0, 0, 0);
+            }
             const int cy = cy0 + cyl, cx = cx0 + cxl;
             const bool real = q < SPF_NCT && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
 #pragma unroll
@@ -141,7 +145,7 @@ stem_pool_f32_kernel(const float *__restrict__ x4, const int N, const int H, con
 
 /* conv 7x7 / 2 / 3 (Cin <= 3 -> 64, + bias) + ReLU + max-pool 3x3 / 2 / 1 in one launch on the fp32 matrix cores (backbone stem,
  * upsnet/models/resnet.py:347-356). x4: [N,H,W,4] fp32 (RGB + zero channel, upsnet_image_to_nhwc4 / upsnet_prep_image_u8); wpack:
- * upsnet_stem_pool_pack_weight_f32 (2 x 84 x 64 floats); bias [64] or NULL; out [N,Hp,Wp,64] fp32 with Hc = (H - 1) / 2 + 1,
+ * upsnet_stem_pool_pack_weight_f32 (2 x 75 x 64 floats); bias [64] or NULL; out [N,Hp,Wp,64] fp32 with Hc = (H - 1) / 2 + 1,
  * Hp = (Hc - 1) / 2 + 1 (likewise for the width). */
 extern "C" int upsnet_stem_pool_f32(void *stream, const float *x4, int batch, int height, int width, const float *wpack, const float *bias,
                                     float *out)

@@ -794,12 +794,12 @@ def pack_stem_weight(weight):
 
 
 def pack_stem_pool_weight_f32(weight):
-    """[64, Cin <= 3, 7, 7] fp32 -> the operand pack of stem_pool_f32 (2 x 84 x 64 floats)."""
+    """[64, Cin <= 3, 7, 7] fp32 -> the operand pack of stem_pool_f32 (2 x 75 x 64 floats)."""
     require_cuda(weight)
     weight = f32c(weight)
     if tuple(weight.shape[0:1] + weight.shape[2:]) != (64, 7, 7) or weight.shape[1] > 3:
         raise RuntimeError("pack_stem_pool_weight_f32: weight must be [64, Cin <= 3, 7, 7]")
-    wp = torch.empty(2 * 84 * 64, dtype=torch.float32, device=weight.device)
+    wp = torch.empty(2 * 75 * 64, dtype=torch.float32, device=weight.device)
     check(lib().upsnet_stem_pool_pack_weight_f32(stream(), ptr(weight), int(weight.shape[1]), ptr(wp)), "stem_pool_pack_weight_f32")
     return wp
 
