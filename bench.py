@@ -124,6 +124,11 @@ def main():
 
     def before_step(s, model):   # (called before the launch of timed image s: with two images in flight that is before image
         on = s % PROFILE_EVERY == 0  # s-1 has been read back, so the switch cannot live in a per-result callback)
+        if s > 0 and (s - 1) % PROFILE_EVERY == 0:
+            # the sampled image has the device to itself: the next image (a graph replay on another stream) is launched only when it
+            # has finished, or its kernels would overlap the sampled launches and inflate their event-to-event times (observed: the
+            # dense family at 0.57 instead of 0.61 of the MFMA peak). One image pair without overlap inside the timed region.
+            torch.cuda.synchronize()
         sample(model, on)
         sampled[0] += int(on)
 
