@@ -146,6 +146,7 @@ def supported(m, x):
 # the bf16 kernels work on 128 x 128 tiles: layers with fewer workgroups than this (res5, the P5 / P6 maps, narrow heads) would leave
 # most CUs idle and stay on the fp32 kernels (exact, and faster there)
 BF16_MIN_WG = int(os.environ.get('UPSNET_BF16_MIN_WG', '192'))
+BF16_MIN_WG_WREG = int(os.environ.get('UPSNET_BF16_MIN_WG_WREG', '16'))
 
 
 def _use_bf16(m, xs, always=False):
@@ -158,7 +159,9 @@ def _use_bf16(m, xs, always=False):
     for x in xs:
         ho, wo = (x.shape[2] + 2 * pd - (dl * (k - 1) + 1)) // st + 1, (x.shape[3] + 2 * pd - (dl * (k - 1) + 1)) // st + 1
         wgs += -(-(x.shape[0] * ho * wo) // 128)
-    return wgs * -(-m.out_channels // 128) >= BF16_MIN_WG
+    # (3x3 / 1 layers with 256-channel blocks run on csrc/conv3x3_wreg_bf16.hip, which has 2-row tiles for small maps: P4 / P5 outputs)
+    small_ok = PRECISION == 'bf16' and k == 3 and st == 1 and dl == 1 and m.out_channels % 256 == 0
+    return wgs * -(-m.out_channels // 128) >= (BF16_MIN_WG_WREG if small_ok else BF16_MIN_WG)
 
 
 def _bf16_plan(m):
