@@ -73,7 +73,7 @@ def ensure_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=200, help='timed images per rank (default 200: a timed region of > 1 s at ~150 img/s)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='upsnet50_cityscapes_1024x2048')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -93,8 +93,14 @@ def main():
                          'rank (checked against the eager forward), communicator warm-up, per-rank device memory; prints one JSON line')
     ap.add_argument('--cpu-baseline-scale', type=float, default=1.0,
                     help='linear scale of the image used for the bounded CPU sample (1.0 = full 1024x2048: 1 warm-up + 3 timed passes, ~35 s)')
+    ap.add_argument('--no-wide-offsets', action='store_true',
+                    help='skip the short extra leg that times the deformable kernels on a model with 2 px offset standard deviation '
+                         '(the headline model predicts ~1 px offsets like a trained DCN; reported as roofline.deformable_wide_offsets)')
     args = ap.parse_args()
+    steps_explicit = any(a == '--steps' or a.startswith('--steps=') for a in sys.argv[1:])
     ensure_ranks(args)
+    from upsnet_amd import knobs as _knobs
+    active_knobs = _knobs.check()      # a UPSNET_* variable no source reads (typo) is an error, not a silently different kernel mix
 
     from upsnet_amd import ops
     from upsnet_amd.models import hipconv
@@ -102,7 +108,7 @@ def main():
     hipconv.PRECISION = args.conv_precision
     if args.dry_run:
         from upsnet_amd.upsnet_end2end_test import preflight
-        rep = preflight(args.workload, in_flight=args.in_flight)
+        rep = preflight(args.workload, in_flight=args.in_flight, steps=args.steps)
         if rep is not None:
             print(json.dumps(rep), flush=True)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -276,6 +282,15 @@ def main():
                                            'launches_timed': n_db, 'avg_launch_ms': round(1000.0 * t_db / n_db, 4),
                                            'algorithmic_bytes_per_launch': b_db / n_db, 'hbm_equiv_GBs': round(b_db / t_db / 1e9, 1)}
 
+    # kernel-form histogram of the sampled image: which form of which kernel family every launch of that image took
+    form_hist = {}
+    for e in ops.PROFILE['events']:
+        key = '%s:%s' % (e[0], (e[5].split() or ['?'])[0] if len(e) > 5 else '?')
+        form_hist[key] = form_hist.get(key, 0) + 1
+    timed_s = res['elapsed']
+    if roofline is not None and timed_s < 1.0 and not steps_explicit:
+        roofline = {'refused': 'timed region %.3f s < 1 s with the default --steps; pass --steps explicitly (the driver does) or raise it' % timed_s}
+
     # ---- CPU baseline: the oracle's composite forward on the host cores (bounded sample)
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -335,7 +350,10 @@ def main():
     n_det, n_inst = int(last['cls_inds'].numel()), int(last['panoptic_cls_inds'].numel())
     agree = float((chk['panoptic_outputs'] == last['panoptic_outputs']).float().mean())
     boxes_same_shape = chk['pred_boxes'].shape == last['pred_boxes'].shape
-    if world == 1 and args.conv_precision == 'fp32' and not args.no_configs2:
+    wide = None
+    run_c2 = world == 1 and args.conv_precision == 'fp32' and not args.no_configs2
+    run_wide = world == 1 and not args.no_wide_offsets and roofline is not None and 'deformable' in roofline
+    if run_c2 or run_wide:
         # the headline's model goes first: with its graph pools still resident the second model runs ~12 % slower (measured:
         # 168 vs 190 img/s; freeing them restores it)
         import gc
@@ -345,17 +363,45 @@ def main():
         res.pop('last_out', None)
         gc.collect()
         torch.cuda.empty_cache()
+    if run_wide:
+        # the headline model's offset predictors are scaled to ~1 px (trained-DCN-like); the deformable gather is more
+        # cache-local there than on wide offsets. Same workload, same kernels, model with 2 px offset standard deviation (SURVEY 8d's
+        # op-level distribution): the deformable launches of one eagerly run, event-bracketed image, outside the timed region.
+        from upsnet_amd.synthetic import DEFAULT_OFFSET_PX
+        ops.PROFILE['events'] = []
+
+        def _sample_first(s_, m_):
+            ops.PROFILE['enabled'] = s_ == 0
+            m_.overlap_streams = s_ != 0
+        rw = upsnet_test(args.workload, steps=3, warmup=2, input_mode=args.input, in_flight=1, before_step=_sample_first, gather=False,
+                         model_kw=dict(offset_px=2.0))
+        ops.PROFILE['enabled'] = False
+        torch.cuda.synchronize()
+        kind = 'dcn_fused_bf16' if args.conv_precision == 'bf16' else 'dcn_fused'
+        n_w2, t_w2, f_w2, b_w2 = agg(kind)
+        if n_w2 and t_w2 > 0:
+            peak = PEAK_BF16_MFMA_TFLOPS if kind.endswith('bf16') else PEAK_FP32_MFMA_TFLOPS
+            wide = {'offset_px_std': 2.0, 'headline_offset_px_std': DEFAULT_OFFSET_PX, 'launches_timed': n_w2,
+                    'avg_launch_ms': round(1000.0 * t_w2 / n_w2, 4), 'achieved': round(f_w2 / t_w2 / 1e12, 3),
+                    'frac': round(f_w2 / t_w2 / 1e12 / peak, 4), 'hbm_equiv_GBs': round(b_w2 / t_w2 / 1e9, 1),
+                    'n_inst': int(rw['last_out']['panoptic_cls_inds'].numel())}
+            roofline['deformable_wide_offsets'] = wide
+        rw['model']._graphs.clear()
+        del rw
+        gc.collect()
+        torch.cuda.empty_cache()
+    if run_c2:
         hipconv.PRECISION = 'bf16'
         try:
-            r2 = upsnet_test(args.workload, steps=30, warmup=6, input_mode=args.input, post=args.post, in_flight=args.in_flight)
+            r2 = upsnet_test(args.workload, steps=60, warmup=6, input_mode=args.input, post=args.post, in_flight=args.in_flight)
             torch.cuda.synchronize()
             net2 = sorted(r2['net_times'])
             configs2 = {'what': 'BASELINE.json configs[2]: same workload in the bf16 mode -- dense convolutions, stem, transposed convolution and '
                                 'fc6 with bf16 products and fp32 accumulation, bf16 activations in the backbone and the mask head (identity '
                                 'bottlenecks and stem + pool as single launches), everything else as in the headline run; '
                                 'own run: python bench.py --conv-precision bf16',
-                        'conv_precision': 'bf16', 'value': round(30 / r2['elapsed'], 4), 'unit': 'images/sec', 'steps': 30, 'warmup': 6,
-                        'ms_per_img_p50': round(1000.0 * net2[len(net2) // 2], 3),
+                        'conv_precision': 'bf16', 'value': round(60 / r2['elapsed'], 4), 'unit': 'images/sec', 'steps': 60, 'warmup': 6,
+                        'timed_s': round(r2['elapsed'], 3), 'ms_per_img_p50': round(1000.0 * net2[len(net2) // 2], 3),
                         'n_det': int(r2['last_out']['cls_inds'].numel()), 'n_inst': int(r2['last_out']['panoptic_cls_inds'].numel())}
             del r2
         finally:
@@ -368,6 +414,8 @@ def main():
                                                    'upsnet101dcn_mixed_1024x2048_800x1333': 'UPSNet-101-DCN mixed 1024x2048 / 800x1333 stream'}.get(args.workload, args.workload),
         'value': round(value, 4), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * res['elapsed'] / max(args.steps, 1), 3),
+        'timed_s': round(timed_s, 4), 'steps_explicit': steps_explicit,
+        'gather_s': None if not res.get('gather') else round(res['gather']['gather_s'], 5),
         'ms_per_img_p50': round(p50_ms, 3), 'ms_per_img_serial': round(serial_ms, 3), 'latency_ms_p50': round(lat_ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (3-term bf16 split of fp32 operands, fp32 accumulate; dense convs only)',
                   'bf16': 'bf16 (dense convs, stem, transposed conv, fc6: bf16 products, fp32 accumulate; bf16 activations in backbone + mask head; rest f32)'}[args.conv_precision], 'data': 'synthetic',
@@ -388,7 +436,13 @@ def main():
                               'latency_ms_p50 = launch -> outputs); the %d roofline-sampled image(s) run eagerly and serially'
                               % (args.in_flight, n_sampled),
                    'hip_graph': bool(g), 'verified_vs_eager_rerun': same,
-                   'n_det': n_det, 'n_inst': n_inst},
+                   'n_det': n_det, 'n_inst': n_inst,
+                   'synthetic_model': 'seeded (235) random weights; frozen-BN statistics calibrated on a seeded image (activations O(1-10)), BN gamma '
+                                      '0.6 / 0.2 (last BN of a bottleneck), DCN offset predictors scaled to 1 px standard deviation (since r08; r01-r07: '
+                                      'identity BN, offsets up to +-26 px -- img/s of those rounds are not comparable), cls_score gain per class count; '
+                                      'roofline.deformable_wide_offsets = the deformable kernels on the same model with 2 px offsets',
+                   'knobs': active_knobs, 'kernel_forms_sampled_image': form_hist,
+                   'gather': res.get('gather')},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'configs2': configs2,
     }
     print(json.dumps(line), flush=True)

@@ -24,6 +24,37 @@ def _worker(rank, world, port, q):
         out = {}
     empty = gather_results([] if rank == 1 else local[:1], world, dev, 6, 10)   # a rank without images must not break the collective
     assert rank != 0 or sorted(empty) == [0]
+    # many records per rank, small chunks: several chunk collectives + a ragged last one, label maps of two sizes (void padded)
+    many = [(i, torch.full((6, 10) if i % 3 else (4, 7), i, dtype=torch.uint8), i) for i in shard_indices(23, rank, world)]
+    big = gather_results(many, world, dev, 6, 10, chunk=4)
+    if rank == 0:
+        assert sorted(big) == list(range(23))
+        for i, (m, n) in big.items():
+            h, w = (6, 10) if i % 3 else (4, 7)
+            assert n == i and bool((m[:h, :w] == i).all()) and (h == 6 or (int(m[h:].min()) == 255 and int(m[:, w:].min()) == 255))
+    # the streamed form of the timed loop: every rank adds `rows` records, full chunks leave asynchronously while the loop runs
+    from upsnet_amd.upsnet_end2end_test import ResultGatherer
+    g = ResultGatherer(world, dev, 6, 10, rows=11, chunk=4)
+    for s in range(11):
+        g.add(s * world + rank, torch.full((6, 10), (s * world + rank) % 251, dtype=torch.int64), s)   # int64 label map: converted in the copy
+        assert g.sent == (s + 1) // 4 * 4          # chunk collectives are issued as soon as a chunk is full
+    streamed = g.finish()
+    assert g.collectives == 3 and g.bytes_sent == 3 * 4 * 60 and g.gather_s >= 0.0
+    if rank == 0:
+        assert sorted(streamed) == list(range(22))
+        assert all(bool((m == i % 251).all()) and n == i // world for i, (m, n) in streamed.items())
+        assert g.store.shape == (2, 12, 60)        # the result store; the collective in flight is world x chunk rows
+    else:
+        assert streamed is None and g.store is None
+    bad = ResultGatherer(world, dev, 6, 10, rows=2, chunk=4)
+    for s in range(2 if rank == 0 else 1):         # a rank that breaks the equal-count promise is reported, not silently truncated
+        bad.add(s, torch.zeros((6, 10), dtype=torch.uint8), 0)
+    try:
+        bad.finish()
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)     # max-over-ranks timing reduction used by the bench
     q.put((rank, sorted(out.keys()), [int(out[i][0][0, 0]) for i in sorted(out)], [out[i][1] for i in sorted(out)], float(t)))

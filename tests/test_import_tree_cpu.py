@@ -84,3 +84,26 @@ def test_host_box_helpers_match_their_definitions():
     assert e.dtype == np.float64 and np.allclose(e[0], [20 - 10 * 30 / 28, 40 - 20 * 30 / 28, 20 + 10 * 30 / 28, 40 + 20 * 30 / 28])
     ov = bbox_overlaps(b, b[1:])
     assert ov.shape == (2, 1) and ov[1, 0] == 1.0 and ov[0, 0] == 0.0
+
+
+def test_alias_import_leaves_the_real_module_spec_intact():
+    """importing `upsnet.X` must not rewrite `upsnet_amd.X.__spec__` (reload and relative imports rely on it)."""
+    import importlib
+    import upsnet.config.config as alias_cfg
+    import upsnet.operators.modules as alias_pkg
+    import upsnet_amd.config.config as real_cfg
+    import upsnet_amd.operators.modules as real_pkg
+    assert alias_cfg is real_cfg and alias_pkg is real_pkg
+    assert real_cfg.__spec__.name == 'upsnet_amd.config.config' and real_cfg.__spec__.origin.endswith('config.py')
+    assert real_cfg.__package__ == 'upsnet_amd.config' and real_pkg.__spec__.submodule_search_locations
+    assert real_pkg.__name__ == 'upsnet_amd.operators.modules' and list(real_pkg.__path__)
+    import lib.utils.timer as alias_timer            # (reload a module without process-wide state: the config singleton must stay ONE object)
+    import upsnet_amd.utils.timer as real_timer
+    assert alias_timer is real_timer and real_timer.__spec__.name == 'upsnet_amd.utils.timer'
+    old_cls = real_timer.Timer
+    importlib.reload(real_timer)                     # really re-executes the module (the alias loader's exec_module is a no-op)
+    assert real_timer.Timer is not old_cls
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        from upsnet_amd.config import parse_args  # noqa: F401  (a relative-import user: no ImportWarning about __package__ != __spec__.parent)

@@ -32,10 +32,20 @@ class AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.util.spec_from_loader(fullname, self, is_package=spec.submodule_search_locations is not None)
 
     def create_module(self, spec):
-        return importlib.import_module(self._real_name(spec.name))   # the same module object under the second name
+        real = importlib.import_module(self._real_name(spec.name))   # the same module object under the second name
+        # importlib is about to overwrite __spec__ / __loader__ / __package__ / __path__ of the object this returns with the ALIAS spec's
+        # values (_init_module_attrs) -- on the real module that would break importlib.reload() (exec_module below does nothing)
+        # and relative imports inside upsnet_amd (`__package__ != __spec__.parent`). Remember the real ones; exec_module puts them back.
+        self._saved = getattr(self, '_saved', {})
+        self._saved[spec.name] = {k: getattr(real, k) for k in ('__spec__', '__loader__', '__package__', '__path__', '__file__', '__cached__')
+                                  if hasattr(real, k)}
+        return real
 
     def exec_module(self, module):
-        pass
+        saved = getattr(self, '_saved', {})
+        for name in [n for n in saved if sys.modules.get(self._real_name(n)) is module]:
+            for k, v in saved.pop(name).items():
+                setattr(module, k, v)
 
 
 def install(alias, real):

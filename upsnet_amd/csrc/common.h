@@ -28,6 +28,19 @@ int ups_set_error(const char *fmt, ...);
         if (e__ != hipSuccess) return ups_set_error("%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+// Once-per-DEVICE flag for per-function attributes (hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, device)
+// pair: a process that drives several devices -- utils/data_parallel.py -- must opt in on each). `mask` is the call site's static
+// bitmask; returns true the first time the current device passes here.
+static inline bool ups_first_on_device(unsigned long long &mask)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 static inline int ups_divup(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Zero `bytes` bytes (a multiple of 4, 4-byte aligned) on `st` with an ordinary kernel launch instead of hipMemsetAsync, so that a

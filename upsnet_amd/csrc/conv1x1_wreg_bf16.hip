@@ -158,6 +158,10 @@ __global__ void __launch_bounds__(256, 2) conv1x1_wreg_bf16_kernel(const ConvPar
                 *reinterpret_cast<float4 *>(ep + (j * 32 + l32) * C1_EPP + (i * 32 + 8 * g + 4 * lhalf) * 4) =
                     make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     }
+    // the tile is written by (pixel, channel group) lanes and read back by a different lane mapping: order the LDS accesses of the
+    // wave (compiler ordering only -- a wavefront's own LDS accesses execute in order; no instruction is emitted)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const bool has_res = sg.res != nullptr, has_bias = p.bias != nullptr, res16 = (p.io & 4) != 0;
     const unsigned oelems = (unsigned)sg.M * (unsigned)p.Cout;
     const unsigned relems = p.res_up == 1 ? (unsigned)(sg.N * (sg.Ho >> 1) * (sg.Wo >> 1)) * (unsigned)p.Cout : oelems;

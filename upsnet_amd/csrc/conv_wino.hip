@@ -346,11 +346,10 @@ static int conv_wino16_launch_tm(hipStream_t st, ConvParams &p)
     p.m_tiles = tiles;
     p.n_tiles = p.ldw / TN;
     const size_t smem = 2 * 16 * 4 * TM * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_dev = 0;
+    if (ups_first_on_device(attr_dev)) {
         UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<false, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_f32_kernel<true, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
     if (p.ksplit > 1) hipLaunchKernelGGL((conv_wino16_f32_kernel<true, TM, TN>), dim3(grid * p.ksplit), dim3(8 * TM), smem, st, p);

@@ -143,6 +143,7 @@ mask_removal_kernel(const float *__restrict__ rois, const float *__restrict__ pr
             const int t = t0 + lane;
             const int idx = t < m ? s_pos[t] : -1;
             const unsigned long long bal = __ballot(idx >= 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the reads of s_pos above stay above the writes below)
             __builtin_amdgcn_wave_barrier();
             if (idx >= 0) {
                 const int pos = base + __builtin_popcountll(bal & ((1ULL << lane) - 1ULL));   // pos <= t: that slot has been read
@@ -850,11 +851,10 @@ extern "C" int upsnet_panoptic_fuse_up(void *stream, const float *fcn_score, int
     const int tiles = ((W + FUP_TW - 1) / FUP_TW) * ((H + FUP_TH - 1) / FUP_TH);
     const size_t smem = (size_t)num_seg * (FUP_TH / 4 + 2) * (FUP_TW / 4 + 2) * sizeof(float) + FUSE_MAXK * (sizeof(FuseInst) + sizeof(int) + 1) + 16;
     const long pix_stride = score_nhwc ? num_seg : 1, ch_stride = score_nhwc ? 1 : (long)score_h * score_w;
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
+    static unsigned long long attr_dev = 0;
+    if (smem > 64 * 1024 && ups_first_on_device(attr_dev)) {
         UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panoptic_fuse_up_kernel<4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     hipLaunchKernelGGL(panoptic_fuse_up_kernel<4>, dim3(tiles), dim3(256), smem, (hipStream_t)stream, fcn_score, pix_stride, ch_stride,
                        num_seg, score_h, score_w, num_stuff, mask_rois, mask_logit, cls_idx, keep_inds, num_keep, real_keep, mask_size,

@@ -387,11 +387,10 @@ extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const fl
     UPS_CHECK_LAUNCH("prop_compact_kernel");
     const int M2 = ups_next_pow2(pre_n < 64 ? 64 : pre_n);
     if ((size_t)M2 * 8 > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_dev = 0;
+        if (ups_first_on_device(attr_dev)) {
             UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&prop_sortk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               PROP_CH * 8));
-            attr_set = true;
         }
     }
     hipLaunchKernelGGL(prop_sortk_kernel, dim3(nlev), dim3(M2 < 1024 ? M2 : 1024), (size_t)M2 * 8, st, lv, sel, kbuf[1], pre_n, M2);

@@ -112,11 +112,10 @@ def calibrate_statistics(model, seed, offset_px=DEFAULT_OFFSET_PX, size=(128, 25
                 t = F.relu(F.conv2d(t, layer.conv.weight, layer.conv.bias, layer.conv.stride, layer.conv.padding, layer.conv.dilation))
 
 
-def build_model(symbol=None, seed=235, device='cuda', offset_px=DEFAULT_OFFSET_PX, cls_gain='default', pipeline='fused',
-                channels_last=True, fold_bn=True, calibrate=True, **calib_kw):
-    """Construct the configured model with seeded synthetic weights, ready for inference.
-    calibrate=False reproduces the r01-r07 synthetic model (identity BN, offset weights N(0, 0.01): activations of magnitude
-    50-140 and offsets of up to +-26 px -- kept for A/B runs of the deformable kernels on wide offsets)."""
+def build_unprepared(symbol=None, seed=235, offset_px=DEFAULT_OFFSET_PX, cls_gain='default', pipeline='fused', calibrate=True, **calib_kw):
+    """The seeded synthetic model as a CHECKPOINT would hold it: on the CPU, frozen BNs unfolded, the reference's state-dict keys
+    (resnet.py:221-299). `state_dict()` of this object is what tests save as a stand-in for a trained .pth; build_model() =
+    build_unprepared() -> .to(device) -> prepare_inference()."""
     from .models.resnet_upsnet import resnet_50_upsnet, resnet_101_upsnet
     ctor = {'resnet_50_upsnet': resnet_50_upsnet, 'resnet_101_upsnet': resnet_101_upsnet}[symbol or config.symbol]
     torch.manual_seed(seed)
@@ -135,6 +134,15 @@ def build_model(symbol=None, seed=235, device='cuda', offset_px=DEFAULT_OFFSET_P
             cls_gain = DEFAULT_CLS_GAIN.get(config.dataset.num_classes, 5.4) if calibrate else 0.3
         if cls_gain is not None:
             model.rcnn.cls_score.weight.mul_(cls_gain)
+    return model
+
+
+def build_model(symbol=None, seed=235, device='cuda', offset_px=DEFAULT_OFFSET_PX, cls_gain='default', pipeline='fused',
+                channels_last=True, fold_bn=True, calibrate=True, **calib_kw):
+    """Construct the configured model with seeded synthetic weights, ready for inference.
+    calibrate=False reproduces the r01-r07 synthetic model (identity BN, offset weights N(0, 0.01): activations of magnitude
+    50-140 and offsets of up to +-26 px -- kept for A/B runs of the deformable kernels on wide offsets)."""
+    model = build_unprepared(symbol, seed, offset_px, cls_gain, pipeline, calibrate, **calib_kw)
     model = model.to(device)
     model.prepare_inference(channels_last=channels_last, fold_bn=fold_bn)
     return model

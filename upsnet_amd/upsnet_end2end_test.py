@@ -112,45 +112,141 @@ def unpack_records(rec, H, W):
     return out
 
 
-def gather_results(local, world, device, H=None, W=None, dst=0, collective=None):
-    """The path's only collective (upsnet_end2end_test.py:224-247 leaves the outputs on their GPUs and the host collects them;
-    data_parallel.py:103-116 gathers to the first device): every rank sends its per-image records -- local = list of
-    (image_id, label_map uint8, n_inst) -- to rank `dst` ONLY. Returns a dict image_id -> (label_map [H,W], n_inst) on rank
-    `dst` and **None on every other rank** (contract since r06: callers must not expect the result on all ranks). H, W = record shape (the workload's padded size; defaults to the first local map).
-    One gather of the 8-byte record counts, then one gather of the payload (ranks with fewer records pad to the largest count:
-    with image i on rank i mod world the counts differ by at most one)."""
+GATHER_CHUNK = 8   # label maps per rank and collective: rank 0 never has more than world x GATHER_CHUNK x H x W bytes in flight
+
+
+class ResultGatherer(object):
+    """The path's only collective, bounded (upsnet_end2end_test.py:224-247 leaves the outputs on their GPUs and the host collects
+    them; data_parallel.py:103-116 gathers to the first device): every rank streams its per-image records -- (image id, uint8 label
+    map, instance count) -- to rank `dst` ONLY, GATHER_CHUNK label maps per collective.
+
+    `rows` = the number of records EVERY rank will add (the process-per-GPU loop: `steps` images per rank): add() writes the label
+    map straight into a preallocated send buffer (two of them, used in turn) and, whenever GATHER_CHUNK rows are filled, issues
+    ONE asynchronous `dist.gather` whose destination tensors are row ranges of rank dst's preallocated result store -- the
+    transfer of chunk k overlaps the forwards of chunk k+1, and the collective in flight is world x GATHER_CHUNK x H x W bytes
+    whatever `steps` is (r03: ONE gather of world x steps x 2 MB after the loop, 1.6 GB at 8 x 100). `rows=None`: the ranks may
+    hold different numbers of records (uneven shards, empty ranks); everything is sent by finish(), in the same chunks.
+    finish(): a gather of the 8-byte record counts + a broadcast of their maximum (the ranks agree on the number of chunk
+    collectives without assuming the sharding rule), the remaining chunk(s), one gather of the 16-byte headers. Returns
+    {image id: (label map [H, W] uint8, n_inst)} on rank dst and **None on every other rank**. `gather_s` = host seconds spent
+    inside the collective calls (issue + waits); `bytes_sent` = payload bytes this rank handed to collectives."""
+
+    def __init__(self, world, device, H, W, rows=None, dst=0, chunk=GATHER_CHUNK, collective=None):
+        self.world, self.H, self.W, self.dst, self.chunk, self.rows = world, int(H), int(W), dst, max(1, int(chunk)), rows
+        self.collective = (world > 1) if collective is None else collective
+        if self.collective and dist.get_backend() == 'gloo':
+            device = torch.device('cpu')
+        self.device = device
+        self.rank = dist.get_rank() if self.collective else 0
+        self.hdr, self.local = [], []       # host side: (image id, n_inst) per record; label maps not yet in a send buffer
+        self.sent, self.filled, self.cur = 0, 0, 0
+        self.gather_s, self.bytes_sent, self.collectives = 0.0, 0, 0
+        self.send = self.work = self.store = None
+        if self.collective:
+            self.send = [torch.empty((self.chunk, self.H * self.W), dtype=torch.uint8, device=device) for _ in range(2)]
+            self.work = [None, None]
+            if rows is not None and self.rank == dst:
+                self._alloc_store(rows)
+
+    def _alloc_store(self, rows):
+        padded = (rows + self.chunk - 1) // self.chunk * self.chunk
+        self.store = torch.empty((self.world, max(padded, self.chunk), self.H * self.W), dtype=torch.uint8, device=self.device)
+
+    def _write(self, row, lab):
+        h, w = lab.shape
+        assert h <= self.H and w <= self.W
+        view = row.view(self.H, self.W)
+        if (h, w) != (self.H, self.W):
+            view.fill_(255)                  # outside a smaller label map: void, never class 0
+        view[:h, :w].copy_(lab)              # (int64 -> uint8 conversion, if any, happens in this one copy)
+
+    def add(self, image_id, lab, n_inst):
+        self.hdr.append((int(image_id), int(n_inst)))
+        if self.collective and self.rows is not None:
+            self._write(self.send[self.cur][self.filled], lab)
+            self.filled += 1
+            if self.filled == self.chunk:
+                self._flush()
+        else:   # (a private uint8 copy: the caller's tensor may be a view into a graph instance's output buffer)
+            self.local.append(lab.to(torch.uint8) if lab.dtype != torch.uint8 else lab.clone())
+
+    def _flush(self):
+        """One collective: this rank's current send buffer -> rows [sent, sent + chunk) of every rank's block in dst's store."""
+        t0 = time.perf_counter()
+        buf = self.send[self.cur]
+        recv = [self.store[r, self.sent:self.sent + self.chunk] for r in range(self.world)] if self.rank == self.dst else None
+        self.work[self.cur] = dist.gather(buf, recv, dst=self.dst, async_op=True)
+        self.sent += self.chunk
+        self.bytes_sent += buf.numel()
+        self.collectives += 1
+        self.cur ^= 1
+        self.filled = 0
+        if self.work[self.cur] is not None:   # the buffer about to be refilled: its collective (two chunks ago) must have read it
+            self.work[self.cur].wait()
+            self.work[self.cur] = None
+        self.gather_s += time.perf_counter() - t0
+
+    def finish(self):
+        if not self.collective:
+            rec = pack_records([(i, lab if lab.dtype == torch.uint8 else lab.to(torch.uint8), n) for (i, n), lab in zip(self.hdr, self.local)],
+                               self.H, self.W, self.device)
+            return unpack_records(rec, self.H, self.W)
+        t0 = time.perf_counter()
+        dev, rank, dst, world = self.device, self.rank, self.dst, self.world
+        count = torch.tensor([len(self.hdr)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(count) for _ in range(world)] if rank == dst else None
+        dist.gather(count, counts, dst=dst)
+        # every rank needs the padded row count; it follows from the sharding rule without another collective only if the caller
+        # sharded by i mod world -- do not assume it: broadcast the maximum (8 bytes)
+        mm = torch.tensor([max(int(c) for c in counts), min(int(c) for c in counts)] if rank == dst else [0, 0], dtype=torch.int64, device=dev)
+        dist.broadcast(mm, src=dst)
+        mx, mn = int(mm[0]), int(mm[1])
+        if self.rows is not None:
+            if mx != self.rows or mn != self.rows:   # (decided from the broadcast values: every rank raises, none is left in a collective)
+                raise RuntimeError('ResultGatherer(rows=%d): the ranks added between %d and %d records (this rank: %d)' % (self.rows, mn, mx, len(self.hdr)))
+        elif rank == dst:
+            self._alloc_store(mx)
+        while self.sent < mx:
+            if self.rows is None:    # records not streamed: fill the send buffer now (ranks with fewer records send stale rows)
+                for j, lab in enumerate(self.local[self.sent:self.sent + self.chunk]):
+                    self._write(self.send[self.cur][j], lab.to(dev))
+            self._flush()
+        for k in (0, 1):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        hdr = torch.zeros((max(mx, 1), 2), dtype=torch.int64)
+        if self.hdr:
+            hdr[:len(self.hdr)] = torch.tensor(self.hdr, dtype=torch.int64)
+        hdr = hdr.to(dev)
+        hdrs = [torch.zeros_like(hdr) for _ in range(world)] if rank == dst else None
+        dist.gather(hdr, hdrs, dst=dst)
+        self.gather_s += time.perf_counter() - t0
+        if rank != dst:
+            return None
+        out = {}
+        for r in range(world):
+            h = hdrs[r].cpu()
+            for j in range(int(counts[r])):
+                out[int(h[j, 0])] = (self.store[r, j].view(self.H, self.W), int(h[j, 1]))
+        return out
+
+
+def gather_results(local, world, device, H=None, W=None, dst=0, collective=None, chunk=GATHER_CHUNK):
+    """local = list of (image_id, label_map uint8, n_inst), any number per rank (also none) -> dict image_id -> (label_map [H,W],
+    n_inst) on rank `dst`, **None on every other rank** (contract since r06). H, W = record shape (the workload's padded size;
+    defaults to the first local map). The transfer is ResultGatherer's: chunks of `chunk` label maps per rank and collective.
+    (collective=True with world == 1: the N > 1 code path on a one-rank communicator -- pre-flight tests.)"""
     if H is None or W is None:
         assert local, 'gather_results: give H, W when a rank may hold no image'
         H, W = local[0][1].shape
-    if collective is None:
-        collective = world > 1      # (collective=True with world == 1: the N > 1 code path on a one-rank communicator -- pre-flight tests)
-    if not collective:
-        return unpack_records(pack_records(local, H, W, device), H, W)
-    if dist.get_backend() == 'gloo':
-        device = torch.device('cpu')
-    rank = dist.get_rank()
-    count = torch.tensor([len(local)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(count) for _ in range(world)] if rank == dst else None
-    dist.gather(count, counts, dst=dst)
-    # every rank needs the padded row count; it follows from the sharding rule without another collective only if the caller
-    # sharded by i mod world -- do not assume it: broadcast the maximum (8 bytes)
-    mx = torch.tensor([max(int(c) for c in counts)] if rank == dst else [0], dtype=torch.int64, device=device)
-    dist.broadcast(mx, src=dst)
-    mx = int(mx)
-    rec = pack_records(local, H, W, device)
-    if rec.shape[0] < mx:
-        rec = torch.cat([rec, rec.new_zeros((mx - rec.shape[0], rec.shape[1]))], 0)
-    recv = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
-    dist.gather(rec, recv, dst=dst)
-    if rank != dst:
-        return None
-    out = {}
-    for r in range(world):
-        out.update(unpack_records(recv[r][:int(counts[r])], H, W))
-    return out
+    g = ResultGatherer(world, device, H, W, rows=None, dst=dst, chunk=chunk, collective=collective)
+    for i, lab, n in local:
+        g.add(i, lab, n)
+    return g.finish()
 
 
-def preflight(workload='upsnet50_cityscapes_1024x2048', in_flight=2):
+def preflight(workload='upsnet50_cityscapes_1024x2048', in_flight=2, steps=100):
     """`bench.py --gpus N --dry-run`: everything a timed N-rank run does BEFORE its timed region, without timing anything -- device
     per rank, model build, graph capture of every input shape on every graph instance (2 per rank by default), one checked forward
     per instance, the communicator warm-up gather of the final record shape -- and a per-rank report of the device memory it took.
@@ -176,9 +272,13 @@ def preflight(workload='upsnet50_cityscapes_1024x2048', in_flight=2):
     torch.cuda.synchronize(device)
     graphs = sum(1 for slots in model._graphs.values() for ent in slots['slots'] if 'graph' in ent)
     if world > 1:
-        dummy = [(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0) for j in range(2)]
-        got = gather_results(dummy, world, device, hp, wp)
-        ok = ok and (got is None if rank != 0 else len(got) == 2 * world)
+        # the streamed gather of the timed loop (ResultGatherer, rows known): one full chunk + one partial chunk per rank
+        n_dummy = GATHER_CHUNK + 1
+        gat = ResultGatherer(world, device, hp, wp, rows=n_dummy)
+        for j in range(n_dummy):
+            gat.add(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0)
+        got = gat.finish()
+        ok = ok and (got is None if rank != 0 else len(got) == n_dummy * world)
         torch.cuda.synchronize(device)
     free, total = torch.cuda.mem_get_info(device)
     mine = torch.tensor([rank, int(ok), graphs, torch.cuda.max_memory_reserved(device) >> 20, (total - free) >> 20, total >> 20,
@@ -194,25 +294,65 @@ def preflight(workload='upsnet50_cityscapes_1024x2048', in_flight=2):
     keys = ('rank', 'graph_replay_equals_eager', 'graphs_captured', 'torch_reserved_peak_mib', 'device_used_mib', 'device_total_mib', 'host_cpus')
     per_rank = [dict(zip(keys, (int(v) for v in r.tolist()))) for r in rows]
     return dict(dry_run=True, workload=workload, ranks=world, shapes=['%dx%d' % s for s in sizes], graph_instances_per_rank=model.graph_slots,
+                # what the final-gather path will move for the requested --steps: payload per rank (label maps + 16-byte headers),
+                # and the bound on what one collective has in flight at rank 0 (independent of steps)
+                gather=dict(steps=steps, chunk_images=GATHER_CHUNK, bytes_sent_per_rank=steps * (hp * wp + _REC_HDR),
+                            collectives_per_rank=(steps + GATHER_CHUNK - 1) // GATHER_CHUNK + 3,
+                            rank0_in_flight_bytes_max=world * GATHER_CHUNK * hp * wp, rank0_result_store_bytes=world * ((steps + GATHER_CHUNK - 1) // GATHER_CHUNK * GATHER_CHUNK) * hp * wp),
                 all_ok=all(r['graph_replay_equals_eager'] == 1 and r['graphs_captured'] == len(sizes) * model.graph_slots for r in per_rank),
                 per_rank=per_rank)
 
 
+def resolve_workload(workload):
+    """name in WORKLOADS | dict(preset=..., sizes=[(H, W), ...], cls_gain=...) -> (preset dict or None, [(H, W), ...], cls_gain)."""
+    if isinstance(workload, dict):
+        return workload.get('preset'), [tuple(s) for s in workload['sizes']], workload.get('cls_gain', 'default')
+    preset, H, W, gain = WORKLOADS[workload]
+    return preset, (list(zip(H, W)) if isinstance(H, (tuple, list)) else [(H, W)]), gain
+
+
+def load_checkpoint_model(weight_path, device, symbol=None, pipeline='fused'):
+    """upsnet_end2end_test.py:162,189-197: `eval(config.symbol)()` -> `load_state_dict(torch.load(weight_path), resume=True)`
+    (resnet.py:221-299: DataParallel 'module.' prefix stripped, BN keys as saved) -> device -> prepare_inference() (frozen BN
+    folded, channels-last, packed weights on first use). A path that does not exist raises FileNotFoundError -- it is never
+    replaced by synthetic weights."""
+    from . import models
+    if not weight_path or not os.path.isfile(weight_path):
+        raise FileNotFoundError('--weight_path: no such file: %r' % (weight_path,))
+    ctor = getattr(models, symbol or config.symbol, None)
+    if ctor is None:
+        raise ValueError('config.symbol %r names no model constructor of upsnet.models' % (symbol or config.symbol,))
+    with torch.device('cpu'):
+        model = ctor(pipeline=pipeline)
+    state = torch.load(weight_path, map_location='cpu')
+    if isinstance(state, dict) and 'state_dict' in state and not any(torch.is_tensor(v) for v in state.values()):
+        state = state['state_dict']
+    with torch.no_grad():
+        model.load_state_dict(state, resume=True)
+    model = model.to(device)
+    model.prepare_inference()
+    return model
+
+
 def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, seed=0, pipeline='fused', gather=True,
-                on_step=None, on_warmup_done=None, input_mode='f32', post=False, in_flight=2, before_step=None):
+                on_step=None, on_warmup_done=None, input_mode='f32', post=False, in_flight=2, before_step=None, model=None, model_kw=None):
     """Run `steps` timed images per rank (after `warmup` untimed ones). Returns a dict with the whole-job
     wall time (max over ranks, barrier + sync bracketed), per-image net_time samples and the gathered results.
+    workload: a name in WORKLOADS, or dict(preset=None | config dict, sizes=[(H, W), ...]). model: a prepared model (from a
+    checkpoint, load_checkpoint_model) -- then the global config is left as the caller set it and no synthetic weights are built;
+    model_kw: extra arguments of synthetic.build_model (e.g. offset_px).
     input_mode 'f32': the fp32 blob is resident in HBM (the benchmark workload); 'u8': the uint8 image is resident and the
     input kernel (dataset/blob.py) runs inside every step. post: get_unified_pan_result (dataset/base_dataset.py) runs inside
     every step too (the reference does it after the loop, on the host). in_flight: images launched per rank before the oldest
     one is read back (1 = strictly one after the other, like the reference's loop; 2 = the next launch overlaps the read-back)."""
     rank, world, device = init_distributed()
-    preset, H, W, gain = WORKLOADS[workload]
-    sizes = list(zip(H, W)) if isinstance(H, (tuple, list)) else [(H, W)]
+    preset, sizes, gain = resolve_workload(workload)
     H, W = max(h for h, _ in sizes), max(w for _, w in sizes)   # (label maps are padded to the largest size for the gather)
-    update_config_dict(preset)
+    if preset is not None:
+        update_config_dict(preset)
     hp, wp = (int(np.ceil(v / 32.0) * 32) for v in (H, W))   # record shape of the final gather (inputs are padded to 32)
-    model = build_model(cls_gain=gain, device=device, pipeline=pipeline)
+    if model is None:
+        model = build_model(cls_gain=gain, device=device, pipeline=pipeline, **(model_kw or {}))
     # each rank owns its images: image id = step * world + rank, seeded by id
     my_ids = [s * world + rank for s in range(steps)]
     if input_mode == 'u8':
@@ -231,7 +371,6 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         post_fn = BaseDataset().get_unified_pan_result
 
     net_timer = Timer()
-    outs = []
     with torch.no_grad():
         # one-off preparation, like the weight packing inside build_model: the HIP graph of each input shape is captured on
         # the third forward of that shape (two eager forwards first: packed weights, kernel attributes, library handles)
@@ -241,19 +380,25 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
                     model(get(j))
         for w in range(warmup):
             model(get(w))
-        torch.cuda.synchronize(device)
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
         if world > 1 and gather:
-            # warm the communicator with a gather of the final shape (RCCL sets up its channels / buffers on first use of a
-            # collective at a given size; that one-off cost belongs to start-up, not to the timed loop)
-            dummy = [(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0) for j in range(steps)]
-            gather_results(dummy, world, device, hp, wp)
-            del dummy
+            # warm the communicator with the collectives of the timed loop at their final shapes (RCCL sets up its channels /
+            # buffers on first use of a collective at a given size; that one-off cost belongs to start-up, not to the timed loop)
+            warm = ResultGatherer(world, device, hp, wp, rows=GATHER_CHUNK + 1)
+            for j in range(GATHER_CHUNK + 1):
+                warm.add(j * world + rank, torch.zeros((hp, wp), dtype=torch.uint8, device=device), 0)
+            warm.finish()
+            del warm
             torch.cuda.synchronize(device)
         if on_warmup_done is not None:
             on_warmup_done(model)
+        # the result store of rank 0 and the two send buffers of every rank are allocated before the timed region
+        gatherer = ResultGatherer(world, device, hp, wp, rows=steps) if gather else None
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         # `in_flight` images per rank: image i+1 is launched (one graph replay on that graph instance's own stream) before image
         # i's outputs are read back, so (a) the host work between two images -- read-back, Python, the next launch -- is off the
@@ -267,13 +412,13 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
             out = handle.result() if hasattr(handle, 'result') else handle
             if post:
                 out['pan_2ch'] = post_fn([out['fcn_outputs']], [out['panoptic_outputs']], [out['panoptic_cls_inds']])[0]
-            lab = out['panoptic_outputs'][0].to(torch.uint8)
-            if len(sizes) > 1:  # mixed stream: common shape for the gather (255 = void outside the image)
-                lab = torch.nn.functional.pad(lab, (0, wp - lab.shape[1], 0, hp - lab.shape[0]), value=255)
-            outs.append((i, lab, int(out['panoptic_cls_inds'].numel())))
+            if gatherer is not None:
+                # streamed to rank 0: the label map goes straight into the send buffer (one copy kernel incl. the int64 -> uint8
+                # conversion; 255 = void outside a smaller image of a mixed stream); every GATHER_CHUNK images one asynchronous gather
+                gatherer.add(i, out['panoptic_outputs'][0], int(out['panoptic_cls_inds'].numel()))
             if on_step is not None:
                 on_step(s, out, model)
-            if in_flight <= 1:
+            if in_flight <= 1 and device.type == 'cuda':
                 torch.cuda.synchronize(device)
             now = time.perf_counter()
             done_at.append(now)
@@ -284,6 +429,7 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         launch = model.forward_async if depth > 1 else model
         pending = []
         done_at.append(time.perf_counter())
+        out = None
         for s, i in enumerate(my_ids):
             if before_step is not None:
                 before_step(s, model)
@@ -293,28 +439,71 @@ def upsnet_test(workload='upsnet50_cityscapes_1024x2048', steps=20, warmup=10, s
         while pending:
             out = finish(*pending.pop(0))
         net_timer.samples = [(done_at[k + depth] - done_at[k]) / depth for k in range(len(done_at) - depth)]
-        results = gather_results(outs, world, device, hp, wp) if gather else None   # rank 0 only; None elsewhere
-        torch.cuda.synchronize(device)
+        results = gatherer.finish() if gather else None   # rank 0 only; None elsewhere
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gstat = None if gatherer is None else dict(gather_s=gatherer.gather_s, bytes_sent=gatherer.bytes_sent + _REC_HDR * steps,
+                                               collectives=gatherer.collectives + (3 if gatherer.collective else 0), chunk_images=gatherer.chunk,
+                                               in_flight_bytes_rank0=world * gatherer.chunk * hp * wp if gatherer.collective else 0)
     return dict(rank=rank, world=world, elapsed=float(t.item()), net_times=list(net_timer.samples), latencies=list(lat), results=results,
-                last_out=out, model=model, image=get(my_ids[-1]), H=H, W=W)
+                last_out=out, model=model, image=get(my_ids[-1]) if my_ids else None, H=H, W=W, gather=gstat)
 
 
 def main(argv=None):
-    """Entry point with the reference's command line (upsnet_end2end_test.py:155-290: --cfg yaml [--weight_path ...]) over the
-    synthetic workloads: builds the model from config.symbol / the workload preset, runs the process-per-GPU loop and logs the
-    reference's line `Batch i/N, data_time, net_time, post_time`. Launch under torch.distributed.run for N > 1 ranks."""
+    """Entry point with the reference's command line (upsnet_end2end_test.py:155-290, config/parse_args.py:19-33):
+
+        python upsnet/upsnet_end2end_test.py --cfg upsnet/experiments/<exp>.yaml --weight_path <model>.pth
+
+    `--cfg` is merged into the global config; the model is `config.symbol` (upsnet_end2end_test.py:162); `--weight_path` is loaded
+    through `load_state_dict(torch.load(path), resume=True)` and `prepare_inference()` (:189-197) -- a missing file raises
+    FileNotFoundError; without `--weight_path` the reference's default checkpoint path (output_path / <cfg name> / <image_set> /
+    <model_prefix><test_iteration>.pth, :190-193) is used and must exist too, unless `--synthetic_weights` asks for the seeded
+    synthetic weights of upsnet_amd.synthetic (the benchmark's). `--eval_only` (re-evaluation of stored results through the dataset
+    classes, :171-186) is outside the hot path and refused. Inputs are synthetic images of the configured test size
+    (config.test.scales[0] x config.test.max_size, or the sizes of --workload); datasets are out of scope. Without `--cfg` the
+    `--workload` preset supplies the config. Runs the process-per-GPU loop and logs the reference's line
+    `Batch i/N, data_time, net_time, post_time`. Launch under torch.distributed.run for N > 1 ranks."""
     import logging
     from .config.parse_args import parse_args
     args = parse_args('UPSNet inference on MI355X (synthetic inputs)', argv)
     logging.basicConfig(level=logging.INFO, format='%(asctime)-15s | %(message)s')
-    res = upsnet_test(args.workload, steps=args.steps, warmup=args.warmup, in_flight=args.in_flight)
+    if args.eval_only:
+        raise SystemExit('--eval_only re-evaluates stored results with the dataset classes (upsnet_end2end_test.py:171-186): datasets and '
+                         'evaluation are outside the inference hot path (SURVEY.md section 2) -- refused, not ignored')
+    if args.cfg:
+        # the yaml already sits in the global config (parse_args); the workload only supplies image sizes
+        if args.workload:
+            _, sizes, _ = resolve_workload(args.workload)
+        else:
+            sizes = [(int(config.test.scales[0]), int(config.test.max_size))]
+        workload = dict(preset=None, sizes=sizes)
+    else:
+        workload = args.workload or 'upsnet50_cityscapes_1024x2048'
+        update_config_dict(resolve_workload(workload)[0])
+    weight_path = args.weight_path
+    if args.cfg and not weight_path and not args.synthetic_weights:
+        # upsnet_end2end_test.py:190-193
+        weight_path = os.path.join(config.get('output_path', ''), os.path.basename(args.cfg).split('.')[0],
+                                   '_'.join(str(config.dataset.get('image_set', '')).split('+')),
+                                   '%s%s.pth' % (config.get('model_prefix', ''), config.test.get('test_iteration', '')))
+    model = None
+    if weight_path:
+        if args.synthetic_weights:
+            raise SystemExit('--weight_path and --synthetic_weights exclude each other')
+        rank, world, device = init_distributed()
+        model = load_checkpoint_model(weight_path, device)
+        logging.info('loaded %s into %s (resume=True)' % (weight_path, config.symbol))
+    else:
+        logging.warning('no checkpoint: seeded SYNTHETIC weights (upsnet_amd.synthetic, seed 235) -- throughput is meaningful, outputs are not')
+    res = upsnet_test(workload, steps=args.steps, warmup=args.warmup, in_flight=args.in_flight, model=model)
     if res['rank'] == 0:
         nt = sorted(res['net_times'])
         n_img = args.steps * res['world']
