@@ -29,6 +29,10 @@ extern "C" {
 
 /* Last error message of the calling thread ("" if none). */
 const char *upsnet_last_error(void);
+/* Name of the kernel instance the calling thread's most recent convolution launch took where the choice is made inside the library
+ * (bf16-mode convolutions: "conv3x3_wreg<8,2>", "conv1x1_wreg<4,1>", "conv3x3_halo", "conv_bf16<2>"; Winograd: "wino<0,64,128>").
+ * Test introspection (tests/test_layerwise_gpu.py asserts the forms a benchmarked configuration runs on); "" before any launch. */
+const char *upsnet_last_kernel_form(void);
 /* Library ABI version (bumped on any signature change). */
 int upsnet_abi_version(void);
 

@@ -188,7 +188,121 @@ def test_mixed_resolution_stream_r101_dcn():
         update_config_dict(CITYSCAPES_R50)
 
 
-@pytest.mark.parametrize("precision,min_agree", [("bf16x3", 0.999), ("bf16", 0.90)])
+def test_coco_r101_dcn_at_1024x2048_stagewise_parity():
+    """BASELINE.json configs[4], its Cityscapes-shaped half at the real size: UPSNet-101-DCN on a 1024x2048 image -- every custom-op
+    stage recomputed by the oracle from the recorded inputs, label map bit-identical (VERDICT r03 next #1b)."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN, CITYSCAPES_R50
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model()
+        data = make_image(1024, 2048, seed=6, device='cuda')
+        model.taps = {}
+        with torch.no_grad():
+            out = model(data)
+        res = check_taps(model.taps, enable_void=True)
+        counts = res.pop('counts')
+        assert all(res.values()), (res, counts)
+        assert counts['label_mismatch'] == 0 and counts['n_rois'] <= 300 and counts['n_det'] >= 1, counts
+        assert out['panoptic_outputs'].shape == (1, 1024, 2048)
+    finally:
+        update_config_dict(CITYSCAPES_R50)
+
+
+def test_mixed_stream_at_real_sizes_graph_replay_equals_eager():
+    """BASELINE.json configs[4] as benchmarked (`--workload upsnet101dcn_mixed_1024x2048_800x1333`): ONE UPSNet-101-DCN fed the
+    alternating 1024x2048 / 800x1333 stream through the HIP-graph path with two images in flight (forward_async, two graph instances per
+    shape, each on its own stream). Every output of every step == the eager single-stream forward of that image; the eager forward
+    itself is stage-wise identical to the oracle (check_taps) at both sizes."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, COCO_R101_DCN, CITYSCAPES_R50
+    update_config_dict(COCO_R101_DCN)
+    try:
+        from upsnet_amd.synthetic import build_model, make_image
+        model = build_model()
+        imgs = [make_image(1024, 2048, seed=7, device='cuda'), make_image(800, 1333, seed=8, device='cuda'),
+                make_image(1024, 2048, seed=9, device='cuda'), make_image(800, 1333, seed=10, device='cuda')]
+        keys = ('panoptic_outputs', 'pred_boxes', 'cls_probs', 'cls_inds', 'mask_probs', 'panoptic_cls_inds', 'fcn_outputs')
+        with torch.no_grad():
+            g, model.use_graph = model.use_graph, False
+            eager = []
+            for j, im in enumerate(imgs):
+                model.taps = {} if j < 2 else None
+                out = model(im)
+                if j < 2:
+                    res = check_taps(model.taps, enable_void=True)
+                    counts = res.pop('counts')
+                    assert all(res.values()) and counts['label_mismatch'] == 0, (j, res, counts)
+                    model.taps = None
+                eager.append({k: out[k].clone() for k in keys})
+            assert eager[0]['panoptic_outputs'].shape == (1, 1024, 2048) and eager[1]['panoptic_outputs'].shape == (1, 800, 1344)
+            model.use_graph = True
+            assert model.graph_slots >= 2
+            for _ in range(3 * model.graph_slots):       # eager, eager, capture -- per instance and shape
+                for im in imgs[:2]:
+                    model(im)
+            pending, seen = [], 0
+            for step in range(12):
+                j = step % 4
+                pending.append((j, model.forward_async(imgs[j])))
+                if len(pending) >= 2:
+                    jj, h = pending.pop(0)
+                    out = h.result()
+                    for k in keys:
+                        assert torch.equal(out[k], eager[jj][k]), (step, jj, k)
+                    seen += 1
+            for jj, h in pending:
+                out = h.result()
+                for k in keys:
+                    assert torch.equal(out[k], eager[jj][k]), (jj, k)
+            graphs = sum(1 for slots in model._graphs.values() for ent in slots['slots'] if 'graph' in ent)
+            assert graphs == 2 * model.graph_slots, graphs      # both shapes really ran as graph replays
+            model.use_graph = g
+    finally:
+        update_config_dict(CITYSCAPES_R50)
+
+
+# Agreement of the bf16 mode with the fp32 run ON THE SAME IMAGE, measured on MI355X (r10) and asserted with a small margin below the
+# measured value (a random synthetic network has no decision margin: a bf16 rounding moves near-tied logits; trained weights agree
+# far better). name: (semantic arg-max agreement, panoptic label-map agreement)
+_BF16_AGREE = {(256, 512): (0.895, 0.81), (1024, 2048): (0.885, 0.87)}   # measured 0.9152 / 0.8330 and 0.9036 / 0.8899
+
+
+def test_bf16_mode_at_1024x2048_stagewise_parity_and_agreement():
+    """BASELINE.json configs[2] at the size it is benchmarked (VERDICT r03 next #1a): the bf16-mode forward of the 1024x2048 image --
+    every custom-op stage recomputed by the oracle from the recorded inputs, bit for bit (the selection / sampling / fusion kernels do
+    not change with the convolution precision) -- and the agreement of its semantic arg-max and of its panoptic label map with the
+    fp32 run of the same image."""
+    from oracle.forward import check_taps
+    from upsnet_amd.config.config import update_config_dict, CITYSCAPES_R50
+    from upsnet_amd.models import hipconv
+    update_config_dict(CITYSCAPES_R50)
+    from upsnet_amd.synthetic import build_model, make_image
+    model = build_model()
+    data = make_image(1024, 2048, seed=1, device='cuda')
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in model(data).items()}
+        hipconv.PRECISION = 'bf16'
+        try:
+            model.taps = {}
+            out = model(data)
+            taps, model.taps = model.taps, None
+        finally:
+            hipconv.PRECISION = 'fp32'
+    res = check_taps(taps, enable_void=True)
+    counts = res.pop('counts')
+    assert all(res.values()), (res, counts)
+    assert counts['label_mismatch'] == 0 and counts['n_det'] >= 1 and counts['n_inst'] >= 5, counts
+    sem = float((out['fcn_outputs'] == ref['fcn_outputs']).float().mean())
+    pan = float((out['panoptic_outputs'] == ref['panoptic_outputs']).float().mean())
+    print('bf16 vs fp32 at 1024x2048: semantic arg-max agreement %.4f, panoptic label-map agreement %.4f, n_det %d / %d, n_inst %d / %d' %
+          (sem, pan, out['cls_inds'].numel(), ref['cls_inds'].numel(), out['panoptic_cls_inds'].numel(), ref['panoptic_cls_inds'].numel()))
+    want_sem, want_pan = _BF16_AGREE[(1024, 2048)]
+    assert sem >= want_sem and pan >= want_pan, (sem, pan)
+
+
+@pytest.mark.parametrize("precision,min_agree", [("bf16x3", 0.999), ("bf16", _BF16_AGREE[(256, 512)][0])])
 def test_bf16_matrix_core_convs_end_to_end(setup, precision, min_agree):
     """BASELINE.json configs[2] (and its fp32-equivalent 3-term split): dense convolutions on the bf16 matrix cores. Every custom-op
     stage still reproduces the oracle bit-for-bit from its recorded inputs; the label map agrees with the fp32 run to the extent
@@ -209,7 +323,10 @@ def test_bf16_matrix_core_convs_end_to_end(setup, precision, min_agree):
     counts = res.pop('counts')
     assert all(res.values()), (res, counts)
     agree = float((out['fcn_outputs'] == ref['fcn_outputs']).float().mean())
+    pan = float((out['panoptic_outputs'] == ref['panoptic_outputs']).float().mean())
+    print('%s vs fp32 at 256x512: semantic arg-max agreement %.4f, panoptic label-map agreement %.4f' % (precision, agree, pan))
     assert agree >= min_agree, agree
+    assert pan >= (0.99 if precision == 'bf16x3' else _BF16_AGREE[(256, 512)][1]), pan
 
 
 @pytest.mark.parametrize("overlap", [True, False])

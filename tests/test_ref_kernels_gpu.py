@@ -115,3 +115,34 @@ def test_reference_nms(ref, n):
     assert np.array_equal(rk, oracle.nms_sorted(sd, 0.6))                 # oracle == the reference's _nms
     assert np.array_equal(rk, U.nms_host(sd, 0.6))                        # our `_nms` drop-in == reference
     assert np.array_equal(order[rk], U.gpu_nms(cu(d), 0.6).cpu().numpy())  # device pipeline == gpu_nms(order[keep])
+
+
+@pytest.mark.parametrize("n,ph", [(1000, 7), (100, 14)])
+def test_fpn_roi_align_at_the_benchmark_shapes(ref, n, ph):
+    """VERDICT r03 next #1c: ROIAlign at the shapes the benchmark runs -- 1000 x 256 x 7 x 7 (box head) and 100 x 256 x 14 x 14 (mask
+    head) on the four 256-channel maps of a 1024x2048 image, log-uniform random ROIs (SURVEY 8d's microbenchmark input) -- all three
+    kernel variants == the oracle == the reference's own kernel (roi_align_kernel.cu:43-95,163-235, per level on the NCHW map)."""
+    from upsnet_amd import ops as U
+    from upsnet_amd._lib import lib
+    rng = np.random.default_rng(11)
+    H, W, C = 1024, 2048, 256
+    feats = [rng.standard_normal(size=(1, C, H // s, W // s), dtype=np.float32) for s in (4, 8, 16, 32)]
+    rois = gen_rois(rng, n, H, W, 16, 512)
+    rois[0] = [0, -40, -30, 20, 25]                 # partly outside
+    rois[1] = [0, W - 10, H - 12, W + 60, H + 40]
+    rois[2] = [0, 17.3, 21.9, 17.3, 21.9]           # degenerate
+    dev = [cu(f).contiguous(memory_format=torch.channels_last) for f in feats]
+    want = oops.fpn_roi_align(feats, rois, ph, ph)  # the oracle (C restatement), whole pyramid
+    lv = oops.fpn_level(rois)
+    assert len(set(lv.tolist())) == 4               # every pyramid level is hit
+    for variant in (0, 1, 2):
+        lib().upsnet_roi_tuning(variant)
+        try:
+            got = U.fpn_roi_align(dev, cu(rois), ph, ph, [1 / 4., 1 / 8., 1 / 16., 1 / 32.]).cpu().numpy()
+        finally:
+            lib().upsnet_roi_tuning(0)
+        assert got.shape == (n, C, ph, ph) and np.array_equal(got, want), variant
+    for l, s in enumerate((4, 8, 16, 32)):          # the reference kernel itself, level by level
+        idx = np.where(lv == l)[0]
+        r = _ref_roi(ref, feats[l], rois[idx], ph, 1.0 / s)
+        assert np.array_equal(r, want[idx]), l

@@ -16,6 +16,7 @@ P = c_void_p
 
 _SIGNATURES = {
     "upsnet_last_error": (ctypes.c_char_p, []),
+    "upsnet_last_kernel_form": (ctypes.c_char_p, []),
     "upsnet_abi_version": (c_int, []),
     "upsnet_zero_fill": (c_int, [P, P, c_size_t]),
     "upsnet_roi_align_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -10,6 +10,9 @@
 
 extern "C" const char *upsnet_last_error(void);
 int ups_set_error(const char *fmt, ...);
+// Kernel-form introspection for the parity tests (upsnet_last_kernel_form): the launchers whose instance choice is made on the C side
+// (bf16 convolutions, Winograd) record which instance the calling thread's last launch took. Never read on the product path.
+void ups_set_form(const char *fmt, ...);
 
 #define UPS_REQUIRE(cond, ...)                      \
     do {                                            \

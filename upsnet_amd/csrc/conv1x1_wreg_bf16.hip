@@ -270,6 +270,7 @@ int conv1x1_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi
         else hipLaunchKernelGGL((conv1x1_wreg_bf16_kernel<2, 0>), dim3(grid), dim3(256), 0, st, p, w);
     }
     UPS_CHECK_LAUNCH("conv1x1_wreg_bf16_kernel");
+    ups_set_form("conv1x1_wreg<%d,%d>", nwc, out16 ? 1 : 0);
     return 0;
 }
 

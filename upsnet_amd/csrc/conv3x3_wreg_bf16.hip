@@ -295,5 +295,6 @@ int conv3x3_wreg_bf16_launch(hipStream_t st, ConvParams &p, const void *wpack_hi
 #undef W3_GO_IO
 #undef W3_GO
     UPS_CHECK_LAUNCH("conv3x3_wreg_bf16_kernel");
+    ups_set_form("conv3x3_wreg<%d,%d>", th, (th == 2 && narrow) ? 1 : 2);
     return 0;
 }

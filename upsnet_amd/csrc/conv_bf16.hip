@@ -616,6 +616,7 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
             default: hipLaunchKernelGGL((conv3x3_bf16_halo_kernel<1, 1, 3>), dim3(g3), dim3(256), 0, (hipStream_t)stream, p, hi, lo); break;
         }
         UPS_CHECK_LAUNCH("conv3x3_bf16_halo_kernel");
+        ups_set_form("conv3x3_halo<%d>", lo ? 3 : 1);
         return 0;
     }
     int tiles = 0;
@@ -633,6 +634,7 @@ extern "C" int upsnet_conv2d_nhwc_bf16(void *stream, int nseg, const float *cons
     else switch (io & 3) { case 0: CB_GO(2, 0); break; case 1: CB_GO(2, 1); break; case 2: CB_GO(2, 2); break; default: CB_GO(2, 3); break; }
 #undef CB_GO
     UPS_CHECK_LAUNCH("conv_bf16_kernel");
+    ups_set_form("conv_bf16<%d,%d>", lo ? 3 : 1, narrow ? 1 : 2);
     return 0;
 }
 

@@ -72,7 +72,7 @@ class FCNSubNet(nn.Module):
                 self.taps.setdefault('offsets', []).append([o.detach().clone() for o in offsets])
             ys = ops.deform_conv_fused(xs, offsets, self._wpack(i, dc), dc.bias, dc.in_channels, dc.out_channels,
                                        dc.kernel_size, dc.stride, dc.padding, dc.dilation, relu=True)
-            hipconv._trace('dcn', module=dc, xs=xs, offsets=offsets, outs=ys, relu=True, form='dcn_fused multi')
+            hipconv._trace('dcn', module=dc, xs=xs, offsets=offsets, outs=ys, relu=True, form='dcn_fused multi' + (' bf16' if ops.dcn_precision() == 'bf16' else ''))
             xs = ys
         return xs
 

@@ -164,6 +164,11 @@ def _use_bf16(m, xs, always=False):
     return wgs * -(-m.out_channels // 128) >= (BF16_MIN_WG_WREG if small_ok else BF16_MIN_WG)
 
 
+def _bf16_form():
+    """Trace label of a bf16-mode launch: the precision + the kernel instance the library picked (only looked up while tracing)."""
+    return PRECISION if TRACE is None else '%s %s' % (PRECISION, ops.last_kernel_form())
+
+
 def _bf16_plan(m):
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version, PRECISION)
@@ -308,7 +313,7 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
             od = out_dtype if (out_dtype == torch.bfloat16 and lo is None) else torch.float32
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual],
-                                              residual_up=residual_up, out_dtype=od)[0], PRECISION
+                                              residual_up=residual_up, out_dtype=od)[0], _bf16_form()
         if winograd and not residual_up and _use_winograd(m, [x], always=(winograd == 'always')):
             wp, ldw = _winograd_plan(m)
             ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])
@@ -339,7 +344,7 @@ def conv_multi(m, xs, relu=False):
     if len(xs) <= 5 and all(supported(m, x) for x in xs):
         if _use_bf16(m, xs):
             hi, lo, ldw = _bf16_plan(m)
-            ys, form = ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu), PRECISION
+            ys, form = ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu), _bf16_form()
         elif _use_winograd(m, xs):
             wp, ldw = _winograd_plan(m)
             ys, form = ops.conv2d_winograd_multi(xs, wp, ldw, m.bias, m.out_channels, relu=relu), 'winograd tm%d multi' % _wino_tm(m, xs)

@@ -78,7 +78,8 @@ class _Block(nn.Module):
         if self.deformable:
             off = hipconv.conv(self.conv2_offset, y)
             y, y_in = torch.relu_(self.conv2(y, off)), y
-            hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, form='dcn_fused')
+            hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, 
+                           form='dcn_fused' + (' bf16' if hipconv.ops.dcn_precision() == 'bf16' else ''))
         else:
             y = hipconv.conv(self.conv2, y, relu=True, out_dtype=ad)
         shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x, out_dtype=ad)

@@ -17,6 +17,12 @@ from ._lib import check, f32c, float_array, int_array, lib, nhwc, ptr, ptr_array
 PROFILE = {'enabled': False, 'events': []}
 
 
+def last_kernel_form():
+    """Test introspection (include/upsnet_hip.h: upsnet_last_kernel_form): the kernel instance this thread's last library-dispatched
+    convolution launch took."""
+    return lib().upsnet_last_kernel_form().decode()
+
+
 def _ws(nbytes, device):
     return torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
 
