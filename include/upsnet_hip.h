@@ -244,6 +244,14 @@ int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const f
                                            int ksplit, void *workspace);
 int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
 
+/* The Winograd convolution on 32-tile x 32-CHANNEL workgroups for any Cout (ldw = Cout rounded up to 32; weights packed by
+ * upsnet_conv_pack_weight_winograd_tn32): twice the workgroups of the 32 x 64 form with half the work each, bit-identical results --
+ * for the part of a launch that would otherwise run as a nearly empty last round (the tail ROIs of the mask head, rcnn.py:96-116). */
+int upsnet_conv2d_winograd_nhwc_f32_tn32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                                         float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                                         const float *wpack, int ldw, const float *bias, int Cout, int relu);
+int upsnet_conv_pack_weight_winograd_tn32(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
+
 /* Dense convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- BASELINE.json configs[2]
  * ("bf16 compute / fp32 accumulate") and its fp32-equivalent 3-term split. OPT-IN: the fp32 kernel above is the default.
  * Activations stay fp32 NHWC in HBM (same tensors as upsnet_conv2d_nhwc_f32) and are split to bf16 on the way into LDS.
@@ -322,6 +330,14 @@ int upsnet_conv_pack_weight_stem(void *stream, const float *weight, int cout, in
 int upsnet_deconv2x2_nhwc_f32(void *stream, const float *x, int batch, int height, int width, int Cin, const float *wpack,
                               int ldw, const float *bias, int Cout, int relu, float *out);
 int upsnet_deconv2x2_pack_weight(void *stream, const float *weight, int cin, int cout, int ldw, float *wpack);
+
+/* The same transposed convolution on the lean 1x1 GEMM kernel (csrc/conv1x1.hip, scatter epilogue): x [N,H,W,Cin] NHWC ->
+ * out [N,2H,2W,Cout] NHWC. wpack: upsnet_dcn_pack_weight(W', 4*Cout, Cin, 1, 1) of the [4*Cout, Cin, 1, 1] matrix W' whose rows are
+ * (dy, dx, co) = weight[ci, co, dy, dx]; bias4 = the bias repeated for the four (dy, dx), [4*Cout], or NULL. Cin % 32 == 0,
+ * Cout % 32 == 0. Same fp32 MFMA arithmetic and K order as upsnet_conv1x1_frag_nhwc_f32. Replaces the reference's
+ * nn.ConvTranspose2d(dim, dim, 2, 2, 0) + ReLU of the mask head (upsnet/models/rcnn.py:132-133). */
+int upsnet_deconv2x2_frag_nhwc_f32(void *stream, const float *x, float *out, int batch, int height, int width, int Cin,
+                                   const float *wpack, const float *bias4, int Cout, int relu);
 
 /* Development knob for A/B measurements: force_tile = 0 auto, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x128, 5: 64x64,
  * 6: 64x64 with 64-channel K slabs (pixels x output channels per workgroup). winograd_tiles = 0 auto, 32 / 64: 2x2 tiles per

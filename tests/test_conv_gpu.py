@@ -466,6 +466,10 @@ def test_conv_bf16_lateral_with_upsampled_residual(N, Cin, Cout, H, W, split):
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride,ksplit,relu,res", [
     (1, 256, 256, 64, 128, 3, 1, 2, True, False), (1, 512, 512, 32, 64, 3, 1, 4, True, False), (1, 2048, 512, 32, 64, 1, 1, 4, True, False),
     (1, 1024, 256, 17, 23, 1, 1, 3, False, True), (2, 64, 128, 9, 9, 3, 2, 2, True, True),
+    # narrow heads (ldw = 32, 128-pixel tiles, one-element reduce for Cout % 4 != 0): the offset predictors of UPSNet-101-DCN's res4 / res5
+    # at 800x1333 (r10), a ragged small map, and a 4-divisible narrow head
+    (1, 256, 18, 50, 84, 3, 1, 8, False, False), (1, 512, 18, 25, 42, 3, 1, 8, False, False), (1, 128, 18, 13, 11, 3, 1, 4, False, True),
+    (2, 64, 12, 9, 10, 1, 1, 2, True, False),
 ])
 def test_conv_splitk_vs_unsplit(N, Cin, Cout, H, W, k, stride, ksplit, relu, res):
     """Split-K instances (small maps): same result as the unsplit kernel up to fp32 summation order, 1e-4 vs fp64; bit-repeatable."""
@@ -597,3 +601,72 @@ def test_deconv2x2_bf16_vs_torch(N, Cin, Cout, H, W, relu, bias, out16):
     assert out.shape == ref.shape and out.permute(0, 2, 3, 1).is_contiguous()
     tol = 2.0 ** -8 if out16 else 1e-4
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,relu,bias", [
+    (100, 256, 256, 14, 14, True, True),       # the mask head's upsampling layer at the benchmark's 100 ROIs (BN = 128 instance)
+    (7, 256, 256, 14, 14, True, True),         # few ROIs: ragged last row tile
+    (2, 64, 32, 5, 9, False, False),           # BN = 64 instance, rows wrap inside a 32-row block, no bias
+    (1, 96, 64, 3, 3, True, True),             # fewer rows than one tile
+])
+def test_deconv2x2_frag_vs_torch(N, Cin, Cout, H, W, relu, bias):
+    """upsnet_deconv2x2_frag_nhwc_f32 (ConvTranspose2d 2x2 / stride 2 on the lean fp32 GEMM kernel with a scatter epilogue,
+    csrc/conv1x1.hip MODE 2; rcnn.py:132-133) vs torch's conv_transpose2d in float64 at rtol = atol = 1e-4, and == the general kernel's
+    result up to the summation order (both exact-product fp32 MFMA)."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, device='cuda')
+    w = torch.randn(Cin, Cout, 2, 2, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    ref = F.conv_transpose2d(x.double(), w.double(), None if b is None else b.double(), stride=2)
+    if relu:
+        ref = ref.clamp_min(0)
+    wp, b4 = ops.pack_deconv2x2_weight_frag(w, b)
+    out = ops.deconv2x2_frag(x, wp, b4, Cout, relu=relu)
+    assert out.shape == ref.shape and out.permute(0, 2, 3, 1).is_contiguous()
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    wq, ldw = ops.pack_deconv2x2_weight(w)
+    old = ops.deconv2x2(x, wq, ldw, b, Cout, relu=relu)
+    np.testing.assert_allclose(out.cpu().numpy(), old.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,relu", [(17, 256, 256, 14, 14, True), (3, 64, 96, 9, 11, False), (1, 128, 64, 32, 40, True)])
+def test_winograd_32_channel_form_is_bit_identical(N, Cin, Cout, H, W, relu):
+    """upsnet_conv2d_winograd_nhwc_f32_tn32 (32-tile x 32-channel workgroups for any Cout, own weight order) == the 32 x 64 form, bit for
+    bit, and 1e-4 vs float64; writes into a caller-provided batch slice."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin)
+    x = torch.randn(N, Cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = ref.clamp_min(0) if relu else ref
+    wp, ldw = ops.pack_winograd_weight(w)
+    wp32, ldw32 = ops.pack_winograd_weight(w, tn32=True)
+    a = ops.conv2d_winograd_multi([x], wp, ldw, b, Cout, relu=relu)[0]
+    whole = ops._nhwc_out(N + 2, Cout, H, W, x.device)
+    whole.fill_(-7.0)
+    got = ops.conv2d_winograd_multi([x], wp32, ldw32, b, Cout, relu=relu, outs=[whole[1:N + 1]], tn32=True)[0]
+    assert torch.equal(got, a) and got.data_ptr() == whole[1:].data_ptr()
+    assert bool((whole[0] == -7.0).all()) and bool((whole[N + 1] == -7.0).all())       # nothing outside the slice is touched
+    np.testing.assert_allclose(a.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_winograd_tail_split_of_a_batched_launch():
+    """hipconv: 100 ROIs of 14 x 14 on the 32 x 64 form are 616 workgroups = 1.2 rounds; the first 83 ROIs (one full round) stay on it,
+    the last 17 run on the 32-channel form -- the same bits as the unsplit launch, for every ROI."""
+    from upsnet_amd.models import hipconv
+    torch.manual_seed(3)
+    m = torch.nn.Conv2d(256, 256, 3, 1, 1).cuda()
+    x = torch.randn(100, 256, 14, 14, device='cuda').contiguous(memory_format=torch.channels_last)
+    assert hipconv._wino_tail_split(m, x) == 83 and hipconv._wino_tail_split(m, x[:64]) == 0
+    hipconv.TRACE = []
+    try:
+        with torch.no_grad():
+            y = hipconv.conv(m, x, relu=True, winograd='always')
+            form = hipconv.TRACE[-1]['form']
+            hipconv.WINO_TAIL_SPLIT = False
+            y0 = hipconv.conv(m, x, relu=True, winograd='always')
+    finally:
+        hipconv.TRACE, hipconv.WINO_TAIL_SPLIT = None, True
+    assert form == 'winograd tm32 + tail tn32' and torch.equal(y, y0)

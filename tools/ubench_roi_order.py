@@ -1,0 +1,46 @@
+"""Does the ORDER of the ROIs (= of the workgroups; workgroup b runs on XCD b % 8) matter for the FPN ROIAlign kernel on random ROIs
+(SURVEY 8d's microbenchmark input)? Same 1000 log-uniform ROIs in four orders: as generated (random), sorted by (level, y, x) cells,
+sorted and dealt so that XCD j gets the j-th contiguous eighth of the sorted list, and reversed-sorted; warm / cold as in
+tools/microbench_roialign.py. Development aid."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+from conftest import gen_rois
+from oracle import ops as oops
+from upsnet_amd import ops
+from upsnet_amd._lib import lib
+feats = [torch.randn(1, 256, 256 >> l, 512 >> l, device='cuda').contiguous(memory_format=torch.channels_last) for l in range(4)]
+flush = torch.empty(160 << 20, dtype=torch.float32, device='cuda')
+sc = [0.25, 0.125, 0.0625, 0.03125]
+for n, ps in ((1000, 7), (100, 14)):
+    base = gen_rois(np.random.default_rng(0), n).astype(np.float32)
+    lv = oops.fpn_level(base)
+    cy, cx = (base[:, 2] + base[:, 4]) * 0.5, (base[:, 1] + base[:, 3]) * 0.5
+    key = lv * 1e9 + np.floor(cy / 64) * 1e4 + cx
+    srt = np.argsort(key, kind='stable')
+    per = (n + 7) // 8
+    dealt = np.full(8 * per, -1, np.int64)
+    for k, idx in enumerate(srt):          # sorted position k -> XCD k // per, slot k % per -> workgroup (k % per) * 8 + k // per
+        dealt[(k % per) * 8 + k // per] = idx
+    dealt = dealt[dealt >= 0]
+    orders = {'random': np.arange(n), 'sorted(level,y,x)': srt, 'sorted, dealt per XCD': dealt, 'by level only': np.argsort(lv, kind='stable')}
+    alg = 4 * n * 256 * ps * ps + 20 * n + 4 * n * 256 * (2 * ps) ** 2
+    for variant in (0, 1):
+        lib().upsnet_roi_tuning(variant)
+        for name, perm in orders.items():
+            rois = torch.from_numpy(base[perm]).cuda()
+            for _ in range(3): out = ops.fpn_roi_align(feats, rois, ps, ps, sc)
+            res = []
+            for cold in (False, True):
+                ts = []
+                for _ in range(14):
+                    if cold: flush.add_(1.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); out = ops.fpn_roi_align(feats, rois, ps, ps, sc); e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1000)
+                ts = sorted(ts[2:]); res.append(ts[len(ts) // 2])
+            print("N=%4d %2dx%-2d variant %d %-24s warm %6.1f us  cold %6.1f us  (%.2f TB/s = %.1f %% of 8 TB/s cold)" %
+                  (n, ps, ps, variant, name, res[0], res[1], alg / res[1] / 1e6, alg / res[1] / 1e6 / 8 * 100), flush=True)
+lib().upsnet_roi_tuning(0)

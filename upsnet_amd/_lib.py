@@ -74,6 +74,7 @@ _SIGNATURES = {
     "upsnet_conv_pack_weight_stem": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "upsnet_deconv2x2_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P]),
     "upsnet_deconv2x2_pack_weight": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "upsnet_deconv2x2_frag_nhwc_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int]),
     "upsnet_prep_image_u8": (c_int, [P, P, c_int, c_int, P, c_double, c_int, c_int, c_int, c_int, c_int, P]),
     "upsnet_image_to_nhwc4": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_unified_pan_workspace_bytes": (c_size_t, []),
@@ -82,6 +83,8 @@ _SIGNATURES = {
     "upsnet_conv2d_winograd_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int]),
     "upsnet_conv2d_winograd_nhwc_f32_splitk": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P]),
     "upsnet_conv_pack_weight_winograd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "upsnet_conv_pack_weight_winograd_tn32": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "upsnet_conv2d_winograd_nhwc_f32_tn32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int]),
     "upsnet_conv2d_nhwc_bf16": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_bottleneck_proj_bf16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "upsnet_conv_bf16_tuning": (c_int, [c_int, c_int]),

@@ -537,9 +537,10 @@ static int conv_dispatch(hipStream_t st, ConvParams &p)
         if (p.res_up == 1) return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 1>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 1>(st, p);
         return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 2>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 2>(st, p);
     }
-    if (p.ksplit > 1) {   // split-K instances (dense, 64x64 tile): partial sums to the workspace
-        UPS_REQUIRE(DEFORM == 0 && n64, "conv: split-K needs a dense convolution with ldw %% 64 == 0");
-        return conv_launch<1, 1, 2, 2, 0, CV_BK, 3>(st, p);
+    if (p.ksplit > 1) {   // split-K instances (dense): partial sums to the workspace. 64x64 tile; 128x32 for the narrow heads (ldw = 32:
+                          // the 18-channel offset predictors of the deformable bottlenecks on small maps, r10)
+        UPS_REQUIRE(DEFORM == 0, "conv: split-K needs a dense convolution");
+        return n64 ? conv_launch<1, 1, 2, 2, 0, CV_BK, 3>(st, p) : conv_launch<1, 1, 4, 1, 0, CV_BK, 3>(st, p);
     }
     if (DEFORM == 3) return n64 ? conv_launch<1, 1, 2, 2, 3>(st, p) : conv_launch<1, 1, 4, 1, 3>(st, p);
     constexpr int D = DEFORM >= 3 ? 0 : DEFORM;  // (the stem returned above; keeps its instantiations to two tiles)
@@ -605,6 +606,22 @@ extern "C" int upsnet_deform_conv_forward_nhwc(void *stream, int nlev, const flo
     return mask ? conv_dispatch<2>((hipStream_t)stream, p) : conv_dispatch<1>((hipStream_t)stream, p);
 }
 
+// the same reduction one element per thread, for channel counts that are not a multiple of 4 (Cout = 18 offset predictors)
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce1_kernel(const float *__restrict__ partial, const int ksplit, const long m_total, const long M, const int Cout,
+                           const float *__restrict__ bias, const float *__restrict__ res, const int relu, float *__restrict__ out)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * Cout) return;
+    const int c = (int)(idx % Cout);
+    float a = partial[idx];
+    for (int z = 1; z < ksplit; ++z) a = a + partial[(long)z * m_total * Cout + idx];   // fixed order: bit-repeatable
+    if (bias) a = a + bias[c];
+    if (res) a = a + res[idx];
+    if (relu) a = fmaxf(a, 0.f);
+    out[idx] = a;
+}
+
 // split-K reduction + the fused epilogue: out = relu?(sum_z partial[z] + bias + residual), float4 along the channels
 __global__ void __launch_bounds__(256)
 conv_splitk_reduce_kernel(const float *__restrict__ partial, const int ksplit, const long m_total, const long M, const int Cout,
@@ -629,6 +646,13 @@ conv_splitk_reduce_kernel(const float *__restrict__ partial, const int ksplit, c
 int conv_splitk_reduce(hipStream_t st, const float *partial, int ksplit, long m_total, long M, int Cout, const float *bias, const float *res,
                        int relu, float *out)
 {
+    if (Cout % 4) {
+        const long n1 = M * Cout;
+        hipLaunchKernelGGL(conv_splitk_reduce1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, partial, ksplit, m_total, M, Cout, bias,
+                           res, relu, out);
+        UPS_CHECK_LAUNCH("conv_splitk_reduce1_kernel");
+        return 0;
+    }
     const long n = M * (Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, ksplit, m_total, M, Cout, bias,
                        res, relu, out);
@@ -641,7 +665,7 @@ extern "C" size_t upsnet_conv2d_splitk_workspace_bytes(int batch, int height, in
 {
     const long Ho = (height + 2 * pad - KH) / stride + 1, Wo = (width + 2 * pad - KW) / stride + 1;
     const long M = (long)batch * Ho * Wo;
-    const long m_pad = (M + 63) / 64 * 64;
+    const long m_pad = (M + 127) / 128 * 128;   // (tile-aligned for both split-K instances: 64- and 128-pixel tiles)
     return (size_t)ksplit * m_pad * Cout * sizeof(float);
 }
 
@@ -659,7 +683,6 @@ extern "C" int upsnet_conv2d_nhwc_f32_splitk(void *stream, const float *x, const
     const int nslabs = KH * KW * (Cin / CV_BK);
     UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8, "conv2d_nhwc_f32_splitk: ksplit must be 2..8 and a workspace given");
     UPS_REQUIRE(((nslabs + ksplit - 1) / ksplit) * (ksplit - 1) < nslabs, "conv2d_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, ksplit);
-    UPS_REQUIRE(Cout % 4 == 0, "conv2d_nhwc_f32_splitk: Cout must be a multiple of 4");
     p.ksplit = ksplit;
     p.partial = (float *)workspace;
     rc = conv_dispatch<0>((hipStream_t)stream, p);

@@ -26,7 +26,11 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 #define C1_BM 64
 
 // NW: waves along N (4: BN = 128, every wave owns both 32-row blocks of one column block; 2: BN = 64, waves 2 x 2).
-// RESUP: the residual lives at half resolution and is read through a nearest x2 upsampling (fpn.py:34,90-96).
+// MODE 1 (RESUP): the residual lives at half resolution and is read through a nearest x2 upsampling (fpn.py:34,90-96).
+// MODE 2: 2x2 / stride-2 transposed convolution (the mask head's upsampling layer, rcnn.py:132-133) as the GEMM [N H W, Cin] x [Cin, 4 C]
+// with columns (dy, dx, c): the epilogue scatters row (n, h, w) / column (dy, dx, c) to output pixel (2h + dy, 2w + dx), channel c. A
+// 32-column block lies inside one (dy, dx) (C % 32 == 0), so (dy, dx) is wave-uniform; the per-row part of the output offset is
+// tabulated once per workgroup in LDS (one division chain per row instead of one per accumulator element).
 // A K step (32 channels, one barrier) is 4 sub-steps of 8 channels (one A fragment, one B fragment, 4 NR MFMAs each). The
 // activations of step t+2 are fetched in sub-step 2 of step t and stashed in sub-step 1 of step t+1. Every load in the loop is
 // unconditional (steps beyond the end read through an out-of-range offset = 0, no memory access) and the prologue issues its loads
@@ -34,9 +38,11 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 // it fell back to vmcnt(3) everywhere, which -- vmcnt retires in order -- made every B wait also a wait for the activations
 // fetched two sub-steps earlier (5-15 % per layer). (Measured and rejected: two slabs per step with a B ring of 8, i.e. 7
 // sub-steps of latency cover and half the barriers: 2-10 % slower on every layer -- latency is not what bounds the loop.)
-template <int NW, bool RESUP>
+template <int NW, int MODE, int VAR = 0>
 __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvParams p)
 {
+    constexpr bool RESUP = MODE == 1;
+    constexpr bool ALT = VAR == 1 && NW == 2;    // experiment: the one-block wave alternates between two accumulators (summed at the end)
     constexpr int NR = NW == 4 ? 2 : 1;          // 32-row blocks per wave
     constexpr int NU = 4;                        // sub-steps per step = B fragments in flight
     constexpr int C1_ABUF = 8 * C1_BM;           // float4 units of one A buffer: 8 channel quarters x 64 pixels
@@ -80,6 +86,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             }
         }
         po0 = po[0]; po1 = po[1];
+        if (VAR == 2) { po0 = 16u * (unsigned)q; po1 = 16u * (unsigned)q + 4u * (unsigned)p.Cin; }   // (timing experiment: every workgroup reads pixel 0 / 1 -- cache hits)
     }
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 4096, 0x00020000);
     const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
-    const int gmax = nsl * 4 - 1;
+    const int gmax = VAR == 3 ? 3 : nsl * 4 - 1;     // (VAR 3, timing experiment: the same four B fragments over and over -- L1 hits)
 
     floatx16 acc0, acc1;
 #pragma unroll
@@ -137,12 +144,19 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             float4 n0_, n1_;
-            if (u < NU - 1) C1_FRAG(cur, u + 1, n0_, n1_)
-            if (u == 1) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
-            if (u == 2) C1_FETCH(t + 2, xa0, xa1)
-            if (u == NU - 1) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
+            if (VAR == 6) { n0_ = a0; n1_ = a1; }
+            if (u < NU - 1 && VAR != 6) C1_FRAG(cur, u + 1, n0_, n1_)
+            if (u == 1 && VAR != 5) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
+            if (u == 2 && VAR != 7) C1_FETCH(t + 2, xa0, xa1)
+            if (u == NU - 1) { if (VAR != 4) __syncthreads(); if (VAR != 6) C1_FRAG(cur ^ 1, 0, n0_, n1_) }
             const float4 bf_ = breg[u];
             __builtin_amdgcn_sched_barrier(0);
+            if (ALT) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc1, 0, 0, 0);
+            } else {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);
@@ -151,12 +165,17 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);
-            C1_BLOAD(u, g + NU + u)
+            }
+            if (VAR != 8) C1_BLOAD(u, g + NU + u)
             a0 = n0_;
             if (NR == 2) a1 = n1_;
             __builtin_amdgcn_sched_barrier(0);
         }
         g += NU;
+    }
+    if (ALT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc0[r] + acc1[r];
     }
 #undef C1_LDX
 #undef C1_FETCH
@@ -174,12 +193,51 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const bool co_ok = co < p.Cout;
     const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
     const bool has_res = sg.res != nullptr;
-    const unsigned crow = (unsigned)p.Cout * 4u;                        // bytes of one output pixel
-    const unsigned lane_off = co_ok ? (4u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
+    const unsigned crow = (unsigned)p.Cout * 4u;                        // bytes of one output pixel (MODE 2: of the four pixels of a row)
     const size_t oaddr = reinterpret_cast<size_t>(sg.out);
     const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)oaddr), ohi = __builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32));
     const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)sg.M * crow);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)ohi << 32) | olo), 0, (int)obytes, 0x00020000);
+    if constexpr (MODE == 2) {
+        // scatter epilogue. Row table: byte offset of output pixel (2h, 2w) of GEMM row p0 + t, or bit 31 beyond the map
+        __syncthreads();                                               // every fragment read of the K walk is done: the A buffers are free
+        unsigned *rowoff = reinterpret_cast<unsigned *>(smem_raw);
+        const unsigned cpix = crow >> 2;                               // bytes of one output pixel: C floats
+        if (tid < C1_BM) {
+            const long pp = p0 + tid;
+            unsigned o = 0x80000000u;
+            if (pp < sg.M) {
+                const int n = (int)(pp / HoWo);
+                const int rem = (int)(pp - (long)n * HoWo);
+                const int h = rem / sg.Wo, w = rem - h * sg.Wo;
+                o = (unsigned)((n * 2 * sg.Ho + 2 * h) * 2 * sg.Wo + 2 * w) * cpix;
+            }
+            rowoff[tid] = o;
+        }
+        __syncthreads();
+        const int cpl = p.Cout >> 2;                                   // C
+        const int dydx = (32 * cb) / cpl, cc = co - dydx * cpl;        // wave-uniform (dy, dx); this lane's channel
+        const unsigned lane_sc = co_ok ? (unsigned)((dydx >> 1) * 2 * sg.Wo + (dydx & 1)) * cpix + 4u * (unsigned)cc : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rb = 32 * (NR == 2 ? i : wm) + 4 * lhalf;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const uintx4 ro = *reinterpret_cast<const uintx4 *>(rowoff + rb + 8 * k4);   // rows rb + 8 k4 + {0..3}
+                const unsigned rr4[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * k4 + j;
+                    float v = i == 0 ? acc0[r] : acc1[r];
+                    if (p.bias != nullptr) v = v + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, (rr4[j] + lane_sc) | ((rr4[j] | lane_sc) & 0x80000000u), 0, 0);   // (bit 31 of either part: dropped)
+                }
+            }
+        }
+        return;
+    }
+    const unsigned lane_off = co_ok ? (4u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
     const size_t raddr = reinterpret_cast<size_t>(has_res ? sg.res : sg.out);
     const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)raddr), rhi = __builtin_amdgcn_readfirstlane((unsigned)(raddr >> 32));
     const int Hr = sg.Ho >> 1, Wr = sg.Wo >> 1;
@@ -234,8 +292,39 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 }
 
 // development knob: 0 auto, 64 / 128 forced BN
-static int g_c1_bn = 0;
-extern "C" void upsnet_conv1x1_tuning(int bn) { g_c1_bn = bn; }
+static int g_c1_bn = 0, g_c1_var = 0;
+extern "C" void upsnet_conv1x1_tuning(int bn) { g_c1_bn = bn % 1000; g_c1_var = bn / 1000; }
+
+// mode: 0 plain, 1 residual through a nearest x2 upsampling, 2 transposed-convolution scatter (p.Cout = 4 C columns)
+static int conv1x1_frag_launch(hipStream_t st, ConvParams &p, int mode)
+{
+    const int Cout = p.Cout;
+    p.seg[0].tile_start = 0;
+    p.m_tiles = (int)((p.seg[0].M + C1_BM - 1) / C1_BM);
+    // BN = 128 halves the A traffic per output and doubles the MFMAs per LDS fragment; BN = 64 for narrow layers and for maps whose
+    // 128-wide tiling would leave CUs idle (fewer than 2 workgroups per CU)
+    int bn = g_c1_bn;
+    if (!bn) bn = (Cout > 64 && (long)p.m_tiles * ((Cout + 127) / 128) >= 512) ? 128 : 64;
+    if (Cout <= 64) bn = 64;
+    p.n_tiles = (Cout + bn - 1) / bn;
+    const size_t smem = (size_t)2 * 8 * C1_BM * 16;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+#define C1_LAUNCH(NW, MODE) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<NW, MODE>), dim3(grid), dim3(256), smem, st, p)
+    if (bn == 128) { if (mode == 2) C1_LAUNCH(4, 2); else if (mode == 1) C1_LAUNCH(4, 1); else C1_LAUNCH(4, 0); }
+    else if (mode == 0 && g_c1_var == 1) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 1>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 2) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 2>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 3) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 3>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 4) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 4>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 5) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 5>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 6) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 6>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 7) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 7>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0 && g_c1_var == 8) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 8>), dim3(grid), dim3(256), smem, st, p);
+    else { if (mode == 2) C1_LAUNCH(2, 2); else if (mode == 1) C1_LAUNCH(2, 1); else C1_LAUNCH(2, 0); }
+#undef C1_LAUNCH
+    UPS_CHECK_LAUNCH("conv1x1_frag_f32_kernel");
+    ups_set_form("conv1x1_frag<%d,%d>", bn == 128 ? 4 : 2, mode);
+    return 0;
+}
 
 /* out = relu?(conv1x1(x, w; stride) + bias + residual). x [N,H,W,Cin] NHWC, out [N,Ho,Wo,Cout] NHWC, residual like out, or -- with
  * residual_up -- [N,Ho/2,Wo/2,Cout] read through a nearest x2 upsampling. wpack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). */
@@ -257,20 +346,24 @@ extern "C" int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const 
         UPS_REQUIRE(residual, "conv1x1_frag_nhwc_f32: residual_up without a residual");
         UPS_REQUIRE(p.seg[0].Ho % 2 == 0 && p.seg[0].Wo % 2 == 0, "conv1x1_frag_nhwc_f32: residual_up needs even output dims");
     }
-    p.seg[0].tile_start = 0;
-    p.m_tiles = (int)((p.seg[0].M + C1_BM - 1) / C1_BM);
-    // BN = 128 halves the A traffic per output and doubles the MFMAs per LDS fragment; BN = 64 for narrow layers and for maps whose
-    // 128-wide tiling would leave CUs idle (fewer than 2 workgroups per CU)
-    int bn = g_c1_bn;
-    if (!bn) bn = (Cout > 64 && (long)p.m_tiles * ((Cout + 127) / 128) >= 512) ? 128 : 64;
-    if (Cout <= 64) bn = 64;
-    p.n_tiles = (Cout + bn - 1) / bn;
-    const size_t smem = (size_t)2 * 8 * C1_BM * 16;
-    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-#define C1_LAUNCH(NW, RU) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<NW, RU>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p)
-    if (bn == 128) { if (residual_up) C1_LAUNCH(4, true); else C1_LAUNCH(4, false); }
-    else { if (residual_up) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
-#undef C1_LAUNCH
-    UPS_CHECK_LAUNCH("conv1x1_frag_f32_kernel");
-    return 0;
+    return conv1x1_frag_launch((hipStream_t)stream, p, residual_up ? 1 : 0);
+}
+
+/* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) on the same kernel (MODE 2): x [N,H,W,Cin] NHWC -> out [N,2H,2W,Cout] NHWC.
+ * wpack: upsnet_dcn_pack_weight of the [4 Cout, Cin, 1, 1] matrix whose rows are (dy, dx, co); bias4: the bias repeated for the four
+ * (dy, dx) -- [4 Cout] -- or NULL. Cout % 32 == 0, Cin % 32 == 0. Reference: the mask head's upsampling layer, upsnet/models/rcnn.py:132-133. */
+extern "C" int upsnet_deconv2x2_frag_nhwc_f32(void *stream, const float *x, float *out, int batch, int height, int width, int Cin,
+                                              const float *wpack, const float *bias4, int Cout, int relu)
+{
+    UPS_REQUIRE(Cout > 0 && Cout % 32 == 0, "deconv2x2_frag_nhwc_f32: Cout must be a multiple of 32");
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = conv_fill(p, "deconv2x2_frag_nhwc_f32", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, 4 * Cout, wpack, 4 * Cout, bias4,
+                       1, 1, 1, 0, 1, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "deconv2x2_frag_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    UPS_REQUIRE((long)p.seg[0].M * 4 * Cout < (1L << 29), "deconv2x2_frag_nhwc_f32: output exceeds 2 GiB; split the batch");
+    return conv1x1_frag_launch((hipStream_t)stream, p, 2);
 }

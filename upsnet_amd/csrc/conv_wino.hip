@@ -355,6 +355,7 @@ static int conv_wino16_launch_tm(hipStream_t st, ConvParams &p)
     if (p.ksplit > 1) hipLaunchKernelGGL((conv_wino16_f32_kernel<true, TM, TN>), dim3(grid * p.ksplit), dim3(8 * TM), smem, st, p);
     else hipLaunchKernelGGL((conv_wino16_f32_kernel<false, TM, TN>), dim3(grid), dim3(8 * TM), smem, st, p);
     UPS_CHECK_LAUNCH("conv_wino16_f32_kernel");
+    ups_set_form("wino<%d,%d,%d>", p.ksplit > 1 ? 1 : 0, TM, TN);
     return 0;
 }
 
@@ -362,9 +363,9 @@ static int conv_wino16_launch_tm(hipStream_t st, ConvParams &p)
 // p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction). The channel tile follows the packing:
 // ldw == 32 (Cout <= 32, packed in 32-channel fragment order) -> the 32x32 form; otherwise ldw % 64 == 0.
 int g_wino_tm = 0;   // 0 auto; 32 / 64 forced (upsnet_conv_tuning, A/B runs)
-static int conv_wino16_launch(hipStream_t st, ConvParams &p)
+static int conv_wino16_launch(hipStream_t st, ConvParams &p, int tn32 = 0)
 {
-    UPS_REQUIRE(p.Cin % 16 == 0 && (p.ldw == 32 || p.ldw % 64 == 0), "conv2d_winograd_nhwc_f32: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
+    UPS_REQUIRE(p.Cin % 16 == 0 && (p.ldw == 32 || p.ldw % 64 == 0 || (tn32 && p.ldw % 32 == 0)), "conv2d_winograd_nhwc_f32: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
     for (int i = 0; i < p.nseg; ++i) {
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].H * p.seg[i].W * p.Cin < (1L << 28), "conv2d_winograd_nhwc_f32: feature map %d exceeds 1 GiB; split the batch", i);
         UPS_REQUIRE((long)p.seg[i].N * p.seg[i].OH * p.seg[i].OW * p.Cout < (1L << 29), "conv2d_winograd_nhwc_f32: output %d exceeds 2 GiB; split the batch", i);
@@ -375,7 +376,10 @@ static int conv_wino16_launch(hipStream_t st, ConvParams &p)
         UPS_REQUIRE(((nslabs + p.ksplit - 1) / p.ksplit) * (p.ksplit - 1) < nslabs, "conv2d_winograd_nhwc_f32_splitk: %d K slabs cannot be split %d ways", nslabs, p.ksplit);
         p.m_total = (long)p.seg[0].N * p.seg[0].OH * p.seg[0].OW;
     }
-    if (p.ldw == 32) return conv_wino16_launch_tm<32, 32>(st, p);
+    if (p.ldw == 32 || tn32) {   // 32-channel workgroups: narrow heads, or on request (weights packed with tn = 32): every ldw % 32 == 0
+        UPS_REQUIRE(p.ldw % 32 == 0, "conv2d_winograd_nhwc_f32: the 32-channel form needs ldw %% 32 == 0");
+        return conv_wino16_launch_tm<32, 32>(st, p);
+    }
     // 64-tile workgroups (one per CU) for the big maps, where the doubled B traffic of the 32-tile form costs more than its
     // overlapped prologue / epilogue gains (FPN P2: 638 vs 733 us); 32-tile workgroups (two per CU) below 768 of the former
     // (FPN P4 78 -> 49 us, res4 conv2 73 -> 46, mask head 148 -> 116; equal at P3 / the RPN launch). hipconv._wino_tm mirrors this.
@@ -390,7 +394,7 @@ static int conv_wino16_launch(hipStream_t st, ConvParams &p)
 // weight [Cout, Cin, 3, 3] -> U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored in fragment order
 // [n-tile = co/TN][slab = c/16][xi = 4i+j][q = (c%16)/4][co%TN][c%4] (16 * Cin * ldw floats; TN = 64 and ldw = Cout rounded up to
 // 64, or TN = ldw = 32 for Cout <= 32)
-__global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
+__global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int cout, int cin, int ldw, int tn, float *__restrict__ wp)
 {
     const long total = (long)ldw * cin;
     const int nslabs = cin >> 4;
@@ -415,7 +419,6 @@ __global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int 
             u[a][2] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
             u[a][3] = t[a][2];
         }
-        const int tn = ldw == 32 ? 32 : 64;
         const long blk = ((long)(co / tn) * nslabs + (c >> 4)) * 16;
         const int q = (c & 15) >> 2, ci = c & 3, cl = co % tn;
 #pragma unroll
@@ -425,16 +428,29 @@ __global__ void conv_pack_weight_wino16_kernel(const float *__restrict__ w, int 
     }
 }
 
-extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
+static int wino_pack(void *stream, const float *weight, int cout, int cin, int ldw, int tn, float *wpack)
 {
     UPS_REQUIRE(weight && wpack && cout > 0 && cin > 0 && ldw >= cout, "conv_pack_weight_winograd: bad args");
-    UPS_REQUIRE(cin % 16 == 0 && (ldw == 32 || ldw % 64 == 0), "conv_pack_weight_winograd: Cin %% 16 must be 0 and ldw 32 or a multiple of 64");
+    UPS_REQUIRE(cin % 16 == 0 && (tn == 32 || tn == 64) && ldw % tn == 0, "conv_pack_weight_winograd: Cin %% 16 must be 0 and ldw a multiple of the channel tile");
     const long total = (long)ldw * cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(conv_pack_weight_wino16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, ldw, wpack);
+    hipLaunchKernelGGL(conv_pack_weight_wino16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, ldw, tn, wpack);
     UPS_CHECK_LAUNCH("conv_pack_weight_wino16_kernel");
     return 0;
+}
+
+extern "C" int upsnet_conv_pack_weight_winograd(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
+{
+    UPS_REQUIRE(ldw == 32 || ldw % 64 == 0, "conv_pack_weight_winograd: ldw 32 or a multiple of 64");
+    return wino_pack(stream, weight, cout, cin, ldw, ldw == 32 ? 32 : 64, wpack);
+}
+
+/* The same U = G g G^T in the fragment order of the 32-CHANNEL workgroup form for any Cout (ldw = Cout rounded up to 32): the operand
+ * of upsnet_conv2d_winograd_nhwc_f32_tn32. */
+extern "C" int upsnet_conv_pack_weight_winograd_tn32(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack)
+{
+    return wino_pack(stream, weight, cout, cin, ldw, 32, wpack);
 }
 
 // geometry of the 3x3 / stride 1 / pad 1 convolution first (conv_fill), then the GEMM rows become 2x2 output tiles
@@ -462,6 +478,20 @@ extern "C" int upsnet_conv2d_winograd_nhwc_f32(void *stream, int nseg, const flo
     int rc = wino_fill(p, "conv2d_winograd_nhwc_f32", nseg, x, residual, out, batch, height, width, Cin, Cout, wpack, ldw, bias, relu);
     if (rc) return rc;
     return conv_wino16_launch((hipStream_t)stream, p);
+}
+
+/* upsnet_conv2d_winograd_nhwc_f32 on 32-tile x 32-CHANNEL workgroups whatever Cout (wpack from upsnet_conv_pack_weight_winograd_tn32,
+ * ldw % 32 == 0): twice the workgroups of the 32 x 64 form with half the work each -- for launches whose 32 x 64 tiling ends in a
+ * nearly empty last round (the tail ROIs of the mask head, models/hipconv.py). Same arithmetic in the same order as the other forms:
+ * bit-identical results. */
+extern "C" int upsnet_conv2d_winograd_nhwc_f32_tn32(void *stream, int nseg, const float *const x[], const float *const residual[],
+                                                    float *const out[], const int batch[], const int height[], const int width[], int Cin,
+                                                    const float *wpack, int ldw, const float *bias, int Cout, int relu)
+{
+    ConvParams p;
+    int rc = wino_fill(p, "conv2d_winograd_nhwc_f32_tn32", nseg, x, residual, out, batch, height, width, Cin, Cout, wpack, ldw, bias, relu);
+    if (rc) return rc;
+    return conv_wino16_launch((hipStream_t)stream, p, 1);
 }
 
 extern "C" int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,

@@ -229,14 +229,52 @@ def block(blk, x):
     return y
 
 
-def _winograd_plan(m):
+def _winograd_plan(m, tn32=False):
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
-    ent = _plans(m).get('wino')
+    name = 'wino32' if tn32 else 'wino'
+    ent = _plans(m).get(name)
     if ent is None or ent[0] != key:
-        ent = (key,) + ops.pack_winograd_weight(w.detach())
-        _plans(m)['wino'] = ent
+        ent = (key,) + ops.pack_winograd_weight(w.detach(), tn32=tn32)
+        _plans(m)[name] = ent
     return ent[1], ent[2]
+
+
+WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '1') != '0'
+_CUS = {}
+
+
+def _wino_tail_split(m, x):
+    """A batched launch (the mask head: N ROIs of 14 x 14) on the 32-tile x 64-channel form is ceil(N tiles / 32) x Cout / 64
+    workgroups, two resident per CU. 100 ROIs = 616 workgroups = 1.2 rounds of 512: the last 104 run one per CU on 104 CUs while 152
+    CUs idle, and the layer takes as long as 1.55 full rounds (115 us, 0.57 of the MFMA peak). Returns n_main > 0 if the batch should
+    be split: the first n_main images = whole rounds on the 32 x 64 form, the remaining ones on the 32 x 32 form (twice the workgroups,
+    half the work each: at most one per CU) -- same bits from both forms, so a ROI's logits still do not depend on the batch."""
+    if not WINO_TAIL_SPLIT or x.shape[0] < 2 or m.out_channels % 64:
+        return 0
+    dev = x.device.index
+    if dev not in _CUS:
+        _CUS[dev] = torch.cuda.get_device_properties(x.device).multi_processor_count
+    cus = _CUS[dev]
+    n, tiles, nt = x.shape[0], ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2), m.out_channels // 64
+    slots = 2 * cus
+    wgs = -(-(n * tiles) // 32) * nt
+    if wgs <= slots or _wino_tm(m, [x]) != 32:
+        return 0
+    n_main = ((wgs // slots) * slots // nt) * 32 // tiles
+    tail = n - n_main
+    if n_main <= 0 or tail <= 0 or -(-(tail * tiles) // 32) * (m.out_channels // 32) > cus:
+        return 0
+    return n_main
+
+
+def _wino_split_launch(m, x, n_main, relu):
+    out = ops._nhwc_out(x.shape[0], m.out_channels, x.shape[2], x.shape[3], x.device)
+    wp, ldw = _winograd_plan(m)
+    ops.conv2d_winograd_multi([x[:n_main]], wp, ldw, m.bias, m.out_channels, relu=relu, outs=[out[:n_main]])
+    wp32, ldw32 = _winograd_plan(m, tn32=True)
+    ops.conv2d_winograd_multi([x[n_main:]], wp32, ldw32, m.bias, m.out_channels, relu=relu, outs=[out[n_main:]], tn32=True)
+    return out
 
 
 def _use_winograd(m, xs, always=False):
@@ -275,14 +313,25 @@ def _wino_ksplit(m, xs):
 
 
 def _ksplit(m, x, ldw):
-    """Split-K factor for maps with too few 64x64 tiles to fill the chip (measured, tools/bench_splitk.py: pays only below
-    ~256 workgroups with a long K walk -- res5 3x3, FPN P5)."""
-    if not SPLITK or ldw % 64 or m.out_channels % 4:
+    """Split-K factor for maps with too few tiles to fill the chip (measured, tools/bench_splitk.py: pays only below
+    ~256 workgroups with a long K walk -- res5 3x3, FPN P5). Narrow heads (ldw = 32: the 18-channel offset predictors of the
+    deformable bottlenecks, 128-pixel tiles): a 3x3 / 256 -> 18 layer on the 50 x 84 map of UPSNet-101-DCN at 800x1333 is 33
+    workgroups walking 72 slabs one after the other (66 us for 2 us of matrix work, 28 such launches per image): split up to 8 ways."""
+    if not SPLITK:
         return 1
     k, st, pd = m.kernel_size[0], m.stride[0], m.padding[0]
     pix = x.shape[0] * ((x.shape[2] + 2 * pd - k) // st + 1) * ((x.shape[3] + 2 * pd - k) // st + 1)
-    blocks = -(-pix // 64) * (ldw // 64)
     slabs = k * k * m.in_channels // 32
+    if ldw == 32:
+        blocks, ks = -(-pix // 128), 1
+        while ks < 8 and blocks * (ks + 1) <= 384 and slabs // (ks + 1) >= 6:
+            ks += 1
+        while ks > 1 and -(-slabs // ks) * (ks - 1) >= slabs:
+            ks -= 1
+        return ks
+    if ldw % 64 or m.out_channels % 4:
+        return 1
+    blocks = -(-pix // 64) * (ldw // 64)
     if blocks <= 128 and slabs >= 32:
         return 4
     if blocks <= 256 and slabs >= 128:
@@ -319,6 +368,9 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
             ks = 1 if winograd == 'always' else _wino_ksplit(m, [x])
             if ks > 1:
                 return ops.conv2d_winograd_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu, residual=residual), 'winograd splitk%d' % ks
+            n_main = _wino_tail_split(m, x) if (residual is None and x.dtype == torch.float32) else 0
+            if n_main:
+                return _wino_split_launch(m, x, n_main, relu), 'winograd tm32 + tail tn32'
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0], 'winograd tm%d' % _wino_tm(m, [x])
         if _use_conv1x1(m, x, always=pin):
@@ -418,6 +470,9 @@ def stem_pool(m, x):
     return y
 
 
+DECONV_FRAG = os.environ.get('UPSNET_DECONV_FRAG', '1') != '0'   # 0: the 2x2 transposed convolution on the general kernel (A/B runs)
+
+
 def deconv2x2(m, x, relu=False):
     """nn.ConvTranspose2d(k=2, s=2, p=0) (+ ReLU) as one MFMA GEMM with a scatter epilogue."""
     geom = (ENABLED and isinstance(m, nn.ConvTranspose2d) and x.is_cuda and tuple(m.kernel_size) == (2, 2) and
@@ -442,6 +497,16 @@ def deconv2x2(m, x, relu=False):
         return F.relu(y, inplace=True) if relu else y
     w = m.weight
     key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    if DECONV_FRAG and m.out_channels % 32 == 0:
+        # the lean 1x1 GEMM kernel with a scatter epilogue (csrc/conv1x1.hip MODE 2): A fragments as one ds_read_b128 per 8 MFMAs, B from
+        # L2 -- the general kernel (csrc/conv.hip) reads two LDS words per MFMA
+        ent = _plans(m).get('deconv_frag')
+        if ent is None or ent[0] != key:
+            ent = (key,) + ops.pack_deconv2x2_weight_frag(w.detach(), m.bias)
+            _plans(m)['deconv_frag'] = ent
+        y = ops.deconv2x2_frag(x, ent[1], ent[2], m.out_channels, relu=relu)
+        _trace('deconv', module=m, x=x, out=y, relu=relu, form='deconv2x2 frag')
+        return y
     ent = _plans(m).get('deconv')
     if ent is None or ent[0] != key:
         ent = (key,) + ops.pack_deconv2x2_weight(w.detach())
@@ -449,6 +514,18 @@ def deconv2x2(m, x, relu=False):
     y = ops.deconv2x2(x, ent[1], ent[2], m.bias, m.out_channels, relu=relu)
     _trace('deconv', module=m, x=x, out=y, relu=relu, form='deconv2x2')
     return y
+
+
+def dcn(m, x, offset, relu=False):
+    """relu?(DeformConv m(x, offset)) for the folded inference graph: the fused kernel applies the ReLU in its epilogue (the module's
+    own forward -- DeformConvFunction, the reference's signature -- has no such argument and would cost a separate elementwise launch
+    per deformable bottleneck: 30 per image of UPSNet-101-DCN). Same bits: max(v, 0) of the same v."""
+    if (ENABLED and x.is_cuda and x.shape[0] == 1 and not torch.is_grad_enabled() and
+            ops.fused_dcn_supported(m.in_channels, m.out_channels, m.deformable_groups, m.groups, m.padding, m.stride, m.dilation)):
+        return ops.deform_conv_fused([x], [offset], ops.cached_dcn_pack(m.weight), m.bias, m.in_channels, m.out_channels, m.kernel_size,
+                                     m.stride, m.padding, m.dilation, relu=relu)[0]
+    y = m(x, offset)
+    return torch.relu_(y) if relu else y
 
 
 def clear_cache(model=None):

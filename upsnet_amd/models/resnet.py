@@ -77,7 +77,7 @@ class _Block(nn.Module):
         y = hipconv.conv(self.conv1, x, relu=True, out_dtype=torch.float32 if self.deformable else ad) if y1 is None else y1
         if self.deformable:
             off = hipconv.conv(self.conv2_offset, y)
-            y, y_in = torch.relu_(self.conv2(y, off)), y
+            y, y_in = hipconv.dcn(self.conv2, y, off, relu=True), y
             hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, 
                            form='dcn_fused' + (' bf16' if hipconv.ops.dcn_precision() == 'bf16' else ''))
         else:

@@ -924,6 +924,35 @@ def deconv2x2(x, wpack, ldw, bias, cout, relu=False):
     return out
 
 
+def pack_deconv2x2_weight_frag(weight, bias):
+    """ConvTranspose2d weight [Cin,Cout,2,2] (+ bias [Cout]) -> (fragment-order pack of the [4 Cout, Cin] matrix with rows (dy, dx, co),
+    bias repeated per (dy, dx)) for deconv2x2_frag (csrc/conv1x1.hip, scatter epilogue)."""
+    require_cuda(weight)
+    Cin, Cout, kh, kw = weight.shape
+    if (kh, kw) != (2, 2) or Cin % 32 or Cout % 32:
+        raise RuntimeError("pack_deconv2x2_weight_frag: kernel 2x2, Cin % 32 == 0, Cout % 32 == 0")
+    w = weight.detach().float().permute(2, 3, 1, 0).reshape(4 * Cout, Cin, 1, 1).contiguous()
+    return pack_conv1x1_weight(w), (None if bias is None else bias.detach().float().repeat(4).contiguous())
+
+
+def deconv2x2_frag(x, wpack, bias4, cout, relu=False):
+    """ConvTranspose2d(k=2, s=2, p=0) (+bias, +ReLU) on the lean GEMM kernel; returns channels_last [N,Cout,2H,2W]."""
+    require_cuda(x, wpack)
+    x = nhwc(x.float())
+    N, C, H, W = x.shape
+    out = _nhwc_out(N, cout, 2 * H, 2 * W, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_deconv2x2_frag_nhwc_f32(stream(), ptr(x), ptr(out), N, H, W, C, ptr(wpack), ptr(bias4), int(cout), int(bool(relu))),
+          "deconv2x2_frag_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * 4 * cout * C * N * H * W, 4.0 * (C * N * H * W + 4 * cout * N * H * W + 4 * cout * C),
+                                  "deconv 2x2/2 %d->%d [%s] (gemm)" % (C, cout, (N, H, W))))
+    return out
+
+
 def pack_deconv2x2_weight_bf16(weight):
     """ConvTranspose2d weight [Cin,Cout,2,2] -> (bf16 pack, ldw) of the [4 Cout, Cin] matrix with rows (ky, kx, co) for deconv2x2_bf16."""
     require_cuda(weight)
@@ -1005,13 +1034,19 @@ def mask_roi_dedup(a_src, a_cls, a_num, b_src, b_cls, b_boxes, b_num):
 
 
 # ----------------------------------------------------------------------------- Winograd F(2x2,3x3)
-def pack_winograd_weight(weight):
-    """[Cout,Cin,3,3] -> (U = G g G^T in the kernel's fragment order, 16*Cin*ldw floats, ldw)."""
+def pack_winograd_weight(weight, tn32=False):
+    """[Cout,Cin,3,3] -> (U = G g G^T in the kernel's fragment order, 16*Cin*ldw floats, ldw). tn32: the order of the 32-channel
+    workgroup form for any Cout (conv2d_winograd_multi(..., tn32=True))."""
     require_cuda(weight)
     weight = f32c(weight)
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise RuntimeError("pack_winograd_weight: kernel must be 3x3")
+    if tn32:
+        ldw = (Cout + 31) // 32 * 32
+        wp = torch.empty((16 * Cin, ldw), dtype=torch.float32, device=weight.device)
+        check(lib().upsnet_conv_pack_weight_winograd_tn32(stream(), ptr(weight), Cout, Cin, ldw, ptr(wp)), "conv_pack_weight_winograd_tn32")
+        return wp, ldw
     ldw = 32 if Cout <= 32 else (Cout + 63) // 64 * 64   # 64 output channels per workgroup; narrow heads: the 32-channel form
     wp = torch.empty((16 * Cin, ldw), dtype=torch.float32, device=weight.device)
     check(lib().upsnet_conv_pack_weight_winograd(stream(), ptr(weight), Cout, Cin, ldw, ptr(wp)), "conv_pack_weight_winograd")
@@ -1045,19 +1080,26 @@ def conv2d_winograd_splitk(x, wpack, ldw, bias, cout, ksplit, relu=False, residu
     return out
 
 
-def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None):
+def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None, outs=None, tn32=False):
     """3x3 / stride 1 / pad 1 convolution of up to 5 maps (shared weights) by fused Winograd F(2x2,3x3); same contract as
-    conv2d_nhwc_multi."""
+    conv2d_nhwc_multi. outs: caller-provided channels_last outputs (e.g. batch slices of one tensor); tn32: the 32-channel workgroup
+    form (wpack from pack_winograd_weight(w, tn32=True))."""
     require_cuda(wpack, *xs)
     assert 1 <= len(xs) <= 5
     xs = [nhwc(x.float()) for x in xs]
     cin = xs[0].shape[1]
-    outs, ress = [], None
-    for x in xs:
+    given, outs, ress = outs, [], None
+    for i, x in enumerate(xs):
         N, C, H, W = x.shape
         if C != cin:
             raise RuntimeError("conv2d_winograd_multi: channel mismatch")
-        outs.append(_nhwc_out(N, cout, H, W, x.device))
+        if given is not None:
+            o = given[i]
+            if tuple(o.shape) != (N, cout, H, W) or o.dtype != torch.float32 or not o.permute(0, 2, 3, 1).is_contiguous():
+                raise RuntimeError("conv2d_winograd_multi: outs[%d] must be a channels_last fp32 [%d,%d,%d,%d]" % (i, N, cout, H, W))
+            outs.append(o)
+        else:
+            outs.append(_nhwc_out(N, cout, H, W, x.device))
     if residuals is not None:
         ress = [nhwc(r.float()) for r in residuals]
         for r, o in zip(ress, outs):
@@ -1066,10 +1108,11 @@ def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().upsnet_conv2d_winograd_nhwc_f32(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None,
-                                                ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
-                                                int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
-                                                ptr(None if bias is None else f32c(bias)), int(cout), int(bool(relu))),
+    fn = lib().upsnet_conv2d_winograd_nhwc_f32_tn32 if tn32 else lib().upsnet_conv2d_winograd_nhwc_f32
+    check(fn(stream(), len(xs), ptr_array(xs), ptr_array(ress) if ress is not None else None,
+             ptr_array(outs), int_array([x.shape[0] for x in xs]), int_array([x.shape[2] for x in xs]),
+             int_array([x.shape[3] for x in xs]), int(cin), ptr(wpack), int(ldw),
+             ptr(None if bias is None else f32c(bias)), int(cout), int(bool(relu))),
           "conv2d_winograd_nhwc_f32")
     if PROFILE['enabled']:
         ev1.record()
@@ -1077,8 +1120,8 @@ def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None
         # algorithmic work of the convolution (direct-form flops), as for the direct kernel
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix,
                                   4.0 * (cin * npix + cout * npix * (2 if ress is not None else 1) + cout * cin * 9),
-                                  "winograd 3x3/1 %d->%d %s%s" % (cin, cout, [tuple(x.shape[0:1] + x.shape[2:]) for x in xs],
-                                                                  " +res" if ress is not None else "")))
+                                  "winograd 3x3/1 %d->%d %s%s%s" % (cin, cout, [tuple(x.shape[0:1] + x.shape[2:]) for x in xs],
+                                                                    " +res" if ress is not None else "", " tn32" if tn32 else "")))
     return outs
 
 
