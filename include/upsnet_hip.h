@@ -357,6 +357,16 @@ int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const float *resi
                                  int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu, int residual_up);
 void upsnet_conv1x1_tuning(int bn);
 
+/* upsnet_conv1x1_frag_nhwc_f32 with the K walk of every tile split over `ksplit` (2..16) workgroups + the shared reduce / epilogue
+ * kernel (bias, residual, ReLU; fixed summation order: bit-repeatable). For maps whose tile count does not spread evenly over the CUs:
+ * a workgroup of this kernel keeps all four SIMDs of its CU at the MFMA rate, so a launch lasts (most workgroups on one CU) x (one K
+ * walk) -- 264 tiles on 256 CUs take two walks, 264 x 4 quarter walks take five quarters (models/hipconv.py: UPSNET_CONV1X1_BALANCE).
+ * workspace: upsnet_conv1x1_splitk_workspace_bytes(batch, Ho, Wo, Cout, ksplit) bytes, caller-allocated. No residual_up. */
+size_t upsnet_conv1x1_splitk_workspace_bytes(int batch, int out_height, int out_width, int Cout, int ksplit);
+int upsnet_conv1x1_frag_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
+                                        int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu, int ksplit,
+                                        void *workspace);
+
 /* Two chained 1x1 convolutions of consecutive bottlenecks in ONE launch (csrc/conv1x1_pair.hip) -- the tail of block b and the
  * head of block b+1 of Bottleneck.forward (upsnet/models/resnet.py:53-100):
  *     out1 = relu(conv1x1(x; w3) + bias3 + residual)      x [pixels, C0], residual / out1 [pixels, C1]   (NHWC, pixels = N*H*W)

@@ -670,3 +670,55 @@ def test_winograd_tail_split_of_a_batched_launch():
     finally:
         hipconv.TRACE, hipconv.WINO_TAIL_SPLIT = None, True
     assert form == 'winograd tm32 + tail tn32' and torch.equal(y, y0)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,relu,res", [
+    (1, 1024, 256, 50, 84, 4, True, False),     # UPSNet-101-DCN res4 conv1 at 800x1333: 264 tiles
+    (1, 1024, 256, 5, 21, 11, True, False),     # the tail rows of that layer alone (104 rows), split 11 ways
+    (1, 2048, 512, 25, 42, 11, True, False),    # res5 conv1: less than one round
+    (2, 256, 1024, 13, 9, 2, True, True),       # BN = 128 instance... with a residual, ragged last tile, two images
+    (1, 96, 64, 7, 5, 3, False, True),          # odd number of K steps (3), one tile
+])
+def test_conv1x1_frag_splitk(N, Cin, Cout, H, W, ks, relu, res):
+    """upsnet_conv1x1_frag_nhwc_f32_splitk (lean 1x1 kernel MODE 3 + reduce): 1e-4 vs float64, within fp32 summation order of the unsplit
+    kernel, bit-repeatable; writes through a caller-provided output view."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda')
+    r = torch.randn(N, Cout, H, W, device='cuda').contiguous(memory_format=torch.channels_last) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double()) + (r.double() if res else 0)
+    ref = ref.clamp_min(0) if relu else ref
+    wp = ops.pack_conv1x1_weight(w)
+    one = ops.conv1x1_frag(x, wp, b, Cout, 1, relu=relu, residual=r)
+    out = ops.conv1x1_frag(x, wp, b, Cout, 1, relu=relu, residual=r, ksplit=ks)
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert float((out - one).abs().max()) < 2e-5
+    assert torch.equal(out, ops.conv1x1_frag(x, wp, b, Cout, 1, relu=relu, residual=r, ksplit=ks))
+
+
+def test_conv1x1_balanced_main_plus_tail():
+    """hipconv: the 1024 -> 256 layer on the 50 x 84 map (66 x 4 = 264 tiles on 256 CUs) runs as 4096 unsplit rows + 104 split-K rows into
+    ONE output tensor; 1e-4 vs float64, and equal to the plain launch on the unsplit rows."""
+    from upsnet_amd.models import hipconv
+    torch.manual_seed(5)
+    m = torch.nn.Conv2d(1024, 256, 1).cuda()
+    x = torch.randn(1, 1024, 50, 84, device='cuda').contiguous(memory_format=torch.channels_last)
+    was, hipconv.BALANCE = hipconv.BALANCE, True       # (opt-in: UPSNET_CONV1X1_BALANCE=1)
+    rows, ks = hipconv._c1_balance(m, x)
+    assert rows == 4096 and ks > 1
+    hipconv.TRACE = []
+    try:
+        with torch.no_grad():
+            y = hipconv.conv(m, x, relu=True)
+            form = hipconv.TRACE[-1]['form']
+            hipconv.BALANCE = False
+            y0 = hipconv.conv(m, x, relu=True)
+    finally:
+        hipconv.TRACE, hipconv.BALANCE = None, was
+    assert form.startswith('conv1x1 main + tail splitk') and y.shape == y0.shape
+    ref = F.relu(F.conv2d(x.double(), m.weight.double(), m.bias.double()))
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    flat, flat0 = y.permute(0, 2, 3, 1).reshape(-1, 256), y0.permute(0, 2, 3, 1).reshape(-1, 256)
+    assert torch.equal(flat[:4096], flat0[:4096]) and float((flat[4096:] - flat0[4096:]).abs().max()) < 2e-5

@@ -38,11 +38,11 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 // it fell back to vmcnt(3) everywhere, which -- vmcnt retires in order -- made every B wait also a wait for the activations
 // fetched two sub-steps earlier (5-15 % per layer). (Measured and rejected: two slabs per step with a B ring of 8, i.e. 7
 // sub-steps of latency cover and half the barriers: 2-10 % slower on every layer -- latency is not what bounds the loop.)
-template <int NW, int MODE, int VAR = 0>
+template <int NW, int MODE>
 __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvParams p)
 {
     constexpr bool RESUP = MODE == 1;
-    constexpr bool ALT = VAR == 1 && NW == 2;    // experiment: the one-block wave alternates between two accumulators (summed at the end)
+    constexpr bool SPLITK = MODE == 3;
     constexpr int NR = NW == 4 ? 2 : 1;          // 32-row blocks per wave
     constexpr int NU = 4;                        // sub-steps per step = B fragments in flight
     constexpr int C1_ABUF = 8 * C1_BM;           // float4 units of one A buffer: 8 channel quarters x 64 pixels
@@ -52,11 +52,12 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const int lhalf = lane >> 5, l32 = lane & 31;
     const int wn = NW == 4 ? wave : (wave >> 1), wm = NW == 4 ? 0 : (wave & 1);
     // XCD-aware tile order (workgroup b runs on XCD b % 8): contiguous m-tile range per XCD, all n-tiles of an m-tile together
-    int m_t, n_t;
+    int m_t, n_t, kz = 0;
     {
         const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
-        const int bid = (int)blockIdx.x;
+        int bid = (int)blockIdx.x;
+        if (SPLITK) { const int base_grid = 8 * per * nt; kz = bid / base_grid; bid -= kz * base_grid; }
         const int qq = bid >> 3;
         n_t = qq % nt;
         const int local = qq / nt;
@@ -66,6 +67,9 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const ConvSeg sg = p.seg[0];
     const long p0 = (long)m_t * C1_BM;
     const int nsl = p.Cin >> 5;                  // K steps (32-channel slabs)
+    // MODE 3 (split-K): workgroup (tile, kz) walks steps [s_begin, s_end) and leaves raw partial sums in p.partial (launcher: never empty)
+    const int s_per = SPLITK ? (nsl + p.ksplit - 1) / p.ksplit : nsl;
+    const int s_begin = SPLITK ? kz * s_per : 0, s_end = SPLITK ? min(s_begin + s_per, nsl) : nsl;
     const long HoWo = (long)sg.Ho * sg.Wo;
 
     // ---- loader geometry: thread = (pixel prow [+32], channel quarter q); byte offset of the pixel's channel vector, bit 31 set
@@ -86,7 +90,6 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             }
         }
         po0 = po[0]; po1 = po[1];
-        if (VAR == 2) { po0 = 16u * (unsigned)q; po1 = 16u * (unsigned)q + 4u * (unsigned)p.Cin; }   // (timing experiment: every workgroup reads pixel 0 / 1 -- cache hits)
     }
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, nsl * 4096, 0x00020000);
     const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
-    const int gmax = VAR == 3 ? 3 : nsl * 4 - 1;     // (VAR 3, timing experiment: the same four B fragments over and over -- L1 hits)
+    const int gmax = s_end * 4 - 1;
 
     floatx16 acc0, acc1;
 #pragma unroll
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 #define C1_LDX(D, O) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (O), 0, 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
     // step S: channels 32 S ... of the two pixels; a step beyond the end reads nothing (offset out of range -> 0)
-#define C1_FETCH(S, D0, D1) { const unsigned c_ = (S) < nsl ? (unsigned)(S) * 128u : 0x80000000u; C1_LDX(D0, po0 + c_) C1_LDX(D1, po1 + c_) }
+#define C1_FETCH(S, D0, D1) { const unsigned c_ = (S) < s_end ? (unsigned)(S) * 128u : 0x80000000u; C1_LDX(D0, po0 + c_) C1_LDX(D1, po1 + c_) }
 #define C1_STASH(BUF, D0, D1) { As[(BUF) * C1_ABUF + st0] = D0; As[(BUF) * C1_ABUF + st1] = D1; }
 #define C1_BLOAD(SLOT, G) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)min((G), gmax) * 1024u, 0); \
         breg[SLOT] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
@@ -127,36 +130,29 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     // for the loop -- the merge of this entry state and the back edge -- are the steady-state ones, not more conservative.
     {
         float4 xp0, xp1;
-        C1_FETCH(0, xp0, xp1)
-        C1_BLOAD(0, 0)
-        C1_BLOAD(1, 1)
-        C1_FETCH(1, xa0, xa1)
-        C1_BLOAD(2, 2)
-        C1_BLOAD(3, 3)
+        C1_FETCH(s_begin, xp0, xp1)
+        C1_BLOAD(0, 4 * s_begin)
+        C1_BLOAD(1, 4 * s_begin + 1)
+        C1_FETCH(s_begin + 1, xa0, xa1)
+        C1_BLOAD(2, 4 * s_begin + 2)
+        C1_BLOAD(3, 4 * s_begin + 3)
         C1_STASH(0, xp0, xp1)
     }
     __syncthreads();
     float4 a0, a1;
     C1_FRAG(0, 0, a0, a1)
-    int g = 0;
-    for (int t = 0; t < nsl; ++t) {
-        const int cur = t & 1;
+    int g = 4 * s_begin;
+    for (int t = s_begin; t < s_end; ++t) {
+        const int cur = (t - s_begin) & 1;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             float4 n0_, n1_;
-            if (VAR == 6) { n0_ = a0; n1_ = a1; }
-            if (u < NU - 1 && VAR != 6) C1_FRAG(cur, u + 1, n0_, n1_)
-            if (u == 1 && VAR != 5) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
-            if (u == 2 && VAR != 7) C1_FETCH(t + 2, xa0, xa1)
-            if (u == NU - 1) { if (VAR != 4) __syncthreads(); if (VAR != 6) C1_FRAG(cur ^ 1, 0, n0_, n1_) }
+            if (u < NU - 1) C1_FRAG(cur, u + 1, n0_, n1_)
+            if (u == 1) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
+            if (u == 2) C1_FETCH(t + 2, xa0, xa1)
+            if (u == NU - 1) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
             const float4 bf_ = breg[u];
             __builtin_amdgcn_sched_barrier(0);
-            if (ALT) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc1, 0, 0, 0);
-            } else {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);
@@ -165,17 +161,12 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);
             if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);
-            }
-            if (VAR != 8) C1_BLOAD(u, g + NU + u)
+            C1_BLOAD(u, g + NU + u)
             a0 = n0_;
             if (NR == 2) a1 = n1_;
             __builtin_amdgcn_sched_barrier(0);
         }
         g += NU;
-    }
-    if (ALT) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc0[r] + acc1[r];
     }
 #undef C1_LDX
 #undef C1_FETCH
@@ -198,6 +189,22 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)oaddr), ohi = __builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32));
     const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)sg.M * crow);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)ohi << 32) | olo), 0, (int)obytes, 0x00020000);
+    if constexpr (MODE == 3) {
+        // split-K: raw partial sums to the workspace [ksplit][m_total = m_tiles * 64][Cout]; bias / residual / ReLU in the reduce kernel
+        const size_t paddr = reinterpret_cast<size_t>(p.partial + (long)kz * p.m_total * p.Cout);
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)paddr), phi = __builtin_amdgcn_readfirstlane((unsigned)(paddr >> 32));
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)phi << 32) | plo), 0,
+                                                                                (int)__builtin_amdgcn_readfirstlane((unsigned)p.m_total * crow), 0x00020000);
+        const unsigned lane_p = co_ok ? (4u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const unsigned row0 = (unsigned)(p0 + 32 * (NR == 2 ? i : wm)) * crow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(i == 0 ? acc0[r] : acc1[r]), prsrc, lane_p, row0 + (unsigned)((r & 3) + 8 * (r >> 2)) * crow, 0);
+        }
+        return;
+    }
     if constexpr (MODE == 2) {
         // scatter epilogue. Row table: byte offset of output pixel (2h, 2w) of GEMM row p0 + t, or bit 31 beyond the map
         __syncthreads();                                               // every fragment read of the K walk is done: the A buffers are free
@@ -292,10 +299,11 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 }
 
 // development knob: 0 auto, 64 / 128 forced BN
-static int g_c1_bn = 0, g_c1_var = 0;
-extern "C" void upsnet_conv1x1_tuning(int bn) { g_c1_bn = bn % 1000; g_c1_var = bn / 1000; }
+static int g_c1_bn = 0;
+extern "C" void upsnet_conv1x1_tuning(int bn) { g_c1_bn = bn; }
 
-// mode: 0 plain, 1 residual through a nearest x2 upsampling, 2 transposed-convolution scatter (p.Cout = 4 C columns)
+// mode: 0 plain, 1 residual through a nearest x2 upsampling, 2 transposed-convolution scatter (p.Cout = 4 C columns), 3 split-K (p.ksplit
+// workgroups per tile, raw partial sums to p.partial; the caller reduces)
 static int conv1x1_frag_launch(hipStream_t st, ConvParams &p, int mode)
 {
     const int Cout = p.Cout;
@@ -308,18 +316,11 @@ static int conv1x1_frag_launch(hipStream_t st, ConvParams &p, int mode)
     if (Cout <= 64) bn = 64;
     p.n_tiles = (Cout + bn - 1) / bn;
     const size_t smem = (size_t)2 * 8 * C1_BM * 16;
-    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
+    p.m_total = (long)p.m_tiles * C1_BM;
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * (mode == 3 ? p.ksplit : 1);
 #define C1_LAUNCH(NW, MODE) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<NW, MODE>), dim3(grid), dim3(256), smem, st, p)
-    if (bn == 128) { if (mode == 2) C1_LAUNCH(4, 2); else if (mode == 1) C1_LAUNCH(4, 1); else C1_LAUNCH(4, 0); }
-    else if (mode == 0 && g_c1_var == 1) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 1>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 2) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 2>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 3) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 3>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 4) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 4>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 5) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 5>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 6) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 6>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 7) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 7>), dim3(grid), dim3(256), smem, st, p);
-    else if (mode == 0 && g_c1_var == 8) hipLaunchKernelGGL((conv1x1_frag_f32_kernel<2, 0, 8>), dim3(grid), dim3(256), smem, st, p);
-    else { if (mode == 2) C1_LAUNCH(2, 2); else if (mode == 1) C1_LAUNCH(2, 1); else C1_LAUNCH(2, 0); }
+    if (bn == 128) { if (mode == 3) C1_LAUNCH(4, 3); else if (mode == 2) C1_LAUNCH(4, 2); else if (mode == 1) C1_LAUNCH(4, 1); else C1_LAUNCH(4, 0); }
+    else { if (mode == 3) C1_LAUNCH(2, 3); else if (mode == 2) C1_LAUNCH(2, 2); else if (mode == 1) C1_LAUNCH(2, 1); else C1_LAUNCH(2, 0); }
 #undef C1_LAUNCH
     UPS_CHECK_LAUNCH("conv1x1_frag_f32_kernel");
     ups_set_form("conv1x1_frag<%d,%d>", bn == 128 ? 4 : 2, mode);
@@ -347,6 +348,40 @@ extern "C" int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const 
         UPS_REQUIRE(p.seg[0].Ho % 2 == 0 && p.seg[0].Wo % 2 == 0, "conv1x1_frag_nhwc_f32: residual_up needs even output dims");
     }
     return conv1x1_frag_launch((hipStream_t)stream, p, residual_up ? 1 : 0);
+}
+
+/* The same convolution with the K walk of every tile split over `ksplit` workgroups (MODE 3) + the shared reduce / epilogue kernel:
+ * for maps whose tile count does not fill the 256 CUs evenly (a workgroup of this kernel keeps all four SIMDs of a CU at the MFMA rate,
+ * so a launch takes max-workgroups-per-CU x one workgroup's K walk: 264 tiles = 2 walks, 264 x 4 quarter walks = 5 quarters).
+ * workspace: upsnet_conv1x1_splitk_workspace_bytes(batch, Ho, Wo, Cout, ksplit) bytes. No residual_up. */
+extern "C" size_t upsnet_conv1x1_splitk_workspace_bytes(int batch, int out_height, int out_width, int Cout, int ksplit)
+{
+    const long M = (long)batch * out_height * out_width;
+    return (size_t)ksplit * ((M + C1_BM - 1) / C1_BM * C1_BM) * Cout * sizeof(float);
+}
+
+extern "C" int upsnet_conv1x1_frag_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,
+                                                   int width, int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu,
+                                                   int ksplit, void *workspace)
+{
+    const float *xs[1] = {x}, *rs[1] = {residual};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    const int ldw = (Cout + 31) / 32 * 32;
+    int rc = conv_fill(p, "conv1x1_frag_nhwc_f32_splitk", 1, xs, residual ? rs : nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw,
+                       bias, 1, 1, stride, 0, 1, relu);
+    if (rc) return rc;
+    const int nsl = Cin / 32;
+    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 16, "conv1x1_frag_nhwc_f32_splitk: ksplit must be 2..16 and a workspace given");
+    UPS_REQUIRE(((nsl + ksplit - 1) / ksplit) * (ksplit - 1) < nsl, "conv1x1_frag_nhwc_f32_splitk: %d K steps cannot be split %d ways", nsl, ksplit);
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "conv1x1_frag_nhwc_f32_splitk: feature map exceeds 2 GiB; split the batch");
+    UPS_REQUIRE((long)(p.seg[0].M + C1_BM) * Cout < (1L << 29), "conv1x1_frag_nhwc_f32_splitk: output exceeds 2 GiB; split the batch");
+    p.ksplit = ksplit;
+    p.partial = (float *)workspace;
+    rc = conv1x1_frag_launch((hipStream_t)stream, p, 3);
+    if (rc) return rc;
+    return conv_splitk_reduce((hipStream_t)stream, p.partial, ksplit, p.m_total, p.seg[0].M, Cout, bias, residual, relu, out);
 }
 
 /* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) on the same kernel (MODE 2): x [N,H,W,Cin] NHWC -> out [N,2H,2W,Cout] NHWC.

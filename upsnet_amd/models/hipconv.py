@@ -111,6 +111,96 @@ def _use_conv1x1(m, x, always=False):
     return -(-pix // 64) * -(-m.out_channels // 64) >= CONV1X1_MIN_WG
 
 
+# A workgroup of the lean 1x1 kernel (4 waves, one per SIMD) keeps its CU's matrix pipe busy by itself (measured: a lone workgroup
+# walks K = 1024 in 16 us = the MFMA time of its 512 MFMAs per wave; two on one CU take twice as long). A launch therefore lasts
+# (most workgroups on any CU) x (one K walk): 256 workgroups take one walk, 264 take two -- the 50 x 84 map of UPSNet-101-DCN at
+# 800x1333 is 66 x 4 = 264 tiles, and its 1024 -> 256 layer ran 38 us against 22 us for 256 tiles. BALANCE: the tiles beyond the last
+# full round (or the whole layer when it is less than one round) run with their K walk split over several workgroups (+ one reduce
+# launch), so that they spread over the chip. Power-of-two maps (1024x2048) tile evenly and are left alone.
+BALANCE = os.environ.get('UPSNET_CONV1X1_BALANCE', '0') == '1'   # measured r10: 118.98 vs 118.40 img/s on UPSNet-101-DCN 800x1333 -- within noise; off by default
+_BAL_OVERHEAD_US = 6.0       # extra launch + reduce pass of a split part
+_BAL_STEP_US = 0.49          # one 32-channel K step of one 32 x 32 block: 16 MFMAs x 64 cycles at ~2.1 GHz
+_CUS = {}
+
+
+def _cus(device):
+    if device.index not in _CUS:
+        _CUS[device.index] = torch.cuda.get_device_properties(device).multi_processor_count
+    return _CUS[device.index]
+
+
+def _c1_bn(m_tiles, cout):
+    """output channels per workgroup the launcher picks (csrc/conv1x1.hip, conv1x1_frag_launch)."""
+    return 128 if (cout > 64 and m_tiles * -(-cout // 128) >= 512) else 64
+
+
+def _c1_walk_us(m_tiles, cin, cout):
+    """(workgroups, microseconds of one workgroup's K walk) of an unsplit launch over m_tiles 64-pixel tiles."""
+    bn = _c1_bn(m_tiles, cout)
+    return m_tiles * -(-cout // bn), (cin // 32) * (2 if bn == 128 else 1) * _BAL_STEP_US
+
+
+def _c1_best_split(wgs, walk_us, nsl, cus):
+    """split factor (1..16) minimising the time of `wgs` workgroups whose walk is cut `ks` ways: ceil(wgs ks / cus) / ks walks (+ overhead)."""
+    best, best_t = 1, -(-wgs // cus) * walk_us
+    for ks in range(2, min(16, nsl // 2) + 1):
+        if -(-nsl // ks) * (ks - 1) >= nsl:
+            continue
+        t = -(-wgs * ks // cus) * (walk_us / ks) + _BAL_OVERHEAD_US
+        if t < best_t - 1.0:
+            best, best_t = ks, t
+    return best, best_t
+
+
+def _c1_balance(m, x, cus=None):
+    """-> (rows of the unsplit main part, split factor of the tail part); (all rows, 1) = one plain launch."""
+    st = m.stride[0]
+    M = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
+    if not BALANCE or st != 1:
+        return M, 1
+    cus = cus or _cus(x.device)
+    cin, cout, nsl = m.in_channels, m.out_channels, m.in_channels // 32
+    m_tiles = -(-M // 64)
+    wgs, walk = _c1_walk_us(m_tiles, cin, cout)
+    plain = -(-wgs // cus) * walk
+    if wgs % cus == 0 or wgs >= 8 * cus:
+        return M, 1
+    nt = wgs // m_tiles
+    main_tiles = (wgs // cus) * cus // nt                      # m-tiles of the whole rounds
+    main_t = 0.0
+    if main_tiles > 0:                                         # (the main part is tiled on its own: its channel tile may differ)
+        mw, mwalk = _c1_walk_us(main_tiles, cin, cout)
+        main_t = -(-mw // cus) * mwalk
+    tw, twalk = _c1_walk_us(m_tiles - main_tiles, cin, cout)
+    ks, tail_t = _c1_best_split(tw, twalk, nsl, cus)
+    if ks == 1 or main_t + tail_t + (_BAL_OVERHEAD_US if main_tiles else 0.0) >= plain - 1.0:
+        return M, 1
+    return main_tiles * 64, ks
+
+
+def _conv1x1_balanced(m, x, relu, residual):
+    """conv1x1_frag of a stride-1 layer as (unsplit main rows) + (split-K tail rows), both writing into one output; rows = pixels in
+    NHWC order, so each part is a contiguous [rows, C] slab viewed as a 1 x rows image."""
+    rows_main, ks = _c1_balance(m, x)
+    wp = _conv1x1_plan(m)
+    if ks == 1:
+        return ops.conv1x1_frag(x, wp, m.bias, m.out_channels, 1, relu=relu, residual=residual), 'conv1x1'
+    x = ops.nhwc(x.float())
+    N, C, H, W = x.shape
+    M, co = N * H * W, m.out_channels
+    out = ops._nhwc_out(N, co, H, W, x.device)
+    slab = lambda t, c: t.permute(0, 2, 3, 1).reshape(M, c)
+    img = lambda rows, c: rows.view(1, 1, rows.shape[0], c).permute(0, 3, 1, 2)
+    xr, orow = slab(x, C), slab(out, co)
+    rr = None if residual is None else slab(ops.nhwc(residual.float()), co)
+    if rows_main:
+        ops.conv1x1_frag(img(xr[:rows_main], C), wp, m.bias, co, 1, relu=relu, residual=None if rr is None else img(rr[:rows_main], co),
+                         out=img(orow[:rows_main], co))
+    ops.conv1x1_frag(img(xr[rows_main:], C), wp, m.bias, co, 1, relu=relu, residual=None if rr is None else img(rr[rows_main:], co),
+                     out=img(orow[rows_main:], co), ksplit=ks)
+    return out, 'conv1x1 %s splitk%d' % ('main + tail' if rows_main else 'all', ks)
+
+
 PAIR = os.environ.get('UPSNET_CONV1X1_PAIR', '1') != '0'
 PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
 
@@ -241,7 +331,6 @@ def _winograd_plan(m, tn32=False):
 
 
 WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '1') != '0'
-_CUS = {}
 
 
 def _wino_tail_split(m, x):
@@ -252,10 +341,7 @@ def _wino_tail_split(m, x):
     half the work each: at most one per CU) -- same bits from both forms, so a ROI's logits still do not depend on the batch."""
     if not WINO_TAIL_SPLIT or x.shape[0] < 2 or m.out_channels % 64:
         return 0
-    dev = x.device.index
-    if dev not in _CUS:
-        _CUS[dev] = torch.cuda.get_device_properties(x.device).multi_processor_count
-    cus = _CUS[dev]
+    cus = _cus(x.device)
     n, tiles, nt = x.shape[0], ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2), m.out_channels // 64
     slots = 2 * cus
     wgs = -(-(n * tiles) // 32) * nt
@@ -374,6 +460,8 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0], 'winograd tm%d' % _wino_tm(m, [x])
         if _use_conv1x1(m, x, always=pin):
+            if not pin and not residual_up and m.stride[0] == 1:
+                return _conv1x1_balanced(m, x, relu, residual)
             return ops.conv1x1_frag(x, _conv1x1_plan(m), m.bias, m.out_channels, m.stride[0], relu=relu, residual=residual,
                                     residual_up=residual_up), 'conv1x1'
         wp, ldw = _plan(m)

@@ -695,14 +695,19 @@ def pack_conv1x1_weight(weight):
     return wp
 
 
-def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, residual_up=False):
+def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, residual_up=False, out=None, ksplit=1):
     """1x1 convolution (stride 1 / 2) on the lean fp32 MFMA GEMM kernel of csrc/conv1x1.hip: out = relu?(conv(x) + bias + residual),
     residual_up: the residual is at half resolution and is added through a nearest x2 upsampling (FPN top-down path).
-    x: logical NCHW (any batch), returns channels_last [N,Cout,Ho,Wo]."""
+    x: logical NCHW (any batch), returns channels_last [N,Cout,Ho,Wo]. out: caller-provided channels_last output (a view of a larger
+    tensor); ksplit > 1: the K walk of every tile split over ksplit workgroups + the reduce kernel (no residual_up)."""
     require_cuda(wpack, x)
     x = nhwc(x.float())
     N, cin, H, W = x.shape
-    out = _nhwc_out(N, cout, (H - 1) // stride + 1, (W - 1) // stride + 1, x.device)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = _nhwc_out(N, cout, Ho, Wo, x.device)
+    elif tuple(out.shape) != (N, cout, Ho, Wo) or out.dtype != torch.float32 or not out.permute(0, 2, 3, 1).is_contiguous():
+        raise RuntimeError("conv1x1_frag: out must be a channels_last fp32 [%d,%d,%d,%d]" % (N, cout, Ho, Wo))
     res = None
     if residual is not None:
         res = nhwc(residual.float())
@@ -712,15 +717,24 @@ def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, resi
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().upsnet_conv1x1_frag_nhwc_f32(stream(), ptr(x), ptr(res), ptr(out), N, H, W, int(cin), ptr(wpack),
-                                             ptr(None if bias is None else f32c(bias)), int(cout), int(stride), int(bool(relu)),
-                                             int(bool(residual_up and res is not None))), "conv1x1_frag_nhwc_f32")
+    if ksplit > 1:
+        if residual_up:
+            raise RuntimeError("conv1x1_frag: split-K has no upsampled-residual epilogue")
+        ws = _ws(lib().upsnet_conv1x1_splitk_workspace_bytes(N, Ho, Wo, int(cout), int(ksplit)), x.device)
+        check(lib().upsnet_conv1x1_frag_nhwc_f32_splitk(stream(), ptr(x), ptr(res), ptr(out), N, H, W, int(cin), ptr(wpack),
+                                                        ptr(None if bias is None else f32c(bias)), int(cout), int(stride), int(bool(relu)),
+                                                        int(ksplit), ptr(ws)), "conv1x1_frag_nhwc_f32_splitk")
+    else:
+        check(lib().upsnet_conv1x1_frag_nhwc_f32(stream(), ptr(x), ptr(res), ptr(out), N, H, W, int(cin), ptr(wpack),
+                                                 ptr(None if bias is None else f32c(bias)), int(cout), int(stride), int(bool(relu)),
+                                                 int(bool(residual_up and res is not None))), "conv1x1_frag_nhwc_f32")
     if PROFILE['enabled']:
         ev1.record()
         npix = out.shape[0] * out.shape[2] * out.shape[3]
         PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * npix,
                                   4.0 * (cin * npix + cout * npix * (2 if res is not None else 1) + cout * cin),
-                                  "direct 1x1/%d %d->%d [%s]%s (gemm)" % (stride, cin, cout, tuple(x.shape[0:1] + x.shape[2:]), " +res" if res is not None else "")))
+                                  "direct 1x1/%d %d->%d [%s]%s%s (gemm)" % (stride, cin, cout, tuple(x.shape[0:1] + x.shape[2:]), " +res" if res is not None else "",
+                                                                            " split-K x%d" % ksplit if ksplit > 1 else "")))
     return out
 
 
