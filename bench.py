@@ -115,10 +115,12 @@ def main():
             torch.distributed.destroy_process_group()
         sys.exit(0 if (rep is None or rep['all_ok']) else 1)
 
-    # kernel events are recorded on ONE timed image (the first): that image runs eagerly and without stream overlap -- two events
-    # per launch, ~190 dispatches instead of one graph replay -- so it is ~2 ms slower than the others and every sampled image
-    # lowers `value`; one image = 76 convolution launches is enough for the per-kernel roofline
-    PROFILE_EVERY = 1 << 30
+    # kernel events are recorded on a few timed images (one below 60 steps, else three spread over the run; never the first ones: the
+    # sample at step 0 read 0.565 instead of 0.61 on one box in three, every kernel of it 8-13 % slower -- clocks / power state right
+    # after the idle-to-load transition): a sampled image runs eagerly and without stream overlap -- two events per launch, ~190
+    # dispatches instead of one graph replay -- so it is ~2 ms slower than the others and every sampled image lowers `value`
+    first = min(3, max(args.steps - 1, 0))
+    SAMPLE_AT = {first} if args.steps < 60 else {first, first + args.steps // 3, first + 2 * (args.steps // 3)}
     ops.PROFILE['events'] = []
     sampled = [0]
 
@@ -129,11 +131,11 @@ def main():
         model.overlap_streams = overlap[0] and not on
 
     def before_step(s, model):   # (called before the launch of timed image s: with two images in flight that is before image
-        on = s % PROFILE_EVERY == 0  # s-1 has been read back, so the switch cannot live in a per-result callback)
-        if s > 0 and (s - 1) % PROFILE_EVERY == 0:
-            # the sampled image has the device to itself: the next image (a graph replay on another stream) is launched only when it
-            # has finished, or its kernels would overlap the sampled launches and inflate their event-to-event times (observed: the
-            # dense family at 0.57 instead of 0.61 of the MFMA peak). One image pair without overlap inside the timed region.
+        on = s in SAMPLE_AT      # s-1 has been read back, so the switch cannot live in a per-result callback)
+        if on or (s - 1) in SAMPLE_AT:
+            # the sampled image has the device to itself: it is launched when the images before it have finished, and the next image (a
+            # graph replay on another stream) only when it has finished -- or their kernels would overlap the sampled launches and inflate
+            # their event-to-event times (observed: the dense family at 0.57 instead of 0.61 of the MFMA peak). Inside the timed region.
             torch.cuda.synchronize()
         sample(model, on)
         sampled[0] += int(on)
@@ -287,6 +289,7 @@ def main():
     for e in ops.PROFILE['events']:
         key = '%s:%s' % (e[0], (e[5].split() or ['?'])[0] if len(e) > 5 else '?')
         form_hist[key] = form_hist.get(key, 0) + 1
+    form_hist = {k: v // max(sampled[0], 1) for k, v in form_hist.items()}      # launches per image
     timed_s = res['elapsed']
     if roofline is not None and timed_s < 1.0 and not steps_explicit:
         roofline = {'refused': 'timed region %.3f s < 1 s with the default --steps; pass --steps explicitly (the driver does) or raise it' % timed_s}
@@ -370,10 +373,10 @@ def main():
         from upsnet_amd.synthetic import DEFAULT_OFFSET_PX
         ops.PROFILE['events'] = []
 
-        def _sample_first(s_, m_):
-            ops.PROFILE['enabled'] = s_ == 0
-            m_.overlap_streams = s_ != 0
-        rw = upsnet_test(args.workload, steps=3, warmup=2, input_mode=args.input, in_flight=1, before_step=_sample_first, gather=False,
+        def _sample_first(s_, m_):        # (in_flight = 1: every image is synchronous; the third timed image is the sampled one)
+            ops.PROFILE['enabled'] = s_ == 2
+            m_.overlap_streams = s_ != 2
+        rw = upsnet_test(args.workload, steps=4, warmup=2, input_mode=args.input, in_flight=1, before_step=_sample_first, gather=False,
                          model_kw=dict(offset_px=2.0))
         ops.PROFILE['enabled'] = False
         torch.cuda.synchronize()

@@ -659,6 +659,7 @@ def test_winograd_tail_split_of_a_batched_launch():
     torch.manual_seed(3)
     m = torch.nn.Conv2d(256, 256, 3, 1, 1).cuda()
     x = torch.randn(100, 256, 14, 14, device='cuda').contiguous(memory_format=torch.channels_last)
+    was, hipconv.WINO_TAIL_SPLIT = hipconv.WINO_TAIL_SPLIT, True      # (opt-in: UPSNET_WINO_TAIL_SPLIT=1)
     assert hipconv._wino_tail_split(m, x) == 83 and hipconv._wino_tail_split(m, x[:64]) == 0
     hipconv.TRACE = []
     try:
@@ -668,7 +669,7 @@ def test_winograd_tail_split_of_a_batched_launch():
             hipconv.WINO_TAIL_SPLIT = False
             y0 = hipconv.conv(m, x, relu=True, winograd='always')
     finally:
-        hipconv.TRACE, hipconv.WINO_TAIL_SPLIT = None, True
+        hipconv.TRACE, hipconv.WINO_TAIL_SPLIT = None, was
     assert form == 'winograd tm32 + tail tn32' and torch.equal(y, y0)
 
 

@@ -34,6 +34,19 @@ def test_gather_to_rank0_on_rccl_single_rank():
             assert n == 3 * i and lab.is_cuda and int(lab[:40].min()) == i == int(lab[:40].max()) and int(lab[40:].min()) == 255
         empty = gather_results([], 1, dev, 48, 64, collective=True)
         assert empty == {}
+        # the STREAMED form of the timed loop on RCCL (r10): rows known up front, int64 label maps written straight into the send buffers,
+        # one asynchronous dist.gather per full chunk into row ranges of the preallocated result store, the ragged last chunk in finish()
+        from upsnet_amd.upsnet_end2end_test import ResultGatherer
+        g = ResultGatherer(1, dev, 48, 64, rows=11, chunk=4, collective=True)
+        for s in range(11):
+            g.add(100 + s, torch.full((48, 64) if s % 2 else (40, 60), s, dtype=torch.int64, device=dev), 7 * s)
+            assert g.sent == (s + 1) // 4 * 4
+        res = g.finish()
+        assert sorted(res) == list(range(100, 111)) and g.collectives == 3 and g.store.is_cuda
+        for s in range(11):
+            lab, n = res[100 + s]
+            h, w = (48, 64) if s % 2 else (40, 60)
+            assert n == 7 * s and bool((lab[:h, :w] == s).all()) and (s % 2 or (int(lab[h:].min()) == 255 and int(lab[:, w:].min()) == 255))
         t = torch.tensor([2.5], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
         dist.barrier()
@@ -72,3 +85,18 @@ def test_dry_run_two_ranks_sharing_the_gpu():
     ncpu = len(os.sched_getaffinity(0))
     if ncpu >= 2:
         assert all(p['host_cpus'] == ncpu // 2 for p in rep['per_rank']), rep['per_rank']
+    g = rep['gather']                                   # what the final-gather path will move for the requested --steps (r10)
+    assert g['chunk_images'] == 8 and g['bytes_sent_per_rank'] == g['steps'] * (1024 * 2048 + 16)
+    assert g['rank0_in_flight_bytes_max'] == 2 * 8 * 1024 * 2048
+
+
+def test_two_rank_timed_run_streams_its_label_maps_to_rank0():
+    """The timed N = 2 path itself on a shared GPU (gloo staging): 11 images per rank -> one full chunk of 8 leaves while the loop is still
+    running, the ragged rest in finish(); rank 0 reports n_gpus 2 and the gather statistics."""
+    r, line = _run_bench(['--gpus', '2', '--steps', '11', '--warmup', '2', '--no-cpu-baseline', '--no-configs2', '--no-wide-offsets'],
+                         {'UPSNET_SHARE_GPU': '1'}, timeout=1500)
+    assert r.returncode == 0 and line is not None, (r.stdout[-1000:], r.stderr[-3000:])
+    assert line['n_gpus'] == 2 and line['steps'] == 11 and line['value'] > 0
+    g = line['config']['gather']
+    assert g['chunk_images'] == 8 and g['collectives'] == 2 + 3 and g['bytes_sent'] == 2 * 8 * 1024 * 2048 + 16 * 11
+    assert line['gather_s'] is not None and line['gather_s'] < line['timed_s']

@@ -14,7 +14,7 @@ mkdir -p $OUT
 export PYTHONPATH=$REPO
 cd /tmp && export TMPDIR=/tmp
 EAGER="env UPSNET_OVERLAP=0 UPSNET_GRAPH=0"
-B="python $REPO/bench.py --no-cpu-baseline --no-configs2"
+B="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets"
 db() { find $1 -name "*.db" | head -1; }
 $EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- $B --steps 10 --warmup 5 > $OUT/${TAG}_trace_bench.log 2>&1
 python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace) 70 > $OUT/${TAG}_kernel_stats.txt 2>&1
@@ -29,7 +29,7 @@ python $REPO/tools/mfma_util.py $(db /tmp/p_mfma) > $OUT/${TAG}_mfma_util_serial
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma2 -o t -- $B --steps 20 --warmup 6 > $OUT/${TAG}_pmc_mfma_graph.log 2>&1
 python $REPO/tools/mfma_util.py $(db /tmp/p_mfma2) --total > $OUT/${TAG}_mfma_util_graph.txt 2>&1
 # bf16 mode (BASELINE configs[2]): eager serial trace -> kernel stats + timeline; the micro-benchmarks of its kernels against the paths they replace
-B16="python $REPO/bench.py --no-cpu-baseline --no-configs2 --conv-precision bf16"
+B16="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets --conv-precision bf16"
 $EAGER rocprofv3 --kernel-trace -d /tmp/p_trace16 -o t -- $B16 --steps 10 --warmup 5 > $OUT/${TAG}_bf16_trace_bench.log 2>&1
 python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace16) 45 > $OUT/${TAG}_bf16_kernel_stats.txt 2>&1
 python $REPO/tools/rocpd_timeline.py $(db /tmp/p_trace16) > $OUT/${TAG}_bf16_timeline_serial.txt 2>&1
@@ -41,12 +41,14 @@ cp $OUT/${TAG}_conv_pmc.json profiles/${TAG}_conv_pmc.json   # (so that the benc
 python tools/layer_table.py > $OUT/${TAG}_layer_table.txt 2>&1
 python tools/microbench_roialign.py > $OUT/${TAG}_roialign.txt 2>&1
 python bench.py > $OUT/${TAG}_bench.log 2>&1
-python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --in-flight 1 > $OUT/${TAG}_bench_serial.log 2>&1
-python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 > $OUT/${TAG}_bench_bf16.log 2>&1
-python bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16x3 > $OUT/${TAG}_bench_bf16x3.log 2>&1
-python bench.py --steps 40 --warmup 8 --no-configs2 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3.log 2>&1
-python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3_bf16.log 2>&1
-python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-configs2 --workload upsnet101dcn_mixed_1024x2048_800x1333 > $OUT/${TAG}_bench_c4.log 2>&1
+python bench.py --steps 150 --warmup 8 --no-cpu-baseline --no-configs2 --in-flight 1 > $OUT/${TAG}_bench_serial.log 2>&1
+python bench.py --steps 400 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 > $OUT/${TAG}_bench_bf16.log 2>&1
+python bench.py --steps 200 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16x3 > $OUT/${TAG}_bench_bf16x3.log 2>&1
+python bench.py --steps 130 --warmup 8 --no-configs2 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3.log 2>&1
+python bench.py --steps 250 --warmup 8 --no-cpu-baseline --no-configs2 --conv-precision bf16 --workload upsnet101dcn_coco_800x1333 > $OUT/${TAG}_bench_c3_bf16.log 2>&1
+python bench.py --steps 100 --warmup 8 --no-cpu-baseline --no-configs2 --workload upsnet101dcn_mixed_1024x2048_800x1333 > $OUT/${TAG}_bench_c4.log 2>&1
+# same-box A/B of this round's dispatch changes on the headline workload: the mask head's transposed convolution back on the general kernel (r09)
+UPSNET_DECONV_FRAG=0 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-configs2 --no-wide-offsets > $OUT/${TAG}_bench_ab_deconv_general.log 2>&1
 python bench.py --gpus 1 --dry-run > $OUT/${TAG}_dry_run.log 2>&1
 timeout 900 python -m pytest tests/test_trunk_gpu.py tests/test_layerwise_gpu.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep -E "worst|launches|passed|failed" > $OUT/${TAG}_parity.txt
 tail -1 $OUT/${TAG}_bench.log | cut -c1-300

@@ -330,7 +330,8 @@ def _winograd_plan(m, tn32=False):
     return ent[1], ent[2]
 
 
-WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '1') != '0'
+WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '0') == '1'   # measured r10: 114.5 vs 117-121 us per mask-head layer (3 %); the 17-ROI tail
+# launches run at 35 % of their MFMA time -- off by default (opt-in, tested)
 
 
 def _wino_tail_split(m, x):
