@@ -12,7 +12,7 @@ for n in ('kernel_stats.txt', 'per_call.txt', 'timeline_serial.txt', 'conv_pmc.j
     p = os.path.join(src, '%s_%s' % (tag, n))
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, n)))
-for n in ('bench', 'bench_serial', 'bench_bf16', 'bench_bf16x3', 'bench_c3', 'bench_c3_bf16', 'bench_c4', 'bench_ab_deconv_general', 'dry_run'):
+for n in ('bench', 'bench_serial', 'bench_bf16', 'bench_bf16x3', 'bench_c3', 'bench_c3_bf16', 'bench_c4', 'bench_ab_deconv_general', 'bench_hot', 'dry_run'):
     p = os.path.join(src, '%s_%s.log' % (tag, n))
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith('{')]

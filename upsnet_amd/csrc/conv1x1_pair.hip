@@ -216,20 +216,27 @@ __global__ void __launch_bounds__(256, 3) conv1x1_pair_f32_kernel(const PairPara
 
 /* out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1) in one launch (see the header of this
  * file). x [pixels, C0], residual / out1 [pixels, C1], out2 [pixels, C2], all NHWC with pixels = N*H*W.
- * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: C0 = 64, C1 % 128 == 0, C2 = 64 (the res2 stage). */
+ * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: (C0, C2) = (64, 64) (the res2 stage) or (128, 128) (res3), C1 % 128 == 0. */
 extern "C" int upsnet_conv1x1_pair_nhwc_f32(void *stream, const float *x, const float *residual, float *out1, float *out2, long pixels,
                                             int C0, const float *w3pack, const float *bias3, int C1, const float *w1pack,
                                             const float *bias1, int C2)
 {
     UPS_REQUIRE(x && residual && out1 && out2 && w3pack && w1pack && pixels > 0, "conv1x1_pair_nhwc_f32: null pointer / empty map");
-    UPS_REQUIRE(C0 == 64 && C2 == 64 && C1 > 0 && C1 % 128 == 0, "conv1x1_pair_nhwc_f32: supported shapes are C0 = 64, C1 %% 128 == 0, C2 = 64 (got %d, %d, %d)", C0, C1, C2);
+    const bool res2 = C0 == 64 && C2 == 64, res3 = C0 == 128 && C2 == 128;
+    UPS_REQUIRE((res2 || res3) && C1 > 0 && C1 % 128 == 0, "conv1x1_pair_nhwc_f32: supported shapes are (C0, C2) = (64, 64) or (128, 128), C1 %% 128 == 0 (got %d, %d, %d)", C0, C1, C2);
     UPS_REQUIRE(pixels * C1 < (1L << 29), "conv1x1_pair_nhwc_f32: feature map exceeds 2 GiB; split the batch");
     PairParams p;
     p.x = x; p.res = residual; p.w3 = w3pack; p.b3 = bias3; p.w1 = w1pack; p.b1 = bias1; p.out1 = out1; p.out2 = out2;
     p.M = pixels; p.C0 = C0; p.C1 = C1; p.C2 = C2;
     const int grid = (int)((pixels + 63) / 64);
     const size_t smem = (size_t)(8 * (C0 / 32) + 32) * CP_PITCH * 16;
-    hipLaunchKernelGGL((conv1x1_pair_f32_kernel<2, 64>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    if (res3) {   // r10: the res3 stage (128 -> 512 -> 128): x tile 32 KiB + chunk 33 KiB = 65 KiB of LDS, two workgroups per CU
+        static unsigned long long attr_dev = 0;
+        if (ups_first_on_device(attr_dev))
+            UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_pair_f32_kernel<4, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((conv1x1_pair_f32_kernel<4, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
+    } else
+        hipLaunchKernelGGL((conv1x1_pair_f32_kernel<2, 64>), dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
     UPS_CHECK_LAUNCH("conv1x1_pair_f32_kernel");
     return 0;
 }

@@ -205,17 +205,26 @@ PAIR = os.environ.get('UPSNET_CONV1X1_PAIR', '1') != '0'
 PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
 
 
+PAIR_RES3 = os.environ.get('UPSNET_CONV1X1_PAIR_RES3', '1') != '0'
+
+
 def use_pair(m3, m1, x, residual):
     """conv3 of one bottleneck (m3, + residual + ReLU) and conv1 of the next (m1, + ReLU) in one launch (csrc/conv1x1_pair.hip)?
-    Only where the pair is HBM-bound and the map has enough 64-pixel tiles: the res2 stage (64 -> 256 -> 64 on the stride-4 map).
+    Where the workgroups of the pair kernel (64 pixels x all channels) still fill the chip: the res2 stage (64 -> 256 -> 64 on the
+    stride-4 map: HBM-bound, the block output is not read back) and -- r10 -- the res3 stage (128 -> 512 -> 128 on the stride-8 map:
+    512 workgroups at 1024x2048; one kernel boundary, one prologue and the re-read of the block output less per block boundary).
     Not in the bf16 modes (there the layers follow hipconv._use_bf16)."""
     if not (PAIR and CONV1X1 and PRECISION == 'fp32' and supported(m3, x) and residual is not None and isinstance(m1, nn.Conv2d)):
         return False
     ok = lambda m: (tuple(m.kernel_size) == (1, 1) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (0, 0) and m.groups == 1)
-    if not (ok(m3) and ok(m1) and m3.in_channels == 64 and m3.out_channels % 128 == 0 and m1.in_channels == m3.out_channels and
-            m1.out_channels == 64):
+    if not (ok(m3) and ok(m1) and m3.out_channels % 128 == 0 and m1.in_channels == m3.out_channels):
         return False
-    return x.shape[0] * x.shape[2] * x.shape[3] >= 64 * PAIR_MIN_TILES
+    tiles = x.shape[0] * x.shape[2] * x.shape[3] // 64
+    if m3.in_channels == 64 and m1.out_channels == 64:
+        return tiles >= PAIR_MIN_TILES
+    if PAIR_RES3 and m3.in_channels == 128 and m1.out_channels == 128:
+        return tiles >= PAIR_MIN_TILES // 2
+    return False
 
 
 def conv_pair(m3, m1, x, residual):
