@@ -158,3 +158,17 @@ def test_conv_instance_selection_rules():
     assert hipconv._ksplit(nn.Conv2d(512, 512, 3, padding=1), x(1, 32, 64, 512), 512) == 3                    # res5 conv2: 256 workgroups
     assert hipconv._ksplit(c3, x(1, 32, 64), 256) == 4                                                        # FPN P5: 128 workgroups
     assert hipconv._ksplit(c3, x(1, 64, 128), 256) == 1 and hipconv._ksplit(nn.Conv2d(256, 1024, 1), x(1, 64, 128), 1024) == 1
+
+
+def test_knobs_report_set_variables_and_reject_unknown_names():
+    """bench hygiene (VERDICT r03 #8): every UPSNET_* variable that is set goes into the bench line; a name no source file reads is an error."""
+    from upsnet_amd import knobs
+    names = knobs.known()
+    assert {'UPSNET_GRAPH', 'UPSNET_OVERLAP', 'UPSNET_WINOGRAD', 'UPSNET_CONV_PRECISION', 'UPSNET_DECONV_FRAG', 'UPSNET_ROI_KERNEL',
+            'UPSNET_NMS_SCAN16', 'UPSNET_SHARE_GPU'} <= names
+    env = {'PATH': '/bin', 'UPSNET_GRAPH': '0', 'UPSNET_DECONV_FRAG': '0'}
+    assert knobs.active(env) == {'UPSNET_DECONV_FRAG': '0', 'UPSNET_GRAPH': '0'} and knobs.check(env) == knobs.active(env)
+    with pytest.raises(ValueError) as e:
+        knobs.check({'UPSNET_GRAHP': '0'})
+    assert 'UPSNET_GRAHP' in str(e.value)
+    assert knobs.check({'HOME': '/root'}) == {}
