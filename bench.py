@@ -303,6 +303,8 @@ def main():
         # seconds for the backbone); use a fixed, stated thread count
         cores = min(32, os.cpu_count() or 1)
         torch.set_num_threads(cores)
+        import oracle
+        oracle.set_threads(cores)      # the deformable im2col and ROIAlign loops of the C restatement on the same `cores` threads
         sc = args.cpu_baseline_scale
         h, w = int(H * sc) // 32 * 32, int(W * sc) // 32 * 32
         m_cpu = cpu_copy(res['model'])
@@ -320,7 +322,7 @@ def main():
         full = dt * (H * W) / float(h * w)
         cpu_baseline = {'value': round(1.0 / full, 5), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
                         'sample': '1 warm-up + 3 timed passes over 1 image %dx%d (%.2fx linear scale of the workload; scaled by pixel count '
-                                  'if < 1), median %.2f s (%s); torch-CPU convs on %d threads (host has %d) + single-thread C oracle ops'
+                                  'if < 1), median %.2f s (%s); torch-CPU convs and the deformable im2col / ROIAlign loops of the C restatement on %d threads (host has %d); proposals, selection and the panoptic head single-threaded'
                                   % (h, w, sc, dt, ' / '.join('%.2f' % t for t in times), cores, os.cpu_count()),
                         'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
                         'n_inst': out_cpu['n_inst']}

@@ -25,6 +25,16 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* The two loops that dominate the CPU baseline of bench.py (deformable im2col: one thread per channel; ROIAlign: one thread per ROI)
+ * are OpenMP-parallel: every output element is still computed by ONE thread with the same expressions in the same order, so results do
+ * not depend on the thread count. orc_set_threads(n): threads those loops use (default: 1 -- the tests run single-threaded). */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 0 ? n : 1; }
+
 
 /* ------------------------------------------------------------------------------------------
  * ROIAlign forward, NCHW.  upsnet/operators/src/roi_align_kernel.cu:43-95 (bilinear_interpolate)
@@ -55,6 +65,7 @@ void orc_roi_align_forward(const float *feat, int channels, int height, int widt
                            const float *rois, int num_rois, int pooled_h, int pooled_w,
                            int sampling_ratio, float spatial_scale, float *out)
 {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(orc_threads)
     for (int n = 0; n < num_rois; ++n) {
         const float *r = rois + n * 5;
         int roi_batch_ind = (int)roundf(r[0]);           /* :181 */
@@ -125,6 +136,7 @@ void orc_deform_im2col(const float *im, const float *offset, const float *mask /
     const int width_col = (width + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
     const int cpg = channels / deformable_group;
     const size_t plane_col = (size_t)height_col * width_col;
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
     for (int c = 0; c < channels; ++c) {
         const int g = c / cpg;
         const float *plane = im + (size_t)c * height * width;

@@ -253,3 +253,23 @@ def test_forward_cpu_covers_the_dcn_backbone():
         assert out['panoptic_outputs'].shape == (64, 96) and out['n_rois'] <= 300 and out['mask_probs'].shape[1:] == (81, 28, 28)
     finally:
         update_config_dict(CITYSCAPES_R50)
+
+
+def test_oracle_openmp_loops_do_not_depend_on_the_thread_count():
+    """bench.py's cpu_baseline runs the C restatement's deformable im2col and ROIAlign on its stated core count (oracle.set_threads):
+    one thread per channel / per ROI, so the results are the single-threaded ones bit for bit."""
+    import oracle
+    rng = np.random.default_rng(5)
+    im = rng.normal(size=(24, 19, 23)).astype(np.float32)
+    off = (rng.normal(size=(18, 19, 23)) * 2).astype(np.float32)
+    feat = rng.normal(size=(1, 16, 40, 64)).astype(np.float32)
+    rois = np.hstack([np.zeros((37, 1)), np.sort(rng.uniform(0, 150, (37, 4)), axis=1)[:, [0, 1, 2, 3]]]).astype(np.float32)
+    try:
+        oracle.set_threads(1)
+        a = oracle.deform_im2col(im, off, (3, 3), (1, 1), (1, 1), (1, 1), 1)
+        b = oracle.roi_align_forward(feat, rois, 7, 7, 0.25)
+        oracle.set_threads(8)
+        assert np.array_equal(a, oracle.deform_im2col(im, off, (3, 3), (1, 1), (1, 1), (1, 1), 1))
+        assert np.array_equal(b, oracle.roi_align_forward(feat, rois, 7, 7, 0.25))
+    finally:
+        oracle.set_threads(1)
