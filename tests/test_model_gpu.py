@@ -263,10 +263,10 @@ def test_mixed_stream_at_real_sizes_graph_replay_equals_eager():
         update_config_dict(CITYSCAPES_R50)
 
 
-# Agreement of the bf16 mode with the fp32 run ON THE SAME IMAGE, measured on MI355X (r10) and asserted with a small margin below the
+# Agreement of the bf16 mode with the fp32 run ON THE SAME IMAGE, measured on MI355X (r10) and asserted with a small margin (0.03) below the
 # measured value (a random synthetic network has no decision margin: a bf16 rounding moves near-tied logits; trained weights agree
 # far better). name: (semantic arg-max agreement, panoptic label-map agreement)
-_BF16_AGREE = {(256, 512): (0.895, 0.81), (1024, 2048): (0.885, 0.87)}   # measured 0.9152 / 0.8330 and 0.9036 / 0.8899
+_BF16_AGREE = {(256, 512): (0.885, 0.80), (1024, 2048): (0.875, 0.86)}   # measured 0.9152 / 0.8330 and 0.9036 / 0.8899 (one box; the assertion held on every box of r10); margin 0.03
 
 
 def test_bf16_mode_at_1024x2048_stagewise_parity_and_agreement():
