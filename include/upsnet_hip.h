@@ -372,7 +372,7 @@ int upsnet_conv1x1_frag_nhwc_f32_splitk(void *stream, const float *x, const floa
  *     out1 = relu(conv1x1(x; w3) + bias3 + residual)      x [pixels, C0], residual / out1 [pixels, C1]   (NHWC, pixels = N*H*W)
  *     out2 = relu(conv1x1(out1; w1) + bias1)              out2 [pixels, C2]
  * Both results are bit-identical to two upsnet_conv1x1_frag_nhwc_f32 launches; out1 is not read back from HBM.
- * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: (C0, C2) = (64, 64) or (128, 128), C1 % 128 == 0 (the res2 and res3 stages). */
+ * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: (C0, C2) = (64, 64), (128, 128) or (256, 256), C1 % 128 == 0 (the res2, res3 and -- on 32-pixel tiles -- res4 stages). */
 int upsnet_conv1x1_pair_nhwc_f32(void *stream, const float *x, const float *residual, float *out1, float *out2, long pixels, int C0,
                                  const float *w3pack, const float *bias3, int C1, const float *w1pack, const float *bias1, int C2);
 

@@ -111,6 +111,29 @@ def test_conv1x1_pair_kernel_res3(N, H, W, C1):
     np.testing.assert_allclose(o2.cpu().numpy(), r2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,C1", [(1, 32, 48, 1024), (2, 19, 21, 1024), (1, 5, 3, 256), (1, 64, 128, 1024)])
+def test_conv1x1_pair_kernel_res4(N, H, W, C1):
+    """r10: the (C0, C2) = (256, 256) instance on 32-pixel tiles (conv1x1_pair32_f32_kernel, res4: 256 -> 1024 -> 256): bit-identical to two
+    launches of csrc/conv1x1.hip, 1e-4 vs float64; ragged tiles, a map smaller than a tile, and the stage's real map at 1024x2048."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + H + W + C1)
+    x = torch.randn(N, 256, H, W, device='cuda').relu()
+    sc = torch.randn(N, C1, H, W, device='cuda')
+    w3 = torch.randn(C1, 256, 1, 1, device='cuda') / 16
+    b3 = torch.randn(C1, device='cuda')
+    w1 = torch.randn(256, C1, 1, 1, device='cuda') / C1 ** 0.5
+    b1 = torch.randn(256, device='cuda')
+    p3, p1 = ops.pack_conv1x1_weight(w3), ops.pack_conv1x1_weight(w1)
+    o1, o2 = ops.conv1x1_pair(x, sc, p3, b3, C1, p1, b1, 256)
+    s1 = ops.conv1x1_frag(x, p3, b3, C1, 1, relu=True, residual=sc)
+    s2 = ops.conv1x1_frag(s1, p1, b1, 256, 1, relu=True)
+    assert torch.equal(o1, s1) and torch.equal(o2, s2)
+    r1 = (F.conv2d(x.double(), w3.double(), b3.double()) + sc.double()).clamp_min(0)
+    r2 = F.conv2d(r1, w1.double(), b1.double()).clamp_min(0)
+    np.testing.assert_allclose(o1.cpu().numpy(), r1.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o2.cpu().numpy(), r2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("N,H,W,C1", [(1, 64, 96, 256), (2, 37, 41, 256), (1, 9, 7, 128), (1, 40, 40, 384)])
 def test_conv1x1_pair_kernel(N, H, W, C1):
     """csrc/conv1x1_pair.hip: relu(conv3(x) + b3 + shortcut) and relu(conv1(that) + b1) in one launch -- bit-identical to two launches

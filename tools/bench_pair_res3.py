@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import torch
 from upsnet_amd import ops
 from gputime import gpu_time
-for name, H, W, c0, c1 in (("res3 1024x2048", 128, 256, 128, 512), ("res3 800x1333", 100, 168, 128, 512), ("res2 1024x2048", 256, 512, 64, 256)):
+for name, H, W, c0, c1 in (("res3 1024x2048", 128, 256, 128, 512), ("res3 800x1333", 100, 168, 128, 512), ("res2 1024x2048", 256, 512, 64, 256), ("res4 1024x2048", 64, 128, 256, 1024), ("res4 800x1333", 50, 84, 256, 1024)):
     x = torch.randn(1, c0, H, W, device='cuda').relu().contiguous(memory_format=torch.channels_last)
     sc = torch.randn(1, c1, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
     w3 = torch.randn(c1, c0, 1, 1, device='cuda') / c0 ** 0.5

@@ -214,20 +214,183 @@ __global__ void __launch_bounds__(256, 3) conv1x1_pair_f32_kernel(const PairPara
     }
 }
 
+// r10: the same pair on 32-PIXEL tiles for the stride-16 map (res4: 256 -> 1024 -> 256). A 64-pixel tile would leave 128 workgroups for the
+// 8192 pixels of a 1024x2048 image; 32 pixels give 256 = one per CU, and one 4-wave workgroup keeps its CU's matrix pipe busy by itself.
+// A wave owns one 32-column block of each 128-channel chunk of out1 (one row block: acc0) and TWO column blocks of out2 (2 wave, 2 wave + 1;
+// two B rings). Same K order through one accumulator per output element as conv1x1_frag_f32_kernel: bit-identical to the two launches.
+// LDS: x tile [8 NSL0 quarters][33] + chunk [32 quarters][33] 16-byte units = 50 KiB at C0 = 256.
+#define CP32_PITCH 33
+template <int NSL0>
+__global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairParams p)
+{
+    constexpr int XQ = 8 * NSL0;
+    constexpr int G1 = 4 * NSL0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4 *Xs = reinterpret_cast<float4 *>(smem_raw);     // [XQ][33]
+    float4 *Ys = Xs + XQ * CP32_PITCH;                      // [32 quarters of the chunk][33]
+    float *Ysf = reinterpret_cast<float *>(Ys);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lhalf = lane >> 5, l32 = lane & 31;
+    const long p0 = (long)blockIdx.x * 32;
+    const int nsl1 = p.C1 >> 5, npass = p.C1 >> 7;
+
+    const size_t xaddr = reinterpret_cast<size_t>(p.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C0) * 4u);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    const size_t w3addr = reinterpret_cast<size_t>(p.w3);
+    const unsigned w3lo = __builtin_amdgcn_readfirstlane((unsigned)w3addr), w3hi = __builtin_amdgcn_readfirstlane((unsigned)(w3addr >> 32));
+    const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w3hi << 32) | w3lo), 0, p.C1 * p.C0 * 4, 0x00020000);
+    // second GEMM: column blocks 2 wave and 2 wave + 1 of out2, contiguous in the packed matrix (nsl1 * 4096 bytes each)
+    const size_t w1addr = reinterpret_cast<size_t>(p.w1) + (size_t)(2 * wave) * (size_t)nsl1 * 4096u;
+    const unsigned w1lo = __builtin_amdgcn_readfirstlane((unsigned)w1addr), w1hi = __builtin_amdgcn_readfirstlane((unsigned)(w1addr >> 32));
+    const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w1hi << 32) | w1lo), 0, 2 * nsl1 * 4096, 0x00020000);
+    const unsigned w1blk = (unsigned)nsl1 * 4096u;
+    const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
+    const int g2max = nsl1 * 4 - 1;
+#define CP_RSRC(NAME, PTR, BYTES)                                                                                      \
+    const size_t NAME##_a = reinterpret_cast<size_t>(PTR);                                                             \
+    const __amdgpu_buffer_rsrc_t NAME = __builtin_amdgcn_make_buffer_rsrc(                                             \
+        reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(NAME##_a >> 32)) << 32) |  \
+                                 (size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)NAME##_a)), 0, (int)(BYTES), 0x00020000);
+    const unsigned bytes1 = __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C1) * 4u);
+    CP_RSRC(rrsrc, p.res, bytes1)
+    CP_RSRC(o1rsrc, p.out1, bytes1)
+    CP_RSRC(o2rsrc, p.out2, __builtin_amdgcn_readfirstlane((unsigned)(p.M * p.C2) * 4u))
+#undef CP_RSRC
+    const unsigned row1 = 4u * (unsigned)p.C1;
+    const unsigned vo1 = ((unsigned)(p0 + 4 * lhalf) * (unsigned)p.C1 + (unsigned)(32 * wave + l32)) * 4u;
+
+#define CP_LD(D, RS, VO, SO) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(RS, (VO), (SO), 0); \
+        D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
+#define CP_B1(SLOT, J, G) CP_LD(b1r[SLOT], w3rsrc, b_lane, (unsigned)((min((J), npass - 1) * 4 + wave) * G1 + (G)) * 1024u)
+#define CP_B2(SLOT, G) { CP_LD(b2a[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u) \
+                         CP_LD(b2b[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u + w1blk) }
+
+    float4 b1r[4], b2a[4], b2b[4];
+    {   // ---- stage the x tile: thread = (pixel prow, channel quarter q of each 32-channel slab)
+        const int q = tid & 7, prow = tid >> 3;
+        float4 xa[NSL0];
+        const long pp = p0 + prow;
+        const unsigned po = pp < p.M ? (unsigned)pp * 4u * (unsigned)p.C0 + 16u * (unsigned)q : 0x80000000u;
+#pragma unroll
+        for (int s = 0; s < NSL0; ++s) CP_LD(xa[s], xrsrc, po + 128u * (unsigned)s, 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) CP_B1(u, 0, u)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) CP_B2(u, u)
+#pragma unroll
+        for (int s = 0; s < NSL0; ++s) Xs[(8 * s + q) * CP32_PITCH + prow] = xa[s];
+    }
+    __syncthreads();
+
+    const float4 *xfrag = Xs + lhalf * CP32_PITCH + l32;
+    const float4 *yfrag = Ys + lhalf * CP32_PITCH + l32;
+    float *ydst = Ysf + (((32 * wave + l32) >> 2) * CP32_PITCH + 4 * lhalf) * 4 + (l32 & 3);
+    floatx16 acc2a, acc2b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2a[r] = 0.f; acc2b[r] = 0.f; }
+    int g2 = 0;
+    for (int j = 0; j < npass; ++j) {
+        floatx16 acc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+        const int co = 128 * j + 32 * wave + l32;
+        float rr[16];          // shortcut of this chunk, in flight during the first GEMM
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 512u * (unsigned)j, 0));
+        {
+            float4 a0 = xfrag[0];
+#pragma unroll
+            for (int g = 0; g < G1; ++g) {
+                float4 n0;
+                if (g + 1 < G1) n0 = xfrag[2 * (g + 1) * CP32_PITCH];
+                const float4 bf = b1r[g & 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf.x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf.y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf.z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf.w, acc0, 0, 0, 0);
+                if (g + 4 < G1) CP_B1(g & 3, j, g + 4) else CP_B1(g & 3, j + 1, g + 4 - G1)
+                if (g + 1 < G1) a0 = n0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float bv = p.b3 != nullptr ? p.b3[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc0[r] + bv;
+            v = v + rr[r];
+            v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o1rsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 512u * (unsigned)j, 0);
+            ydst[((r & 3) + 8 * (r >> 2)) * 4] = v;
+        }
+        __syncthreads();   // chunk complete in LDS
+        {
+            float4 a0 = yfrag[0];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float4 n0;
+                if (t + 1 < 16) n0 = yfrag[2 * (t + 1) * CP32_PITCH];
+                const float4 bfa = b2a[t & 3], bfb = b2b[t & 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bfa.x, acc2a, 0, 0, 0);
+                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bfb.x, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bfa.y, acc2a, 0, 0, 0);
+                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bfb.y, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bfa.z, acc2a, 0, 0, 0);
+                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bfb.z, acc2b, 0, 0, 0);
+                acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bfa.w, acc2a, 0, 0, 0);
+                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bfb.w, acc2b, 0, 0, 0);
+                CP_B2(t & 3, g2 + 4 + t)
+                if (t + 1 < 16) a0 = n0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        g2 += 16;
+        __syncthreads();   // every read of the chunk is done before the next one overwrites it
+    }
+#undef CP_LD
+#undef CP_B1
+#undef CP_B2
+
+    const unsigned row2 = 4u * (unsigned)p.C2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co2 = 32 * (2 * wave + i) + l32;
+        const float bv2 = p.b1 != nullptr ? p.b1[co2] : 0.f;
+        const unsigned vo2 = ((unsigned)(p0 + 4 * lhalf) * (unsigned)p.C2 + (unsigned)co2) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = (i == 0 ? acc2a[r] : acc2b[r]) + bv2;
+            v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o2rsrc, vo2, (unsigned)((r & 3) + 8 * (r >> 2)) * row2, 0);
+        }
+    }
+}
+
 /* out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1) in one launch (see the header of this
  * file). x [pixels, C0], residual / out1 [pixels, C1], out2 [pixels, C2], all NHWC with pixels = N*H*W.
- * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: (C0, C2) = (64, 64) (the res2 stage) or (128, 128) (res3), C1 % 128 == 0. */
+ * w3pack / w1pack: upsnet_dcn_pack_weight(weight, cout, cin, 1, 1). Supported: (C0, C2) = (64, 64) (the res2 stage), (128, 128) (res3) or (256, 256) (res4, 32-pixel tiles), C1 % 128 == 0. */
 extern "C" int upsnet_conv1x1_pair_nhwc_f32(void *stream, const float *x, const float *residual, float *out1, float *out2, long pixels,
                                             int C0, const float *w3pack, const float *bias3, int C1, const float *w1pack,
                                             const float *bias1, int C2)
 {
     UPS_REQUIRE(x && residual && out1 && out2 && w3pack && w1pack && pixels > 0, "conv1x1_pair_nhwc_f32: null pointer / empty map");
-    const bool res2 = C0 == 64 && C2 == 64, res3 = C0 == 128 && C2 == 128;
-    UPS_REQUIRE((res2 || res3) && C1 > 0 && C1 % 128 == 0, "conv1x1_pair_nhwc_f32: supported shapes are (C0, C2) = (64, 64) or (128, 128), C1 %% 128 == 0 (got %d, %d, %d)", C0, C1, C2);
+    const bool res2 = C0 == 64 && C2 == 64, res3 = C0 == 128 && C2 == 128, res4 = C0 == 256 && C2 == 256;
+    UPS_REQUIRE((res2 || res3 || res4) && C1 > 0 && C1 % 128 == 0, "conv1x1_pair_nhwc_f32: supported shapes are (C0, C2) = (64, 64), (128, 128) or (256, 256), C1 %% 128 == 0 (got %d, %d, %d)", C0, C1, C2);
     UPS_REQUIRE(pixels * C1 < (1L << 29), "conv1x1_pair_nhwc_f32: feature map exceeds 2 GiB; split the batch");
     PairParams p;
     p.x = x; p.res = residual; p.w3 = w3pack; p.b3 = bias3; p.w1 = w1pack; p.b1 = bias1; p.out1 = out1; p.out2 = out2;
     p.M = pixels; p.C0 = C0; p.C1 = C1; p.C2 = C2;
+    if (res4) {   // r10: 32-pixel tiles (csrc comment above conv1x1_pair32_f32_kernel)
+        const size_t smem32 = (size_t)(8 * (C0 / 32) + 32) * CP32_PITCH * 16;
+        hipLaunchKernelGGL((conv1x1_pair32_f32_kernel<8>), dim3((unsigned)((pixels + 31) / 32)), dim3(256), smem32, (hipStream_t)stream, p);
+        UPS_CHECK_LAUNCH("conv1x1_pair32_f32_kernel");
+        return 0;
+    }
     const int grid = (int)((pixels + 63) / 64);
     const size_t smem = (size_t)(8 * (C0 / 32) + 32) * CP_PITCH * 16;
     if (res3) {   // r10: the res3 stage (128 -> 512 -> 128): x tile 32 KiB + chunk 33 KiB = 65 KiB of LDS, two workgroups per CU

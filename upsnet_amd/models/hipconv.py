@@ -206,13 +206,15 @@ PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
 
 
 PAIR_RES3 = os.environ.get('UPSNET_CONV1X1_PAIR_RES3', '1') != '0'
+PAIR_RES4 = os.environ.get('UPSNET_CONV1X1_PAIR_RES4', '1') != '0'
 
 
 def use_pair(m3, m1, x, residual):
     """conv3 of one bottleneck (m3, + residual + ReLU) and conv1 of the next (m1, + ReLU) in one launch (csrc/conv1x1_pair.hip)?
     Where the workgroups of the pair kernel (64 pixels x all channels) still fill the chip: the res2 stage (64 -> 256 -> 64 on the
     stride-4 map: HBM-bound, the block output is not read back) and -- r10 -- the res3 stage (128 -> 512 -> 128 on the stride-8 map:
-    512 workgroups at 1024x2048; one kernel boundary, one prologue and the re-read of the block output less per block boundary).
+    512 workgroups at 1024x2048; one kernel boundary, one prologue and the re-read of the block output less per block boundary) and the
+    res4 stage (256 -> 1024 -> 256 on 32-pixel tiles: 256 workgroups at 1024x2048).
     Not in the bf16 modes (there the layers follow hipconv._use_bf16)."""
     if not (PAIR and CONV1X1 and PRECISION == 'fp32' and supported(m3, x) and residual is not None and isinstance(m1, nn.Conv2d)):
         return False
@@ -224,6 +226,8 @@ def use_pair(m3, m1, x, residual):
         return tiles >= PAIR_MIN_TILES
     if PAIR_RES3 and m3.in_channels == 128 and m1.out_channels == 128:
         return tiles >= PAIR_MIN_TILES // 2
+    if PAIR_RES4 and m3.in_channels == 256 and m1.out_channels == 256:   # 32-pixel tiles: 256 -> 1024 -> 256 on the stride-16 map, >= one workgroup per CU
+        return 2 * tiles >= PAIR_MIN_TILES // 4
     return False
 
 
