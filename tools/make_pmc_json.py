@@ -28,14 +28,18 @@ def parse(path, counter):
 
 
 fetch, write = parse(fpath, 'FETCH_SIZE'), parse(wpath, 'WRITE_SIZE')
-DENSE = ('conv_igemm_f32_kernel', 'conv_wino16_f32_kernel', 'conv1x1_frag_f32_kernel')
+# the launches bench.py's roofline counts as the dense family (upsnet_amd/ops.py, PROFILE events of kind 'conv'): the three convolution
+# kernels, the block-boundary pair kernels and the fused stem; a split-K launch's reduce kernel belongs to that launch (bytes, no count)
+DENSE = ('conv_igemm_f32_kernel', 'conv_wino16_f32_kernel', 'conv1x1_frag_f32_kernel', 'conv1x1_pair_f32_kernel', 'conv1x1_pair32_f32_kernel',
+         'stem_pool_f32_kernel')
+EXTRA = ('conv_splitk_reduce',)
 per, n_tot, f_tot, w_tot = {}, 0, 0.0, 0.0
 for name, (n, f) in fetch.items():
     w = write.get(name, (n, 0.0))[1]
-    if any(k in name for k in DENSE + ('dcn_fused_f32_kernel', 'fpn_roi_align', 'panoptic_fuse')):
+    if any(k in name for k in DENSE + EXTRA + ('dcn_fused_f32_kernel', 'fpn_roi_align', 'panoptic_fuse')):
         per[name] = dict(launches=n, fetch_kib=round(f, 1), write_kib=round(w, 1), hbm_bytes_per_launch=int((2 * f + w) * 1024))
-    if any(k in name for k in DENSE) and 'ConvParams' in name:
-        n_tot += n
+    if any(k in name for k in DENSE + EXTRA):
+        n_tot += 0 if any(k in name for k in EXTRA) else n
         f_tot += f * n
         w_tot += w * n
 doc = {
@@ -44,7 +48,7 @@ doc = {
     'correction': 'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB: FETCH doubled for 16 B/lane streaming reads (gfx950 counts 128-B requests '
                   'at 64 B, MI355X_MICROARCH.md); counters sit at the L2 <-> fabric boundary and include Infinity-Cache hits',
     'srchash': B._source_hash(),
-    'kernel': 'dense convolution family (conv_igemm_f32_kernel + conv1x1_frag_f32_kernel + conv_wino16_f32_kernel), %d launches' % n_tot,
+    'kernel': 'dense convolution family (' + ' + '.join(DENSE) + '; split-K reduce passes added to their launches), %d launches' % n_tot,
     'fetch_kb_per_launch_raw': round(f_tot / max(n_tot, 1), 1), 'write_kb_per_launch_raw': round(w_tot / max(n_tot, 1), 1),
     'hbm_bytes_per_launch': int((2 * f_tot + w_tot) / max(n_tot, 1) * 1024),
     'per_kernel': per,
