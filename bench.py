@@ -70,6 +70,46 @@ def ensure_ranks(args):
         os.execvpe(cmd[0], cmd, env)
 
 
+def roialign_microbench(H, W, n_iter=10):
+    """The isolated FPN ROIAlign on log-uniform random ROIs (sizes 16-512 px, aspect 0.5-2, centres uniform) over a random
+    256-channel pyramid of the workload's shape: box-head (1000 x 7 x 7) and mask-head (100 x 14 x 14) launches, warm and cold."""
+    import numpy as np
+    from upsnet_amd import ops
+    rng = np.random.default_rng(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    feats = [torch.randn(1, 256, H >> (2 + l), W >> (2 + l), device=dev).contiguous(memory_format=torch.channels_last) for l in range(4)]
+    flush = torch.empty(160 << 20, dtype=torch.float32, device=dev)
+    out = []
+    for n, ps in ((1000, 7), (100, 14)):
+        size = np.exp(rng.uniform(np.log(16.0), np.log(512.0), n))
+        ar = np.exp(rng.uniform(np.log(0.5), np.log(2.0), n))
+        w, h = size * np.sqrt(ar), size / np.sqrt(ar)
+        cx, cy = rng.uniform(0, W, n), rng.uniform(0, H, n)
+        b = np.stack([np.clip(cx - w / 2, 0, W - 1), np.clip(cy - h / 2, 0, H - 1), np.clip(cx + w / 2, 0, W - 1), np.clip(cy + h / 2, 0, H - 1)], 1)
+        rois = torch.from_numpy(np.hstack([np.zeros((n, 1)), b]).astype(np.float32)).to(dev)
+        alg = ops.roi_align_algorithmic_bytes(feats, n, 256, ps, ps)
+        row = {'launch': 'roialign %dx256x%dx%d' % (n, ps, ps), 'algorithmic_bytes': alg}
+        for cold in (False, True):
+            ts = []
+            for _ in range(n_iter + 2):
+                if cold:
+                    flush.add_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.fpn_roi_align(feats, rois, ps, ps, [0.25, 0.125, 0.0625, 0.03125])
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1000.0)
+            us = sorted(ts[2:])[n_iter // 2]
+            tag = 'cold' if cold else 'warm'
+            row[tag + '_us'] = round(us, 1)
+            row[tag + '_GBs'] = round(alg / us / 1e3, 1)
+            row[tag + '_frac'] = round(alg / us / 1e3 / PEAK_HBM_GBS, 4)
+        out.append(row)
+    del flush, feats
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -96,6 +136,8 @@ def main():
     ap.add_argument('--no-wide-offsets', action='store_true',
                     help='skip the short extra leg that times the deformable kernels on a model with 2 px offset standard deviation '
                          '(the headline model predicts ~1 px offsets like a trained DCN; reported as roofline.deformable_wide_offsets)')
+    ap.add_argument('--no-roialign', action='store_true',
+                    help='skip the ROIAlign report (roofline.roialign: the launches of the sampled image + the isolated kernel on random ROIs)')
     args = ap.parse_args()
     steps_explicit = any(a == '--steps' or a.startswith('--steps=') for a in sys.argv[1:])
     ensure_ranks(args)
@@ -283,6 +325,31 @@ def main():
                                            'achieved': round(f_db / t_db / 1e12, 3), 'frac': round(f_db / t_db / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                                            'launches_timed': n_db, 'avg_launch_ms': round(1000.0 * t_db / n_db, 4),
                                            'algorithmic_bytes_per_launch': b_db / n_db, 'hbm_equiv_GBs': round(b_db / t_db / 1e9, 1)}
+
+    # ---- FPN ROIAlign (HBM-bound): the two launches of the sampled image(s) on the model's own proposals, and the isolated
+    # kernel on log-uniform random ROIs over the same pyramid shape (warm: the pyramid resident in the Infinity Cache; cold: 640 MB
+    # rewritten between calls, as the activations of an image do between the FPN and the ROIAlign)
+    ev_r = [e for e in ops.PROFILE['events'] if e[0] == 'roialign']
+    if roofline is not None and ev_r and not args.no_roialign:
+        per = {}
+        for e in ev_r:
+            per.setdefault(e[5], []).append((e[1].elapsed_time(e[2]) * 1000.0, e[4]))
+        in_model = []
+        for k, v in per.items():
+            us = sorted(t for t, _ in v)[len(v) // 2]
+            in_model.append({'launch': k, 'us': round(us, 1), 'algorithmic_bytes': v[0][1], 'GBs': round(v[0][1] / us / 1e3, 1),
+                             'frac': round(v[0][1] / us / 1e3 / PEAK_HBM_GBS, 4)})
+        pmc_r = None
+        if traffic_src:
+            jr = json.load(open(os.path.join(ROOT, traffic_src)))
+            hits = [v for k, v in (jr.get('per_kernel') or {}).items() if 'fpn_roi_align' in k]
+            if hits:
+                pmc_r = {'fabric_bytes_per_launch_avg': int(sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / sum(h['launches'] for h in hits)),
+                         'source': traffic_src}
+        roofline['roialign'] = {'kernel': 'fpn_roi_align_nhwc_tab_kernel (csrc/roi_align.hip)', 'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                'in_model': in_model, 'traffic': pmc_r, 'random_rois': roialign_microbench(H, W),
+                                'note': 'algorithmic bytes per SURVEY 8d: output + ROI records + min(pyramid, per-ROI sample neighbourhoods); the '
+                                        "model's proposals overlap, so part of its reads are L2 hits (fabric bytes < algorithmic)"}
 
     # kernel-form histogram of the sampled image: which form of which kernel family every launch of that image took
     form_hist = {}

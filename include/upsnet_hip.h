@@ -356,6 +356,8 @@ int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin
 int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
                                  int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu, int residual_up);
 void upsnet_conv1x1_tuning(int bn);
+/* development knob: waves per workgroup of the 32-pixel form of upsnet_conv1x1_pair_nhwc_f32 (8: two per SIMD, default; 4). */
+void upsnet_conv1x1_pair32_tuning(int waves);
 
 /* upsnet_conv1x1_frag_nhwc_f32 with the K walk of every tile split over `ksplit` (2..16) workgroups + the shared reduce / epilogue
  * kernel (bias, residual, ReLU; fixed summation order: bit-repeatable). For maps whose tile count does not spread evenly over the CUs:

@@ -111,11 +111,14 @@ def test_conv1x1_pair_kernel_res3(N, H, W, C1):
     np.testing.assert_allclose(o2.cpu().numpy(), r2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("N,H,W,C1", [(1, 32, 48, 1024), (2, 19, 21, 1024), (1, 5, 3, 256), (1, 64, 128, 1024)])
-def test_conv1x1_pair_kernel_res4(N, H, W, C1):
+@pytest.mark.parametrize("N,H,W,C1", [(1, 32, 48, 1024), (2, 19, 21, 1024), (1, 5, 3, 256), (1, 11, 13, 384), (1, 64, 128, 1024)])
+@pytest.mark.parametrize("waves", [8, 4])
+def test_conv1x1_pair_kernel_res4(N, H, W, C1, waves, monkeypatch):
     """r10: the (C0, C2) = (256, 256) instance on 32-pixel tiles (conv1x1_pair32_f32_kernel, res4: 256 -> 1024 -> 256): bit-identical to two
-    launches of csrc/conv1x1.hip, 1e-4 vs float64; ragged tiles, a map smaller than a tile, and the stage's real map at 1024x2048."""
+    launches of csrc/conv1x1.hip, 1e-4 vs float64; ragged tiles, a map smaller than a tile, and the stage's real map at 1024x2048. Both
+    workgroup forms: 8 waves (256-channel chunks; falls back to 4 when C1 % 256 != 0) and 4 waves."""
     from upsnet_amd import ops
+    monkeypatch.setattr(ops, 'PAIR32_WAVES', waves)
     torch.manual_seed(N + H + W + C1)
     x = torch.randn(N, 256, H, W, device='cuda').relu()
     sc = torch.randn(N, C1, H, W, device='cuda')

@@ -28,7 +28,7 @@ from upsnet_amd.models import hipconv
 import torch.nn as nn
 for cout in (256,):
     row = []
-    for cin in (16, 32, 64, 128, 256):
+    for cin in (32, 64, 128, 256):
         m = nn.Conv2d(cin, cout, 3, padding=1).cuda()
         x = torch.randn(1, cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
         wp, ldw = hipconv._winograd_plan(m)

@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 # 0. the default bench line on the fresh box (what the driver's BENCH run measures): before anything else has heated the chip
 (cd $REPO && python bench.py > $OUT/${TAG}_bench.log 2>&1)
 EAGER="env UPSNET_OVERLAP=0 UPSNET_GRAPH=0"
-B="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets"
+B="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets --no-roialign"
 db() { find $1 -name "*.db" | head -1; }
 $EAGER rocprofv3 --kernel-trace -d /tmp/p_trace -o t -- $B --steps 10 --warmup 5 > $OUT/${TAG}_trace_bench.log 2>&1
 python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace) 70 > $OUT/${TAG}_kernel_stats.txt 2>&1
@@ -31,7 +31,7 @@ python $REPO/tools/mfma_util.py $(db /tmp/p_mfma) > $OUT/${TAG}_mfma_util_serial
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_mfma2 -o t -- $B --steps 20 --warmup 6 > $OUT/${TAG}_pmc_mfma_graph.log 2>&1
 python $REPO/tools/mfma_util.py $(db /tmp/p_mfma2) --total > $OUT/${TAG}_mfma_util_graph.txt 2>&1
 # bf16 mode (BASELINE configs[2]): eager serial trace -> kernel stats + timeline; the micro-benchmarks of its kernels against the paths they replace
-B16="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets --conv-precision bf16"
+B16="python $REPO/bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets --no-roialign --conv-precision bf16"
 $EAGER rocprofv3 --kernel-trace -d /tmp/p_trace16 -o t -- $B16 --steps 10 --warmup 5 > $OUT/${TAG}_bf16_trace_bench.log 2>&1
 python $REPO/tools/rocpd_stats.py $(db /tmp/p_trace16) 45 > $OUT/${TAG}_bf16_kernel_stats.txt 2>&1
 python $REPO/tools/rocpd_timeline.py $(db /tmp/p_trace16) > $OUT/${TAG}_bf16_timeline_serial.txt 2>&1

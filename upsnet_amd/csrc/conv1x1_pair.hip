@@ -220,20 +220,25 @@ __global__ void __launch_bounds__(256, 3) conv1x1_pair_f32_kernel(const PairPara
 // two B rings). Same K order through one accumulator per output element as conv1x1_frag_f32_kernel: bit-identical to the two launches.
 // LDS: x tile [8 NSL0 quarters][33] + chunk [32 quarters][33] 16-byte units = 50 KiB at C0 = 256.
 #define CP32_PITCH 33
-template <int NSL0>
-__global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairParams p)
+// NWV = 8 (r10b): EIGHT waves, two per SIMD -- the chunk of out1 is 256 channels (one column block per wave), and a wave owns ONE column
+// block of out2; half the MFMAs per wave, the same K order per output element (bit-identical). One wave per SIMD (NWV = 4) ran the two
+// GEMM loops at 0.79 of the issue rate: nothing covers a wave's LDS reads, weight loads and the chunk epilogue.
+template <int NSL0, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 1) conv1x1_pair32_f32_kernel(const PairParams p)
 {
     constexpr int XQ = 8 * NSL0;
     constexpr int G1 = 4 * NSL0;
+    constexpr int T2 = 4 * NWV;                             // K steps (8 channels) of the second GEMM per chunk
+    constexpr bool TWO = NWV == 4;                          // two column blocks of out2 per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4 *Xs = reinterpret_cast<float4 *>(smem_raw);     // [XQ][33]
-    float4 *Ys = Xs + XQ * CP32_PITCH;                      // [32 quarters of the chunk][33]
+    float4 *Ys = Xs + XQ * CP32_PITCH;                      // [8 NWV quarters of the chunk (32 NWV channels)][33]
     float *Ysf = reinterpret_cast<float *>(Ys);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lhalf = lane >> 5, l32 = lane & 31;
     const long p0 = (long)blockIdx.x * 32;
-    const int nsl1 = p.C1 >> 5, npass = p.C1 >> 7;
+    const int nsl1 = p.C1 >> 5, npass = p.C1 / (32 * NWV);
 
     const size_t xaddr = reinterpret_cast<size_t>(p.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
@@ -242,10 +247,11 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
     const size_t w3addr = reinterpret_cast<size_t>(p.w3);
     const unsigned w3lo = __builtin_amdgcn_readfirstlane((unsigned)w3addr), w3hi = __builtin_amdgcn_readfirstlane((unsigned)(w3addr >> 32));
     const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w3hi << 32) | w3lo), 0, p.C1 * p.C0 * 4, 0x00020000);
-    // second GEMM: column blocks 2 wave and 2 wave + 1 of out2, contiguous in the packed matrix (nsl1 * 4096 bytes each)
-    const size_t w1addr = reinterpret_cast<size_t>(p.w1) + (size_t)(2 * wave) * (size_t)nsl1 * 4096u;
+    // second GEMM: column blocks 2 wave and 2 wave + 1 of out2 (NWV = 4) or block wave (NWV = 8), contiguous in the packed matrix
+    // (nsl1 * 4096 bytes each)
+    const size_t w1addr = reinterpret_cast<size_t>(p.w1) + (size_t)((TWO ? 2 : 1) * wave) * (size_t)nsl1 * 4096u;
     const unsigned w1lo = __builtin_amdgcn_readfirstlane((unsigned)w1addr), w1hi = __builtin_amdgcn_readfirstlane((unsigned)(w1addr >> 32));
-    const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w1hi << 32) | w1lo), 0, 2 * nsl1 * 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)w1hi << 32) | w1lo), 0, (TWO ? 2 : 1) * nsl1 * 4096, 0x00020000);
     const unsigned w1blk = (unsigned)nsl1 * 4096u;
     const unsigned b_lane = (unsigned)(lhalf * 512 + l32 * 16);
     const int g2max = nsl1 * 4 - 1;
@@ -264,24 +270,26 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
 
 #define CP_LD(D, RS, VO, SO) { const uintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(RS, (VO), (SO), 0); \
         D = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); }
-#define CP_B1(SLOT, J, G) CP_LD(b1r[SLOT], w3rsrc, b_lane, (unsigned)((min((J), npass - 1) * 4 + wave) * G1 + (G)) * 1024u)
+#define CP_B1(SLOT, J, G) CP_LD(b1r[SLOT], w3rsrc, b_lane, (unsigned)((min((J), npass - 1) * NWV + wave) * G1 + (G)) * 1024u)
 #define CP_B2(SLOT, G) { CP_LD(b2a[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u) \
-                         CP_LD(b2b[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u + w1blk) }
+                         if (TWO) CP_LD(b2b[SLOT], w1rsrc, b_lane, (unsigned)min((G), g2max) * 1024u + w1blk) }
 
     float4 b1r[4], b2a[4], b2b[4];
     {   // ---- stage the x tile: thread = (pixel prow, channel quarter q of each 32-channel slab)
-        const int q = tid & 7, prow = tid >> 3;
-        float4 xa[NSL0];
+        // (NWV = 8: the two halves of the workgroup take the even / the odd slabs)
+        constexpr int NST = NSL0 * 4 / NWV;                 // slabs staged per thread
+        const int q = tid & 7, prow = (tid >> 3) & 31, sh = tid >> 8;
+        float4 xa[NST];
         const long pp = p0 + prow;
         const unsigned po = pp < p.M ? (unsigned)pp * 4u * (unsigned)p.C0 + 16u * (unsigned)q : 0x80000000u;
 #pragma unroll
-        for (int s = 0; s < NSL0; ++s) CP_LD(xa[s], xrsrc, po + 128u * (unsigned)s, 0)
+        for (int s = 0; s < NST; ++s) CP_LD(xa[s], xrsrc, po + 128u * (unsigned)(TWO ? s : 2 * s + sh), 0)
 #pragma unroll
         for (int u = 0; u < 4; ++u) CP_B1(u, 0, u)
 #pragma unroll
         for (int u = 0; u < 4; ++u) CP_B2(u, u)
 #pragma unroll
-        for (int s = 0; s < NSL0; ++s) Xs[(8 * s + q) * CP32_PITCH + prow] = xa[s];
+        for (int s = 0; s < NST; ++s) Xs[(8 * (TWO ? s : 2 * s + sh) + q) * CP32_PITCH + prow] = xa[s];
     }
     __syncthreads();
 
@@ -296,11 +304,11 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
         floatx16 acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-        const int co = 128 * j + 32 * wave + l32;
+        const int co = 32 * NWV * j + 32 * wave + l32;
         float rr[16];          // shortcut of this chunk, in flight during the first GEMM
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 512u * (unsigned)j, 0));
+            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 128u * NWV * (unsigned)j, 0));
         {
             float4 a0 = xfrag[0];
 #pragma unroll
@@ -324,32 +332,32 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
             float v = acc0[r] + bv;
             v = v + rr[r];
             v = fmaxf(v, 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o1rsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 512u * (unsigned)j, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o1rsrc, vo1, (unsigned)((r & 3) + 8 * (r >> 2)) * row1 + 128u * NWV * (unsigned)j, 0);
             ydst[((r & 3) + 8 * (r >> 2)) * 4] = v;
         }
         __syncthreads();   // chunk complete in LDS
         {
             float4 a0 = yfrag[0];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < T2; ++t) {
                 float4 n0;
-                if (t + 1 < 16) n0 = yfrag[2 * (t + 1) * CP32_PITCH];
+                if (t + 1 < T2) n0 = yfrag[2 * (t + 1) * CP32_PITCH];
                 const float4 bfa = b2a[t & 3], bfb = b2b[t & 3];
                 __builtin_amdgcn_sched_barrier(0);
                 acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bfa.x, acc2a, 0, 0, 0);
-                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bfb.x, acc2b, 0, 0, 0);
+                if (TWO) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bfb.x, acc2b, 0, 0, 0);
                 acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bfa.y, acc2a, 0, 0, 0);
-                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bfb.y, acc2b, 0, 0, 0);
+                if (TWO) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bfb.y, acc2b, 0, 0, 0);
                 acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bfa.z, acc2a, 0, 0, 0);
-                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bfb.z, acc2b, 0, 0, 0);
+                if (TWO) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bfb.z, acc2b, 0, 0, 0);
                 acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bfa.w, acc2a, 0, 0, 0);
-                acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bfb.w, acc2b, 0, 0, 0);
+                if (TWO) acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bfb.w, acc2b, 0, 0, 0);
                 CP_B2(t & 3, g2 + 4 + t)
-                if (t + 1 < 16) a0 = n0;
+                if (t + 1 < T2) a0 = n0;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        g2 += 16;
+        g2 += T2;
         __syncthreads();   // every read of the chunk is done before the next one overwrites it
     }
 #undef CP_LD
@@ -358,8 +366,8 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
 
     const unsigned row2 = 4u * (unsigned)p.C2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int co2 = 32 * (2 * wave + i) + l32;
+    for (int i = 0; i < (TWO ? 2 : 1); ++i) {
+        const int co2 = 32 * ((TWO ? 2 : 1) * wave + i) + l32;
         const float bv2 = p.b1 != nullptr ? p.b1[co2] : 0.f;
         const unsigned vo2 = ((unsigned)(p0 + 4 * lhalf) * (unsigned)p.C2 + (unsigned)co2) * 4u;
 #pragma unroll
@@ -370,6 +378,10 @@ __global__ void __launch_bounds__(256, 1) conv1x1_pair32_f32_kernel(const PairPa
         }
     }
 }
+
+// development knob: waves per workgroup of the 32-pixel pair kernel (8: two per SIMD, the default; 4: the first r10 form)
+static int g_pair32_waves = 8;
+extern "C" void upsnet_conv1x1_pair32_tuning(int waves) { g_pair32_waves = waves == 4 ? 4 : 8; }
 
 /* out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1) in one launch (see the header of this
  * file). x [pixels, C0], residual / out1 [pixels, C1], out2 [pixels, C2], all NHWC with pixels = N*H*W.
@@ -386,8 +398,16 @@ extern "C" int upsnet_conv1x1_pair_nhwc_f32(void *stream, const float *x, const 
     p.x = x; p.res = residual; p.w3 = w3pack; p.b3 = bias3; p.w1 = w1pack; p.b1 = bias1; p.out1 = out1; p.out2 = out2;
     p.M = pixels; p.C0 = C0; p.C1 = C1; p.C2 = C2;
     if (res4) {   // r10: 32-pixel tiles (csrc comment above conv1x1_pair32_f32_kernel)
-        const size_t smem32 = (size_t)(8 * (C0 / 32) + 32) * CP32_PITCH * 16;
-        hipLaunchKernelGGL((conv1x1_pair32_f32_kernel<8>), dim3((unsigned)((pixels + 31) / 32)), dim3(256), smem32, (hipStream_t)stream, p);
+        if (g_pair32_waves == 8 && C1 % 256 == 0) {      // two waves per SIMD; 66 KiB of LDS (x tile + a 256-channel chunk)
+            const size_t smem8 = (size_t)(8 * (C0 / 32) + 64) * CP32_PITCH * 16;
+            static unsigned long long attr_dev8 = 0;
+            if (ups_first_on_device(attr_dev8))
+                UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_pair32_f32_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            hipLaunchKernelGGL((conv1x1_pair32_f32_kernel<8, 8>), dim3((unsigned)((pixels + 31) / 32)), dim3(512), smem8, (hipStream_t)stream, p);
+        } else {
+            const size_t smem32 = (size_t)(8 * (C0 / 32) + 32) * CP32_PITCH * 16;
+            hipLaunchKernelGGL((conv1x1_pair32_f32_kernel<8, 4>), dim3((unsigned)((pixels + 31) / 32)), dim3(256), smem32, (hipStream_t)stream, p);
+        }
         UPS_CHECK_LAUNCH("conv1x1_pair32_f32_kernel");
         return 0;
     }

@@ -56,6 +56,13 @@ def roi_align_nhwc(features, rois, pooled_h, pooled_w, spatial_scale, sampling_r
     return out
 
 
+def roi_align_algorithmic_bytes(feats, n, C, ph, pw):
+    """the pooled output written once + the ROI records + the feature pixels the ROIs can touch read once (per ROI the
+    (2 ph + 1) x (2 pw + 1) sample neighbourhood of its level, capped at the whole pyramid)."""
+    feat_bytes = 4 * C * sum(f.shape[2] * f.shape[3] for f in feats)
+    return 4.0 * n * C * ph * pw + 20.0 * n + min(feat_bytes, 4.0 * n * C * (2 * ph + 1) * (2 * pw + 1))
+
+
 def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=2, num_rois_dev=None,
                   return_levels=False):
     """FPNRoIAlign.forward on device: feats = 4 logical-NCHW tensors (batch 1), rois [N,5].
@@ -73,10 +80,18 @@ def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio
     dev = rois.device
     out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     levels = torch.empty((max(N, 1),), dtype=torch.int32, device=dev) if return_levels else None
+    if PROFILE['enabled']:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().upsnet_fpn_roi_align_forward(stream(), ptr_array(feats), int_array([f.shape[2] for f in feats]),
                                              int_array([f.shape[3] for f in feats]), float_array(spatial_scale), C,
                                              ptr(rois), N, ptr(num_rois_dev), int(pooled_h), int(pooled_w),
                                              int(sampling_ratio), ptr(out), ptr(levels)), "fpn_roi_align_forward")
+    if PROFILE['enabled']:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        PROFILE['events'].append(('roialign', ev0, ev1, 0.0, roi_align_algorithmic_bytes(feats, N, C, pooled_h, pooled_w),
+                                  'roialign %dx%dx%dx%d' % (N, C, pooled_h, pooled_w)))
     return (out, levels[:N]) if return_levels else out
 
 
@@ -738,6 +753,10 @@ def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, resi
     return out
 
 
+PAIR32_WAVES = int(os.environ.get('UPSNET_CONV1X1_PAIR32_WAVES', '8'))   # waves per workgroup of the 32-pixel pair kernel (res4): 8 (two per SIMD) or 4
+_pair32_waves_set = [None]
+
+
 def conv1x1_pair(x, residual, w3pack, bias3, c1, w1pack, bias1, c2):
     """Tail of one bottleneck and head of the next in one launch (csrc/conv1x1_pair.hip):
     out1 = relu(conv1x1(x; w3) + bias3 + residual), out2 = relu(conv1x1(out1; w1) + bias1); both bit-identical to two
@@ -748,6 +767,9 @@ def conv1x1_pair(x, residual, w3pack, bias3, c1, w1pack, bias1, c2):
     if tuple(res.shape) != (N, c1, H, W):
         raise RuntimeError("conv1x1_pair: residual shape %s != %s" % (tuple(res.shape), (N, c1, H, W)))
     out1, out2 = _nhwc_out(N, c1, H, W, x.device), _nhwc_out(N, c2, H, W, x.device)
+    if _pair32_waves_set[0] != PAIR32_WAVES:
+        lib().upsnet_conv1x1_pair32_tuning(PAIR32_WAVES)
+        _pair32_waves_set[0] = PAIR32_WAVES
     if PROFILE['enabled']:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
