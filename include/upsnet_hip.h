@@ -251,6 +251,11 @@ int upsnet_conv2d_winograd_nhwc_f32_tn32(void *stream, int nseg, const float *co
                                          float *const out[], const int batch[], const int height[], const int width[], int Cin,
                                          const float *wpack, int ldw, const float *bias, int Cout, int relu);
 int upsnet_conv_pack_weight_winograd_tn32(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
+/* One launch of both forms over a batch x [batch, H, W, Cin] (the mask head's 100 ROIs: 616 workgroups of the 32 x 64 form for 512 slots):
+ * images [0, n_main) on 32 x 64 workgroups (wpack / ldw), images [n_main, batch) on 32 x 32 workgroups (wpack32 / ldw32), which the
+ * dispatcher deals out as the main workgroups retire. out [batch, H, W, Cout]; bit-identical to upsnet_conv2d_winograd_nhwc_f32. */
+int upsnet_conv2d_winograd_nhwc_f32_tail(void *stream, const float *x, float *out, int batch, int n_main, int height, int width, int Cin,
+                                         const float *wpack, int ldw, const float *wpack32, int ldw32, const float *bias, int Cout, int relu);
 
 /* Dense convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- BASELINE.json configs[2]
  * ("bf16 compute / fp32 accumulate") and its fp32-equivalent 3-term split. OPT-IN: the fp32 kernel above is the default.

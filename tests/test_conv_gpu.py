@@ -701,25 +701,49 @@ def test_winograd_32_channel_form_is_bit_identical(N, Cin, Cout, H, W, relu):
     np.testing.assert_allclose(a.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_winograd_tail_split_of_a_batched_launch():
-    """hipconv: 100 ROIs of 14 x 14 on the 32 x 64 form are 616 workgroups = 1.2 rounds; the first 83 ROIs (one full round) stay on it,
-    the last 17 run on the 32-channel form -- the same bits as the unsplit launch, for every ROI."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_winograd_tail_split_of_a_batched_launch(fused, monkeypatch):
+    """hipconv: 100 ROIs of 14 x 14 on the 32 x 64 form are 616 workgroups = 1.2 rounds; the first 80 ROIs stay on it,
+    the last 20 (one half-size workgroup per CU) run on the 32-channel form -- in the same launch (conv_wino16_tail_f32_kernel) or as a second one -- the same bits as the
+    unsplit launch, for every ROI."""
+    from upsnet_amd import ops
     from upsnet_amd.models import hipconv
     torch.manual_seed(3)
     m = torch.nn.Conv2d(256, 256, 3, 1, 1).cuda()
     x = torch.randn(100, 256, 14, 14, device='cuda').contiguous(memory_format=torch.channels_last)
-    was, hipconv.WINO_TAIL_SPLIT = hipconv.WINO_TAIL_SPLIT, True      # (opt-in: UPSNET_WINO_TAIL_SPLIT=1)
-    assert hipconv._wino_tail_split(m, x) == 83 and hipconv._wino_tail_split(m, x[:64]) == 0
+    monkeypatch.setattr(hipconv, 'WINO_TAIL_SPLIT', True)
+    monkeypatch.setattr(hipconv, 'WINO_TAIL_FUSED', fused)
+    assert hipconv._wino_tail_split(m, x) == 80 and hipconv._wino_tail_split(m, x[:64]) == 0
     hipconv.TRACE = []
     try:
         with torch.no_grad():
             y = hipconv.conv(m, x, relu=True, winograd='always')
-            form = hipconv.TRACE[-1]['form']
+            form, kform = hipconv.TRACE[-1]['form'], ops.last_kernel_form()
             hipconv.WINO_TAIL_SPLIT = False
             y0 = hipconv.conv(m, x, relu=True, winograd='always')
     finally:
-        hipconv.TRACE, hipconv.WINO_TAIL_SPLIT = None, was
+        hipconv.TRACE = None
     assert form == 'winograd tm32 + tail tn32' and torch.equal(y, y0)
+    assert kform == ('wino_tail<512,256>' if fused else 'wino<0,32,32>')
+
+
+@pytest.mark.parametrize("N,n_main,C,Cout,H,W,relu", [(7, 3, 32, 64, 14, 14, True), (5, 4, 64, 192, 9, 11, False), (100, 83, 256, 256, 14, 14, True)])
+def test_winograd_tail_entry_point(N, n_main, C, Cout, H, W, relu):
+    """upsnet_conv2d_winograd_nhwc_f32_tail: images [0, n_main) on 32 x 64 workgroups and the rest on 32 x 32 workgroups in one launch ==
+    the plain launch bit for bit, 1e-4 vs float64; odd maps, ragged tiles, Cout not a multiple of 128."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + C)
+    x = torch.randn(N, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, C, 3, 3, device='cuda') / (3 * C ** 0.5)
+    b = torch.randn(Cout, device='cuda')
+    wp, ldw = ops.pack_winograd_weight(w)
+    wp32, ldw32 = ops.pack_winograd_weight(w, tn32=True)
+    y = ops.conv2d_winograd_tail(x, wp, ldw, wp32, ldw32, b, Cout, n_main, relu=relu)
+    y0 = ops.conv2d_winograd_multi([x], wp, ldw, b, Cout, relu=relu)[0]
+    assert torch.equal(y, y0)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = ref.clamp_min(0) if relu else ref
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks,relu,res", [

@@ -96,7 +96,7 @@ def _check_model(preset, h, w, seed, need_forms, min_shapes):
         update_config_dict(CITYSCAPES_R50)
 
 
-_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd tm64', 'winograd tm32', 'winograd splitk', 'igemm', 'igemm splitk',
+_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd tm64', 'winograd tm32', 'winograd tm32 + tail tn32', 'winograd splitk', 'igemm', 'igemm splitk',
              'igemm multi cat', 'deconv2x2', 'dcn_fused multi']
 
 

@@ -48,7 +48,7 @@ __device__ static inline float2 f2add(const float2 a, const float2 b) { return m
 // TN: output channels per workgroup. 64, or 32 (only with TM = 32) for the narrow heads (the DCN offset convolutions, Cout = 18,
 // would waste 46 of 64 columns): one 32x32 block, the 16 positions split over FOUR waves (4 accumulators each).
 template <bool SPLITK, int TM, int TN>
-__global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kernel(const ConvParams p)
+__device__ __forceinline__ void conv_wino16_body(const ConvParams &p, const int wg)
 {
     static_assert(TN == 64 || (TN == 32 && TM == 32), "tile forms: 64x64, 32x64, 32x32");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
         const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
         const int base_grid = 8 * per * nt;
-        kz = SPLITK ? (int)blockIdx.x / base_grid : 0;
-        const int bid = (int)blockIdx.x - kz * base_grid;
+        kz = SPLITK ? wg / base_grid : 0;
+        const int bid = wg - kz * base_grid;
         const int q = bid >> 3;
         n_t = q % nt;
         const int local = q / nt;
@@ -336,6 +336,23 @@ __global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kern
 #undef WG_STORE_ROW
 }
 
+template <bool SPLITK, int TM, int TN>
+__global__ void __launch_bounds__(8 * TM, TM == 64 ? 1 : 2) conv_wino16_f32_kernel(const ConvParams p)
+{
+    conv_wino16_body<SPLITK, TM, TN>(p, (int)blockIdx.x);
+}
+
+// r10: a launch whose 32 x 64 tiling ends in a nearly empty last round (the mask head: 100 ROIs = 616 workgroups for 512 slots) as ONE
+// launch of two forms: workgroups [0, main_grid) are the 32 x 64 tiles of the first images (pm: as many as fill whole rounds), the rest
+// 32 x 32 tiles of the remaining images (pt, weights in the 32-channel packing) -- half the work each, dealt out by the dispatcher as the
+// main workgroups retire, so the tail of the launch is balanced over the CUs instead of leaving most of them idle behind a few full-size
+// stragglers. Same arithmetic per output element as either form alone (bit-identical).
+__global__ void __launch_bounds__(256, 2) conv_wino16_tail_f32_kernel(const ConvParams pm, const ConvParams pt, const int main_grid)
+{
+    if ((int)blockIdx.x < main_grid) conv_wino16_body<false, 32, 64>(pm, (int)blockIdx.x);
+    else conv_wino16_body<false, 32, 32>(pt, (int)blockIdx.x - main_grid);
+}
+
 // Launch: p is a filled 3x3 / stride 1 / pad 1 description (conv_fill) whose Ho, Wo already count 2x2 output tiles.
 // p.ksplit > 1: one map, partial sums into p.partial (the caller runs the reduction).
 template <int TM, int TN>
@@ -492,6 +509,38 @@ extern "C" int upsnet_conv2d_winograd_nhwc_f32_tn32(void *stream, int nseg, cons
     int rc = wino_fill(p, "conv2d_winograd_nhwc_f32_tn32", nseg, x, residual, out, batch, height, width, Cin, Cout, wpack, ldw, bias, relu);
     if (rc) return rc;
     return conv_wino16_launch((hipStream_t)stream, p, 1);
+}
+
+/* One launch over a batch x [N, H, W, Cin]: images [0, n_main) on 32-tile x 64-channel workgroups (wpack / ldw from
+ * upsnet_conv_pack_weight_winograd), images [n_main, N) on 32 x 32 workgroups (wpack32 / ldw32 from ..._winograd_tn32) -- see
+ * conv_wino16_tail_f32_kernel. out [N, H, W, Cout]. Bit-identical to upsnet_conv2d_winograd_nhwc_f32 on the whole batch. */
+extern "C" int upsnet_conv2d_winograd_nhwc_f32_tail(void *stream, const float *x, float *out, int batch, int n_main, int height, int width,
+                                                    int Cin, const float *wpack, int ldw, const float *wpack32, int ldw32, const float *bias,
+                                                    int Cout, int relu)
+{
+    UPS_REQUIRE(x && out && wpack && wpack32 && n_main > 0 && n_main < batch && ldw % 64 == 0 && ldw32 % 32 == 0 && Cin % 16 == 0,
+                "conv2d_winograd_nhwc_f32_tail: 0 < n_main < batch, ldw %% 64 == 0, ldw32 %% 32 == 0, Cin %% 16 == 0");
+    ConvParams pm, pt;
+    const float *xm[1] = {x}, *xt[1] = {x + (size_t)n_main * height * width * Cin};
+    float *om[1] = {out}, *ot[1] = {out + (size_t)n_main * height * width * Cout};
+    const int nm[1] = {n_main}, nt[1] = {batch - n_main}, hh[1] = {height}, ww[1] = {width};
+    int rc = wino_fill(pm, "conv2d_winograd_nhwc_f32_tail", 1, xm, nullptr, om, nm, hh, ww, Cin, Cout, wpack, ldw, bias, relu);
+    if (rc) return rc;
+    rc = wino_fill(pt, "conv2d_winograd_nhwc_f32_tail", 1, xt, nullptr, ot, nt, hh, ww, Cin, Cout, wpack32, ldw32, bias, relu);
+    if (rc) return rc;
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 28) && (long)batch * height * width * Cout < (1L << 29),
+                "conv2d_winograd_nhwc_f32_tail: feature map exceeds 1 GiB; split the batch");
+    pm.seg[0].tile_start = 0; pm.m_tiles = (int)((pm.seg[0].M + 31) / 32); pm.n_tiles = ldw / 64;
+    pt.seg[0].tile_start = 0; pt.m_tiles = (int)((pt.seg[0].M + 31) / 32); pt.n_tiles = ldw32 / 32;
+    const int main_grid = 8 * ((pm.m_tiles + 7) / 8) * pm.n_tiles, tail_grid = 8 * ((pt.m_tiles + 7) / 8) * pt.n_tiles;
+    const size_t smem = 2 * 16 * 4 * 32 * 16;
+    static unsigned long long attr_dev = 0;
+    if (ups_first_on_device(attr_dev))
+        UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino16_tail_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(conv_wino16_tail_f32_kernel, dim3(main_grid + tail_grid), dim3(256), smem, (hipStream_t)stream, pm, pt, main_grid);
+    UPS_CHECK_LAUNCH("conv_wino16_tail_f32_kernel");
+    ups_set_form("wino_tail<%d,%d>", main_grid, tail_grid);
+    return 0;
 }
 
 extern "C" int upsnet_conv2d_winograd_nhwc_f32_splitk(void *stream, const float *x, const float *residual, float *out, int batch, int height,

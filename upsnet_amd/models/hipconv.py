@@ -343,8 +343,9 @@ def _winograd_plan(m, tn32=False):
     return ent[1], ent[2]
 
 
-WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '0') == '1'   # measured r10: 114.5 vs 117-121 us per mask-head layer (3 %); the 17-ROI tail
-# launches run at 35 % of their MFMA time -- off by default (opt-in, tested)
+WINO_TAIL_SPLIT = os.environ.get('UPSNET_WINO_TAIL_SPLIT', '1') != '0'   # r10: the mask head's last partial round on half-size workgroups IN the
+# same launch (conv_wino16_tail_f32_kernel): 117 -> 107.5 us per layer in the model (graph-timed alone: 127.7 -> 99.5); as a second launch
+# (UPSNET_WINO_TAIL_FUSED=0) it was 114.5
 
 
 def _wino_tail_split(m, x):
@@ -362,15 +363,24 @@ def _wino_tail_split(m, x):
     if wgs <= slots or _wino_tm(m, [x]) != 32:
         return 0
     n_main = ((wgs // slots) * slots // nt) * 32 // tiles
+    # the tail as large as still fits one half-size workgroup per CU (100 ROIs: 80 + 20 -- 99.5 us against 102.5 for 83 + 17)
+    fit = (cus // (m.out_channels // 32)) * 32 // tiles
+    n_main = min(n_main, n - fit) if n - fit > 0 else n_main
     tail = n - n_main
     if n_main <= 0 or tail <= 0 or -(-(tail * tiles) // 32) * (m.out_channels // 32) > cus:
         return 0
     return n_main
 
 
+WINO_TAIL_FUSED = os.environ.get('UPSNET_WINO_TAIL_FUSED', '1') != '0'   # both forms in ONE launch (conv_wino16_tail_f32_kernel); 0: two launches
+
+
 def _wino_split_launch(m, x, n_main, relu):
-    out = ops._nhwc_out(x.shape[0], m.out_channels, x.shape[2], x.shape[3], x.device)
     wp, ldw = _winograd_plan(m)
+    if WINO_TAIL_FUSED:
+        wp32, ldw32 = _winograd_plan(m, tn32=True)
+        return ops.conv2d_winograd_tail(x, wp, ldw, wp32, ldw32, m.bias, m.out_channels, n_main, relu=relu)
+    out = ops._nhwc_out(x.shape[0], m.out_channels, x.shape[2], x.shape[3], x.device)
     ops.conv2d_winograd_multi([x[:n_main]], wp, ldw, m.bias, m.out_channels, relu=relu, outs=[out[:n_main]])
     wp32, ldw32 = _winograd_plan(m, tn32=True)
     ops.conv2d_winograd_multi([x[n_main:]], wp32, ldw32, m.bias, m.out_channels, relu=relu, outs=[out[n_main:]], tn32=True)

@@ -1116,6 +1116,28 @@ def conv2d_winograd_splitk(x, wpack, ldw, bias, cout, ksplit, relu=False, residu
     return out
 
 
+def conv2d_winograd_tail(x, wpack, ldw, wpack32, ldw32, bias, cout, n_main, relu=False):
+    """3x3 / stride 1 / pad 1 Winograd convolution of a batch in ONE launch of two workgroup forms (csrc/conv_wino.hip,
+    conv_wino16_tail_f32_kernel): images [0, n_main) on 32 x 64 tiles, the rest on 32 x 32 tiles (wpack32 from
+    pack_winograd_weight(w, tn32=True)). Bit-identical to conv2d_winograd_multi([x], ...)."""
+    require_cuda(wpack, wpack32, x)
+    x = nhwc(x.float())
+    N, C, H, W = x.shape
+    out = _nhwc_out(N, cout, H, W, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_winograd_nhwc_f32_tail(stream(), ptr(x), ptr(out), int(N), int(n_main), int(H), int(W), int(C), ptr(wpack), int(ldw),
+                                                     ptr(wpack32), int(ldw32), ptr(None if bias is None else f32c(bias)), int(cout),
+                                                     int(bool(relu))), "conv2d_winograd_nhwc_f32_tail")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * H * W
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * C * 9 * npix, 4.0 * (C * npix + cout * npix + cout * C * 9),
+                                  "winograd 3x3/1 %d->%d [%s] tail %d" % (C, cout, (N, H, W), N - n_main)))
+    return out
+
+
 def conv2d_winograd_multi(xs, wpack, ldw, bias, cout, relu=False, residuals=None, outs=None, tn32=False):
     """3x3 / stride 1 / pad 1 convolution of up to 5 maps (shared weights) by fused Winograd F(2x2,3x3); same contract as
     conv2d_nhwc_multi. outs: caller-provided channels_last outputs (e.g. batch slices of one tensor); tn32: the 32-channel workgroup
