@@ -215,14 +215,14 @@ __global__ void __launch_bounds__(256, 3) conv1x1_pair_f32_kernel(const PairPara
 }
 
 // r10: the same pair on 32-PIXEL tiles for the stride-16 map (res4: 256 -> 1024 -> 256). A 64-pixel tile would leave 128 workgroups for the
-// 8192 pixels of a 1024x2048 image; 32 pixels give 256 = one per CU, and one 4-wave workgroup keeps its CU's matrix pipe busy by itself.
-// A wave owns one 32-column block of each 128-channel chunk of out1 (one row block: acc0) and TWO column blocks of out2 (2 wave, 2 wave + 1;
-// two B rings). Same K order through one accumulator per output element as conv1x1_frag_f32_kernel: bit-identical to the two launches.
-// LDS: x tile [8 NSL0 quarters][33] + chunk [32 quarters][33] 16-byte units = 50 KiB at C0 = 256.
+// 8192 pixels of a 1024x2048 image; 32 pixels give 256 = one per CU.
+// NWV = 8 (the default): EIGHT waves, two per SIMD. out1 is produced in chunks of 256 channels; a wave owns one 32-column block of each
+// chunk (one row block: acc0) and ONE column block of out2. NWV = 4 (the first form, UPSNET_CONV1X1_PAIR32_WAVES=4): chunks of 128
+// channels, TWO column blocks of out2 per wave (2 wave, 2 wave + 1; two B rings) -- one wave per SIMD ran the two GEMM loops at 0.79 of the
+// issue rate (nothing covers a wave's LDS reads, weight loads and the chunk epilogue): 78.1 us per launch against 73.5 with eight.
+// Same K order through one accumulator per output element as conv1x1_frag_f32_kernel in both forms: bit-identical to the two launches.
+// LDS: x tile [8 NSL0 quarters][33] + chunk [8 NWV quarters][33] 16-byte units = 66 KiB (NWV = 8) / 50 KiB (NWV = 4) at C0 = 256.
 #define CP32_PITCH 33
-// NWV = 8 (r10b): EIGHT waves, two per SIMD -- the chunk of out1 is 256 channels (one column block per wave), and a wave owns ONE column
-// block of out2; half the MFMAs per wave, the same K order per output element (bit-identical). One wave per SIMD (NWV = 4) ran the two
-// GEMM loops at 0.79 of the issue rate: nothing covers a wave's LDS reads, weight loads and the chunk epilogue.
 template <int NSL0, int NWV>
 __global__ void __launch_bounds__(64 * NWV, 1) conv1x1_pair32_f32_kernel(const PairParams p)
 {
