@@ -361,6 +361,12 @@ int upsnet_conv_pack_weight(void *stream, const float *weight, int cout, int cin
 int upsnet_conv1x1_frag_nhwc_f32(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width,
                                  int Cin, const float *wpack, const float *bias, int Cout, int stride, int relu, int residual_up);
 void upsnet_conv1x1_tuning(int bn);
+/* Two 1x1 convolutions of the same input in one launch -- conv1 and the projection shortcut (`downsample`) of a stage's first bottleneck
+ * (upsnet/models/resnet.py:53-100 reads x twice): out_a [N,Ho,Wo,cout_a] from rows [0, cout_a) of the concatenated weight, out_b
+ * [N,Ho,Wo,cout_b] from the rest; wpack = upsnet_dcn_pack_weight of the concatenated [cout_a + cout_b, Cin, 1, 1] weight, bias = both
+ * biases concatenated (or NULL), cout_a % 32 == 0. Bit-identical to two upsnet_conv1x1_frag_nhwc_f32 launches. */
+int upsnet_conv1x1_siblings_nhwc_f32(void *stream, const float *x, float *out_a, float *out_b, int batch, int height, int width, int Cin,
+                                     const float *wpack, const float *bias, int cout_a, int cout_b, int stride, int relu_a, int relu_b);
 /* development knob: waves per workgroup of the 32-pixel form of upsnet_conv1x1_pair_nhwc_f32 (8: two per SIMD, default; 4). */
 void upsnet_conv1x1_pair32_tuning(int waves);
 

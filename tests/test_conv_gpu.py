@@ -137,6 +137,30 @@ def test_conv1x1_pair_kernel_res4(N, H, W, C1, waves, monkeypatch):
     np.testing.assert_allclose(o2.cpu().numpy(), r2.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,Cin,H,W,ca,cb,stride", [(1, 64, 40, 56, 64, 256, 1), (2, 256, 37, 41, 128, 512, 2), (1, 1024, 16, 32, 512, 2048, 2),
+                                                     (1, 512, 9, 7, 256, 1024, 2), (1, 32, 33, 17, 96, 40, 1), (1, 64, 256, 512, 64, 256, 1)])
+def test_conv1x1_sibling_launch(N, Cin, H, W, ca, cb, stride):
+    """csrc/conv1x1.hip, sibling mode: conv1 (+ ReLU) and the projection shortcut of a stage's first bottleneck (same input, same stride)
+    in one launch over the concatenated output channels -- each output bit-identical to a launch of its own, 1e-4 vs float64; both tile
+    widths, a split inside a 128-channel tile (64 + 256), a ragged last column block, the res2 map at 1024x2048."""
+    from upsnet_amd import ops
+    torch.manual_seed(N + Cin + ca)
+    x = torch.randn(N, Cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    wa, wb = torch.randn(ca, Cin, 1, 1, device='cuda') / Cin ** 0.5, torch.randn(cb, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    ba, bb = torch.randn(ca, device='cuda'), torch.randn(cb, device='cuda')
+    ya, yb = ops.conv1x1_siblings(x, ops.pack_conv1x1_weight(torch.cat([wa, wb])), torch.cat([ba, bb]), ca, cb, stride, relu_a=True, relu_b=False)
+    assert ops.last_kernel_form() == 'conv1x1_siblings<%d+%d>' % (ca, cb)
+    sa = ops.conv1x1_frag(x, ops.pack_conv1x1_weight(wa), ba, ca, stride, relu=True)
+    sb = ops.conv1x1_frag(x, ops.pack_conv1x1_weight(wb), bb, cb, stride, relu=False)
+    assert torch.equal(ya, sa) and torch.equal(yb, sb)
+    ra = F.conv2d(x.double(), wa.double(), ba.double(), stride=stride).clamp_min(0)
+    rb = F.conv2d(x.double(), wb.double(), bb.double(), stride=stride)
+    np.testing.assert_allclose(ya.cpu().numpy(), ra.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(yb.cpu().numpy(), rb.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    y0, _ = ops.conv1x1_siblings(x, ops.pack_conv1x1_weight(torch.cat([wa, wb])), None, ca, cb, stride, relu_a=False, relu_b=True)
+    assert torch.equal(y0, ops.conv1x1_frag(x, ops.pack_conv1x1_weight(wa), None, ca, stride, relu=False))
+
+
 @pytest.mark.parametrize("N,H,W,C1", [(1, 64, 96, 256), (2, 37, 41, 256), (1, 9, 7, 128), (1, 40, 40, 384)])
 def test_conv1x1_pair_kernel(N, H, W, C1):
     """csrc/conv1x1_pair.hip: relu(conv3(x) + b3 + shortcut) and relu(conv1(that) + b1) in one launch -- bit-identical to two launches

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "upsnet_deform_conv_fused_nhwc_bf16": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 7 + [P, P, c_int]),
     "upsnet_conv1x1_frag_nhwc_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int]),
     "upsnet_conv1x1_tuning": (None, [c_int]),
+    "upsnet_conv1x1_siblings_nhwc_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv1x1_pair32_tuning": (None, [c_int]),
     "upsnet_conv1x1_splitk_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv1x1_frag_nhwc_f32_splitk": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P]),

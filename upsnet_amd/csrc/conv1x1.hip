@@ -180,12 +180,24 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     // SCALAR row offset per element -- no 64-bit address arithmetic per element (r07: ~8 VALU instructions for each of the 64 loads /
     // stores of a lane, and 5 spilled registers in the 128-wide form); rows beyond the map and padded columns are out-of-range
     // offsets (loads return 0, stores are dropped), so there is no per-element predicate either.
-    const int co = 32 * cb + l32;
-    const bool co_ok = co < p.Cout;
-    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+    // Sibling launch (MODE 0, p.sib_split > 0: conv1 and the projection shortcut of a stage's first bottleneck read the same input): this
+    // wave's 32-column block belongs to the first layer (columns below the split: its own output tensor, width, ReLU flag) or to the second --
+    // wave-uniform, the split is a multiple of 32.
+    int co = 32 * cb + l32;
+    int cw = p.Cout, relu_f = p.relu;
+    float *obase = sg.out;
+    const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    if (MODE == 0 && p.sib_split > 0) {
+        const bool second = 32 * cb >= p.sib_split;
+        cw = second ? p.Cout - p.sib_split : p.sib_split;
+        co = second ? co - p.sib_split : co;
+        obase = second ? p.sib_out : sg.out;
+        relu_f = second ? p.sib_relu : p.relu;
+    }
+    const bool co_ok = co < cw;
     const bool has_res = sg.res != nullptr;
-    const unsigned crow = (unsigned)p.Cout * 4u;                        // bytes of one output pixel (MODE 2: of the four pixels of a row)
-    const size_t oaddr = reinterpret_cast<size_t>(sg.out);
+    const unsigned crow = (unsigned)cw * 4u;                            // bytes of one output pixel (MODE 2: of the four pixels of a row)
+    const size_t oaddr = reinterpret_cast<size_t>(obase);
     const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)oaddr), ohi = __builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32));
     const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)sg.M * crow);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)ohi << 32) | olo), 0, (int)obytes, 0x00020000);
@@ -292,7 +304,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
             float v = i == 0 ? acc0[r] : acc1[r];
             if (p.bias != nullptr) v = v + bv;
             if (has_res) v = v + rr[r];
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (relu_f) v = fmaxf(v, 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, lane_off, row0 + (unsigned)((r & 3) + 8 * (r >> 2)) * crow, 0);
         }
     }
@@ -382,6 +394,30 @@ extern "C" int upsnet_conv1x1_frag_nhwc_f32_splitk(void *stream, const float *x,
     rc = conv1x1_frag_launch((hipStream_t)stream, p, 3);
     if (rc) return rc;
     return conv_splitk_reduce((hipStream_t)stream, p.partial, ksplit, p.m_total, p.seg[0].M, Cout, bias, residual, relu, out);
+}
+
+/* Two 1x1 convolutions of the SAME input in one launch (conv1 and the projection shortcut of a stage's first bottleneck, resnet.py:53-100):
+ * out_a [N,Ho,Wo,cout_a] = relu_a?(conv(x; rows [0, cout_a) of the weight) + bias), out_b [N,Ho,Wo,cout_b] likewise from the remaining rows.
+ * wpack: upsnet_dcn_pack_weight of the concatenated [cout_a + cout_b, Cin, 1, 1] weight; bias: the two biases concatenated (or NULL);
+ * cout_a % 32 == 0. Every output element is computed exactly as in a launch of its own layer (bit-identical). */
+extern "C" int upsnet_conv1x1_siblings_nhwc_f32(void *stream, const float *x, float *out_a, float *out_b, int batch, int height, int width,
+                                                int Cin, const float *wpack, const float *bias, int cout_a, int cout_b, int stride, int relu_a,
+                                                int relu_b)
+{
+    UPS_REQUIRE(out_a && out_b && cout_a > 0 && cout_b > 0 && cout_a % 32 == 0, "conv1x1_siblings_nhwc_f32: two outputs, cout_a %% 32 == 0 (got %d, %d)", cout_a, cout_b);
+    const int Cout = cout_a + cout_b;
+    const float *xs[1] = {x};
+    float *os[1] = {out_a};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    const int ldw = (Cout + 31) / 32 * 32;
+    int rc = conv_fill(p, "conv1x1_siblings_nhwc_f32", 1, xs, nullptr, nullptr, nullptr, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias, 1, 1, stride, 0, 1, relu_a);
+    if (rc) return rc;
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "conv1x1_siblings_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    p.sib_split = cout_a; p.sib_relu = relu_b; p.sib_out = out_b;
+    rc = conv1x1_frag_launch((hipStream_t)stream, p, 0);
+    if (rc == 0) ups_set_form("conv1x1_siblings<%d+%d>", cout_a, cout_b);
+    return rc;
 }
 
 /* ConvTranspose2d(kernel 2, stride 2, pad 0) (+ bias, + ReLU) on the same kernel (MODE 2): x [N,H,W,Cin] NHWC -> out [N,2H,2W,Cout] NHWC.

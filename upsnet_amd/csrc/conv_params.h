@@ -30,6 +30,10 @@ struct ConvParams {
     float *partial;    // [ksplit][sum of M over the maps][Cout] (workspace), reduced by conv_splitk_reduce_kernel
     long m_total;      // sum of M over the maps
     int io;            // conv_bf16.hip: bit 0 / 1 / 2 = the input / output / residual tensors are bf16 instead of fp32
+    // conv1x1.hip, sibling launch: output channels [sib_split, Cout) belong to a second layer on the same input -- they go to sib_out (an
+    // [M, Cout - sib_split] tensor) with ReLU flag sib_relu; channels [0, sib_split) to seg[0].out ([M, sib_split]) with p.relu. 0: one layer
+    int sib_split, sib_relu;
+    float *sib_out;
 };
 
 // Validates the arguments of a convolution entry point and fills the per-map descriptors (output geometry, pixel counts).
@@ -46,7 +50,7 @@ static inline int conv_fill(ConvParams &p, const char *who, int nseg, const floa
     UPS_REQUIRE((long)KH * KW * Cin * ldw < (1L << 30), "%s: packed weight exceeds 4 GiB", who);
     p.w = wpack; p.bias = bias; p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.ldw = ldw; p.KH = KH; p.KW = KW;
     p.stride = stride; p.pad = pad; p.dil = dil; p.relu = relu; p.res_up = 0;
-    p.ksplit = 1; p.partial = nullptr; p.m_total = 0; p.io = 0;
+    p.ksplit = 1; p.partial = nullptr; p.m_total = 0; p.io = 0; p.sib_split = 0; p.sib_relu = 0; p.sib_out = nullptr;
     int tiles = 0;
     for (int i = 0; i < CV_MAXSEG; ++i) {
         ConvSeg &s = p.seg[i];

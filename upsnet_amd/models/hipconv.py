@@ -239,6 +239,35 @@ def conv_pair(m3, m1, x, residual):
     return out1, out2
 
 
+SIBLINGS = os.environ.get('UPSNET_CONV1X1_SIBLINGS', '1') != '0'
+
+
+def use_siblings(ma, mb, x):
+    """conv1 (ma, + ReLU) and the projection shortcut (mb) of a stage's first bottleneck read the same map with the same stride: one launch
+    over the concatenated output channels (csrc/conv1x1.hip, sibling mode) reads it once and saves a kernel boundary. fp32 mode only."""
+    if not (SIBLINGS and CONV1X1 and PRECISION == 'fp32' and isinstance(ma, nn.Conv2d) and isinstance(mb, nn.Conv2d) and supported(ma, x) and
+            supported(mb, x) and x.dtype == torch.float32):
+        return False
+    ok = lambda m: tuple(m.kernel_size) == (1, 1) and tuple(m.padding) == (0, 0) and m.groups == 1 and m.stride[0] in (1, 2)
+    return (ok(ma) and ok(mb) and ma.stride == mb.stride and ma.in_channels == mb.in_channels and ma.in_channels % 32 == 0 and
+            ma.out_channels % 32 == 0 and (ma.bias is None) == (mb.bias is None))
+
+
+def conv_siblings(ma, mb, x, relu_a=True, relu_b=False):
+    """(relu_a?(ma(x)), relu_b?(mb(x))) in one launch -- see use_siblings. Bit-identical to the two launches."""
+    key = tuple((m.weight.data_ptr(), m.weight._version, tuple(m.weight.shape), None if m.bias is None else m.bias._version) for m in (ma, mb))
+    ent = _plans(ma).get('siblings')
+    if ent is None or ent[0] != key:
+        wp = ops.pack_conv1x1_weight(torch.cat([ma.weight.detach(), mb.weight.detach()], 0))
+        b = None if ma.bias is None else torch.cat([ma.bias.detach(), mb.bias.detach()], 0).contiguous()
+        ent = (key, wp, b)
+        _plans(ma)['siblings'] = ent
+    ya, yb = ops.conv1x1_siblings(x, ent[1], ent[2], ma.out_channels, mb.out_channels, ma.stride[0], relu_a=relu_a, relu_b=relu_b)
+    _trace('conv', module=ma, x=x, out=ya, relu=relu_a, residual=None, residual_up=False, form='conv1x1 siblings(a)')
+    _trace('conv', module=mb, x=x, out=yb, relu=relu_b, residual=None, residual_up=False, form='conv1x1 siblings(b)')
+    return ya, yb
+
+
 def supported(m, x):
     return (ENABLED and isinstance(m, nn.Conv2d) and x.is_cuda and
             (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and PRECISION == 'bf16')) and

@@ -74,7 +74,12 @@ class _Block(nn.Module):
         if y1 is None and hipconv.use_block(self, x):      # bf16 mode: the whole identity block as one launch
             return hipconv.block(self, x), None
         ad = hipconv.act_dtype()
-        y = hipconv.conv(self.conv1, x, relu=True, out_dtype=torch.float32 if self.deformable else ad) if y1 is None else y1
+        shortcut = None
+        if y1 is None and self.downsample is not None and hipconv.use_siblings(self.conv1, self.downsample[0], x):
+            # first block of a stage: conv1 and the projection shortcut read the same map -- one launch over both sets of output channels
+            y, shortcut = hipconv.conv_siblings(self.conv1, self.downsample[0], x)
+        else:
+            y = hipconv.conv(self.conv1, x, relu=True, out_dtype=torch.float32 if self.deformable else ad) if y1 is None else y1
         if self.deformable:
             off = hipconv.conv(self.conv2_offset, y)
             y, y_in = hipconv.dcn(self.conv2, y, off, relu=True), y
@@ -82,7 +87,8 @@ class _Block(nn.Module):
                            form='dcn_fused' + (' bf16' if hipconv.ops.dcn_precision() == 'bf16' else ''))
         else:
             y = hipconv.conv(self.conv2, y, relu=True, out_dtype=ad)
-        shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x, out_dtype=ad)
+        if shortcut is None:
+            shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x, out_dtype=ad)
         if nxt is not None and isinstance(nxt.bn1, nn.Identity) and hipconv.use_pair(self.conv3, nxt.conv1, y, shortcut):
             return hipconv.conv_pair(self.conv3, nxt.conv1, y, shortcut)
         return hipconv.conv(self.conv3, y, relu=True, residual=shortcut, out_dtype=ad), None

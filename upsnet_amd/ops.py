@@ -753,6 +753,29 @@ def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, resi
     return out
 
 
+def conv1x1_siblings(x, wpack, bias, cout_a, cout_b, stride=1, relu_a=True, relu_b=False):
+    """Two 1x1 convolutions of the same input in one launch (csrc/conv1x1.hip, sibling mode): rows [0, cout_a) of the concatenated weight
+    -> out_a (ReLU flag relu_a), the remaining cout_b rows -> out_b. wpack: pack_conv1x1_weight(torch.cat([w_a, w_b])); bias: both biases
+    concatenated or None. Bit-identical to two conv1x1_frag calls. Returns two channels_last tensors."""
+    require_cuda(wpack, x)
+    x = nhwc(x.float())
+    N, cin, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out_a, out_b = _nhwc_out(N, cout_a, Ho, Wo, x.device), _nhwc_out(N, cout_b, Ho, Wo, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv1x1_siblings_nhwc_f32(stream(), ptr(x), ptr(out_a), ptr(out_b), N, H, W, int(cin), ptr(wpack),
+                                                 ptr(None if bias is None else f32c(bias)), int(cout_a), int(cout_b), int(stride),
+                                                 int(bool(relu_a)), int(bool(relu_b))), "conv1x1_siblings_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix, cout = N * Ho * Wo, cout_a + cout_b
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * npix, 4.0 * (cin * npix + cout * npix + cout * cin),
+                                  "direct 1x1/%d siblings %d->%d+%d [%s] (gemm)" % (stride, cin, cout_a, cout_b, (N, H, W))))
+    return out_a, out_b
+
+
 PAIR32_WAVES = int(os.environ.get('UPSNET_CONV1X1_PAIR32_WAVES', '8'))   # waves per workgroup of the 32-pixel pair kernel (res4): 8 (two per SIMD) or 4
 _pair32_waves_set = [None]
 
