@@ -1,3 +1,5 @@
+"""Mask head 3x3 layer (N ROIs x 256 x 14 x 14) on the Winograd kernel: the 32 x 64 form, the 32 x 32 form, and both in one launch
+(conv_wino16_tail_f32_kernel) for several main / tail splits; graph-replay-timed (r10, profiles/HISTORY.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, torch.nn as nn
