@@ -141,33 +141,39 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     __syncthreads();
     float4 a0, a1;
     C1_FRAG(0, 0, a0, a1)
+    // The K steps are walked in PAIRS with the LDS buffer index static (step t in buffer 0, t + 1 in buffer 1): every LDS address of the loop
+    // is an immediate and the loop has one form (as `cur = (t - s_begin) & 1` the compiler unrolled it by two itself and kept a remainder
+    // copy, across which it spilled 5 registers). An odd number of steps ends in one step past s_end: its activations read as 0 (C1_FETCH),
+    // its weights are the last valid ones (C1_BLOAD clamps), so it adds exact zeros.
+#define C1_STEP(T, CUR)                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                                   \
+        float4 n0_, n1_;                                                                                               \
+        if (u < NU - 1) C1_FRAG(CUR, u + 1, n0_, n1_)                                                                  \
+        if (u == 1) C1_STASH((CUR) ^ 1, xa0, xa1)         /* step T+1 (fetched during step T-1); after the last step: zeros, unread */ \
+        if (u == 2) C1_FETCH((T) + 2, xa0, xa1)                                                                        \
+        if (u == NU - 1) { __syncthreads(); C1_FRAG((CUR) ^ 1, 0, n0_, n1_) }                                          \
+        const float4 bf_ = breg[u];                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);                                       \
+        if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);                          \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);                                       \
+        if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf_.y, acc1, 0, 0, 0);                          \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);                                       \
+        if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);                          \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);                                       \
+        if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);                          \
+        C1_BLOAD(u, g + NU + u)                                                                                        \
+        a0 = n0_;                                                                                                      \
+        if (NR == 2) a1 = n1_;                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                  \
+    g += NU;
     int g = 4 * s_begin;
-    for (int t = s_begin; t < s_end; ++t) {
-        const int cur = (t - s_begin) & 1;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            float4 n0_, n1_;
-            if (u < NU - 1) C1_FRAG(cur, u + 1, n0_, n1_)
-            if (u == 1) C1_STASH(cur ^ 1, xa0, xa1)       // step t+1 (fetched during step t-1); after the last step: zeros, unread
-            if (u == 2) C1_FETCH(t + 2, xa0, xa1)
-            if (u == NU - 1) { __syncthreads(); C1_FRAG(cur ^ 1, 0, n0_, n1_) }
-            const float4 bf_ = breg[u];
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf_.x, acc0, 0, 0, 0);
-            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf_.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf_.y, acc0, 0, 0, 0);
-            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf_.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bf_.z, acc0, 0, 0, 0);
-            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bf_.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bf_.w, acc0, 0, 0, 0);
-            if (NR == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bf_.w, acc1, 0, 0, 0);
-            C1_BLOAD(u, g + NU + u)
-            a0 = n0_;
-            if (NR == 2) a1 = n1_;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        g += NU;
+    for (int t = s_begin; t < s_end; t += 2) {
+        C1_STEP(t, 0)
+        C1_STEP(t + 1, 1)
     }
+#undef C1_STEP
 #undef C1_LDX
 #undef C1_FETCH
 #undef C1_STASH
