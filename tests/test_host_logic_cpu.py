@@ -160,6 +160,26 @@ def test_conv_instance_selection_rules():
     assert hipconv._ksplit(c3, x(1, 64, 128), 256) == 1 and hipconv._ksplit(nn.Conv2d(256, 1024, 1), x(1, 64, 128), 1024) == 1
 
 
+def test_mask_head_tail_split_rule(monkeypatch):
+    """hipconv, r10: the mask head's batched Winograd launch is split into main + half-size tail only where the tail fits one half-size
+    workgroup per CU. Shape-only decisions."""
+    import torch
+    import torch.nn as nn
+    from upsnet_amd.models import hipconv
+    monkeypatch.setattr(hipconv, '_cus', lambda device: 256)
+    monkeypatch.setattr(hipconv, 'WINO_TAIL_SPLIT', True)
+    c3 = nn.Conv2d(256, 256, 3, padding=1)
+    x = lambda n, h=14, w=14, c=256: torch.empty(n, c, h, w, device='meta')
+    assert hipconv._wino_tail_split(c3, x(100)) == 80          # 616 workgroups for 512 slots: 80 ROIs + 20 on half-size workgroups (248 <= 256)
+    assert hipconv._wino_tail_split(c3, x(83)) == 0            # exactly one round
+    assert hipconv._wino_tail_split(c3, x(64)) == 0 and hipconv._wino_tail_split(c3, x(1)) == 0
+    assert hipconv._wino_tail_split(c3, x(143)) == 0           # the tail (60 ROIs) would be 736 half-size workgroups
+    assert hipconv._wino_tail_split(c3, x(200)) == 0
+    assert hipconv._wino_tail_split(nn.Conv2d(256, 96, 3, padding=1), x(100)) == 0     # Cout % 64
+    monkeypatch.setattr(hipconv, 'WINO_TAIL_SPLIT', False)
+    assert hipconv._wino_tail_split(c3, x(100)) == 0
+
+
 def test_knobs_report_set_variables_and_reject_unknown_names():
     """bench hygiene (VERDICT r03 #8): every UPSNET_* variable that is set goes into the bench line; a name no source file reads is an error."""
     from upsnet_amd import knobs
