@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
     }
     const bool co_ok = co < cw;
     const bool has_res = sg.res != nullptr;
-    const unsigned crow = (unsigned)cw * 4u;                            // bytes of one output pixel (MODE 2: of the four pixels of a row)
+    // (wave-uniform: readfirstlane makes that visible to the compiler -- the scalar-offset operands of the epilogue's buffer loads / stores
+    // derived from it were otherwise materialised in VGPRs and every one of the 64 accesses of a lane wrapped in a waterfall loop)
+    const unsigned crow = __builtin_amdgcn_readfirstlane((unsigned)cw * 4u);   // bytes of one output pixel (MODE 2: of the four pixels of a row)
     const size_t oaddr = reinterpret_cast<size_t>(obase);
     const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)oaddr), ohi = __builtin_amdgcn_readfirstlane((unsigned)(oaddr >> 32));
     const unsigned obytes = __builtin_amdgcn_readfirstlane((unsigned)sg.M * crow);
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
         const unsigned lane_p = co_ok ? (4u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const unsigned row0 = (unsigned)(p0 + 32 * (NR == 2 ? i : wm)) * crow;
+            const unsigned row0 = __builtin_amdgcn_readfirstlane((unsigned)(p0 + 32 * (NR == 2 ? i : wm)) * crow);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(i == 0 ? acc0[r] : acc1[r]), prsrc, lane_p, row0 + (unsigned)((r & 3) + 8 * (r >> 2)) * crow, 0);
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const long pb0 = p0 + 32 * (NR == 2 ? i : wm);                 // first of the 32 consecutive output pixels of this block (wave-uniform)
-        const unsigned row0 = (unsigned)pb0 * crow;
+        const unsigned row0 = __builtin_amdgcn_readfirstlane((unsigned)pb0 * crow);
         float rr[16];
         if (has_res) {
             if (RESUP && (sg.Wo & 31) == 0) {
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256, 4) conv1x1_frag_f32_kernel(const ConvPara
                 const int n_b = (int)(pb / HoWo);
                 const int rem_b = (int)(pb - (long)n_b * HoWo);
                 const int h_b = rem_b / sg.Wo, w_b = rem_b - h_b * sg.Wo;      // w_b: multiple of 32
-                const unsigned rb = (unsigned)(((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1)) * crow;
+                const unsigned rb = __builtin_amdgcn_readfirstlane((unsigned)(((long)n_b * Hr + (h_b >> 1)) * Wr + (w_b >> 1)) * crow);
                 const unsigned lane_r = co_ok ? (2u * (unsigned)lhalf * crow + 4u * (unsigned)co) : 0x80000000u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
