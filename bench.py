@@ -431,6 +431,38 @@ def main():
                                   % (h, w, sc, dt, ' / '.join('%.2f' % t for t in times), cores, os.cpu_count()),
                         'sample_seconds': round(dt, 2), 'stages_s': {k: round(v, 2) for k, v in stages.items()},
                         'n_inst': out_cpu['n_inst']}
+        # report-only: how far apart do the fp32 product and this independent fp32 execution of the same graph
+        # (resnet_upsnet.py:197-248; torch-CPU convolutions + the oracle's ops) land on the SAME image, free-running end to end? Every
+        # bit-exact claim of the repository is per stage on identical inputs (oracle/forward.py check_taps); this one number shows the
+        # composition: the two differ only where an fp32 rounding difference flips a decision (an NMS / threshold margin, an argmax tie).
+        # Instance ids depend on the instance ORDER, so the id-free class map (stuff class, or the class of the pixel's instance) is
+        # compared as well.
+        import numpy as np
+        from upsnet_amd.config.config import config
+        g_, o_ = res['model'].use_graph, res['model'].overlap_streams
+        res['model'].use_graph, res['model'].overlap_streams = False, False
+        with torch.no_grad():
+            out_gpu = res['model'](make_image(h, w, seed=0, device=res['image']['data'].device))
+        res['model'].use_graph, res['model'].overlap_streams = g_, o_
+        pg, pc_ = out_gpu['panoptic_outputs'][0].cpu().numpy(), np.asarray(out_cpu['panoptic_outputs']).reshape(-1, *out_gpu['panoptic_outputs'].shape[-2:])[0]
+        n_stuff = config.dataset.num_seg_classes - config.dataset.num_classes + 1
+
+        def class_map(pan, cls_inds):     # ids: 0 .. n_stuff-1 = stuff classes, n_stuff + k = instance k, 255 = void (resnet_upsnet.py:234-243)
+            cls_inds = np.asarray(cls_inds).astype(np.int64).reshape(-1)
+            out = pan.copy()
+            inst = (pan >= n_stuff) & (pan != 255)
+            out[inst] = n_stuff + cls_inds[pan[inst] - n_stuff] - 1
+            return out
+        cg = class_map(pg, out_gpu['panoptic_cls_inds'].cpu().numpy())
+        cc = class_map(pc_, out_cpu['panoptic_cls_inds'])
+        sg, sc_ = out_gpu['fcn_outputs'].cpu().numpy().reshape(pg.shape), np.asarray(out_cpu['fcn_outputs']).reshape(pg.shape)
+        cpu_baseline['label_agreement'] = {
+            'panoptic_label_map': round(float((pg == pc_).mean()), 6), 'panoptic_class_map': round(float((cg == cc).mean()), 6),
+            'semantic_argmax': round(float((sg == sc_).mean()), 6), 'n_inst_product': int(out_gpu['panoptic_cls_inds'].numel()),
+            'n_inst_cpu': int(out_cpu['n_inst']), 'n_det_product': int(out_gpu['cls_inds'].numel()), 'n_det_cpu': int(out_cpu['n_det']),
+            'note': 'report-only: fraction of pixels of the SAME seeded image (seed 0, %dx%d) on which the product (fp32 MFMA kernels) and the CPU '
+                    'baseline (torch-CPU fp32 convolutions + the oracle ops), both free-running end to end, give the same panoptic id / the same '
+                    'class (id-free) / the same semantic arg-max. Not a parity test: parity is per stage on identical inputs (tests/)' % (h, w)}
 
     last = res['last_out']
     # after the timed region: the last image once more, eagerly (no HIP graph, no side stream) -- the label map of the timed

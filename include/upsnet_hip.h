@@ -67,8 +67,9 @@ int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], 
 
 /* Development knob of upsnet_fpn_roi_align_forward: 0 = LDS tap-table kernel, one register set; 1 = two sets;
  * 2 = the r03-r07 kernel (per-bin tap setup in registers); 3 = the table kernel loading only the UNIQUE corner cells of a bin (r11);
- * 4 = 3 with packed fp32 blend arithmetic; < 0 (default) = automatic: 3 for launches with >= 100 bins per ROI, else 0. All variants return the
- * same bits. upsnet_roi_geometry: the bins of a ROI are split over
+ * 4 = 3 with packed fp32 blend arithmetic; < 0 = back to the default behaviour: the environment variable UPSNET_ROI_KERNEL (a variant number)
+ * if set, else automatic -- 3 for launches with >= 100 bins per ROI, else 0. A call with variant >= 0 overrides the variable. All variants
+ * return the same bits. upsnet_roi_geometry: the bins of a ROI are split over
  * workgroups until the launch has `target_workgroups` (default 1536), at least `min_bins` (default 8) bins each; 0 = default. */
 void upsnet_roi_tuning(int variant);
 void upsnet_roi_geometry(int target_workgroups, int min_bins);
@@ -377,8 +378,10 @@ int upsnet_conv1x1_siblings_nhwc_f32(void *stream, const float *x, float *out_a,
 void upsnet_conv1x1_pair32_tuning(int waves);
 
 /* 3x3 / stride 1 / pad 1 convolution (+ bias, ReLU) of up to 5 NHWC maps sharing weights by Winograd F(4x4, 3x3) (csrc/conv_wino36.hip,
- * r11): 36 multiplies per 16 outputs, 0.5625 of the F(2x2) kernel's matrix work. Interpolation points {0, 1, -1, 1/2, -2, inf}: within
- * rtol = atol = 1e-4 of float64 on the model's layers with a margin of >= 10 (tools/winograd_error_cpu.py, tests/test_conv_gpu.py). The
+ * r11 / r12): 36 multiplies per 16 outputs, 0.5625 of the F(2x2) kernel's matrix work. Interpolation points {0, 3/4, -3/4, 3/2, -3/2, inf}:
+ * within rtol = atol = 1e-4 of float64 on the model's layers, measured worst error 0.07-0.15 of that bound at the model's shapes (3-4x the
+ * F(2x2) kernel's 0.014-0.032; tools/bench_winograd36.py), asserted <= 0.35 in tests/test_conv_gpu.py (small maps and the real 1024x2048
+ * sizes). H, W of any size (maps with H < 4 take the bounds-flagged loads throughout). The
  * contract of upsnet_conv2d_winograd_nhwc_f32 without a residual; Cin % 32 == 0; wpack (36 * Cin * ldw floats, ldw = Cout rounded up to
  * 64) from upsnet_conv_pack_weight_winograd36 (weight [Cout, Cin, 3, 3]). */
 int upsnet_conv2d_winograd36_nhwc_f32(void *stream, int nseg, const float *const x[], float *const out[], const int batch[],

@@ -87,6 +87,13 @@ def test_dcn_backbone_config():
     assert all(isinstance(l, DCNBottleneck) for l in b.res3.layers) and all(isinstance(l, DCNBottleneck) for l in b.res5.layers)
     assert not any(isinstance(l, DCNBottleneck) for l in b.res2.layers)
     assert 'res4.layers.22.conv2_offset.weight' in b.state_dict()
+    # r13 routing rule: the plain 3x3 layers upstream of the deformable chain (res2) stay off the F(4x4) Winograd form
+    assert all(l.feeds_deformable for l in b.res2.layers)
+    assert not any(l.feeds_deformable for n in ('res3', 'res4', 'res5') for l in getattr(b, n).layers)
+    from upsnet_amd.config.config import CITYSCAPES_R50
+    update_config_dict(CITYSCAPES_R50)
+    b50 = ResNetBackbone([3, 4, 6, 3])
+    assert not any(l.feeds_deformable for n in ('res2', 'res3', 'res4', 'res5') for l in getattr(b50, n).layers)
 
 
 def test_fold_frozen_bn_is_exact_reparameterisation():

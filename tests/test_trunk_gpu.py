@@ -24,9 +24,9 @@ def _err(got, ref):
 
 
 def _run(preset, h, w, seed, strict, report_only=()):
-    """strict: names that must be within rtol = atol = 1e-4 (elementwise) of the float64 value (or, where a plain fp32 library execution is
-    itself beyond 0.9 of that bound, no more than 1.25x as far from the float64 value as the library); report_only: names that are compared
-    and printed but not asserted. Every other name must be within 1e-4 OR at most 3x as far from the float64 value as a plain fp32
+    """strict: names that must be within rtol = atol = 1e-4 (elementwise) of the float64 value -- no escape clause (the r11 one, "as close
+    as an fp32 library execution that is itself beyond 0.9 of the bound", is gone: r13 keeps the 3x3 layers upstream of a deformable chain
+    on the F(2x2) form instead, models/resnet.py _Block.feeds_deformable); report_only: names that are compared and printed but not asserted. Every other name must be within 1e-4 OR at most 3x as far from the float64 value as a plain fp32
     library execution of the same graph (torch / MIOpen convolutions, oracle.dense_ref in float32) -- since r08 (calibrated synthetic
     statistics, activations O(1-10) as in a trained network) no tensor of either model needs that escape.
 
@@ -90,11 +90,6 @@ def _run(preset, h, w, seed, strict, report_only=()):
             if not ok and name not in strict and name not in report_only:
                 ok = max_abs <= 3.0 * lib_abs
                 ent['criterion'] = '<= 3x the fp32 library execution'
-            if not ok and name in strict and lib_worst > 0.9:
-                # (r11) a tensor the fp32 LIBRARY execution itself cannot hold within 1e-4 (UPSNet-101-DCN @1024x2048, the offset prediction
-                # of the 30th deformable bottleneck: library 1.001 of the bound): the product must then be as close as the library, +25 %
-                ok = max_abs <= 1.25 * lib_abs
-                ent['note'] = 'fp32 library execution at %.3f of the bound; product within 1.25x its distance' % lib_worst
             rep[name] = ent
             if not ok and name not in report_only:
                 bad[name] = ent

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
     //    of column 0, (h0 + 1, w0 + 1) for the other 25 -- each non-negative wherever one of its elements lies inside the image; and (b)
     //    origin + scalar offset may point up to 4 rows + 4 pixels beyond the element's own image: harmless inside the tensor (the next
     //    image), NOT allowed beyond its end -- so
-    //  * SAFE (workgroups holding tiles of the last two tile rows of the last image, `risky`): the r10 form, every load with its own
+    //  * SAFE (workgroups whose last tile could reach beyond the end of the tensor, `risky` -- the last 1-2 tile rows of the last image): the r10 form, every load with its own
     //    per-lane offset, rows / columns outside the image flagged beyond the bounds (no access, reads 0). 16 of FPN P2's 1024 workgroups.
     int hrow0, wcol0;            // n * H + h0 (h0 = 4 ty - 1), w0 = 4 tx - 1
     int hlo, hhi;                // valid range of hrow0 + r: [n * H, n * H + H) (empty for a tile beyond the map: every row reads 0)
@@ -144,7 +144,16 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
         tbase = (unsigned)(hrow0 * sg.W + wcol0) * (4u * (unsigned)p.Cin) + 4u * (unsigned)lch;
     }
     const bool fix = __builtin_amdgcn_ballot_w64(lane_fix) != 0ull;
-    const bool risky = p0 + W36_TM > sg.M - 2 * (long)sg.Wo;          // workgroup-uniform
+    // workgroup-uniform, from the real extent (r13; the r12 rule "last two tile rows of the last image" assumed H > 3): the FAST loads of a
+    // tile (n, ty, tx) reach pixel (4 ty + 4, 4 tx + 4) of image n -- up to 4 pixels into map row n H + 4 ty + 5 -- and tiles are ordered
+    // by (n, ty, tx), so the workgroup's LAST tile decides: that row must exist inside the tensor
+    bool risky;
+    {
+        const long plast = min(p0 + (long)W36_TM, sg.M) - 1;
+        const long nl = plast / HoWo;
+        const long tyl = (plast - nl * HoWo) / sg.Wo;
+        risky = nl * sg.H + 4 * tyl + 5 >= (long)sg.N * sg.H;
+    }
     const unsigned cin4 = 4u * (unsigned)p.Cin;
     const unsigned rowpitch = (unsigned)sg.W * cin4;
     const unsigned cin4_s = __builtin_amdgcn_readfirstlane(cin4);
@@ -375,8 +384,8 @@ extern "C" int upsnet_conv2d_winograd36_nhwc_f32(void *stream, int nseg, const f
     return 0;
 }
 
-// weight [Cout, Cin, 3, 3] -> U = G g G^T (double precision, rounded once), G = [[1,0,0],[1/3,1/3,1/3],[-1/3,1/3,-1/3],[-16/15,-8/15,-4/15],
-// [1/15,-2/15,4/15],[0,0,1]], stored in fragment order [n-tile = co/64][slab = c/16][xi = 6i+j][q = (c%16)/4][co%64][c%4]
+// weight [Cout, Cin, 3, 3] -> U = G g G^T (double precision, rounded once), G of the points {0, 3/4, -3/4, 3/2, -3/2, inf} =
+// [[64/81,0,0],[-128/243,-32/81,-8/27],[-128/243,32/81,-8/27],[32/243,16/81,8/27],[32/243,-16/81,8/27],[0,0,1]], stored in fragment order [n-tile = co/64][slab = c/16][xi = 6i+j][q = (c%16)/4][co%64][c%4]
 __global__ void conv_pack_weight_wino36_kernel(const float *__restrict__ w, int cout, int cin, int ldw, float *__restrict__ wp)
 {
     const long total = (long)ldw * cin;

@@ -582,9 +582,11 @@ static int prop_select_compact(hipStream_t st, const PropLevels &lv, int nlev, i
 }
 
 // dynamic LDS of the per-level sort kernels: M2 = pre_n rounded up to a power of two (>= 64) keys of 8 bytes; > 64 KiB is opted into
-template <typename K>
-static int prop_sort_lds(K kernel, int pre_n, int *M2_out)
+// (templated on the kernel's VALUE: each kernel gets its own once-per-device flag, whatever its signature)
+template <auto KERNEL>
+static int prop_sort_lds(int pre_n, int *M2_out)
 {
+    constexpr auto kernel = KERNEL;
     const int M2 = ups_next_pow2(pre_n < 64 ? 64 : pre_n);
     *M2_out = M2;
     if ((size_t)M2 * 8 > 64 * 1024) {
@@ -634,7 +636,7 @@ extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const fl
     if (int rc = prop_select_compact(st, lv, nlev, maxn, pre_n, kbuf[0], kbuf[1], hist, sel)) return rc;
     // sort + decode + the NMS's visiting order in one launch (the survivors of every level at key_off[l] of kbuf[1]); then mask + scan
     int M2;
-    if (int rc = prop_sort_lds(&prop_sort_decode_kernel, pre_n, &M2)) return rc;
+    if (int rc = prop_sort_lds<&prop_sort_decode_kernel>(pre_n, &M2)) return rc;
     float4 *nms_sorted_boxes;
     int *nms_order;
     ups_nms_ws_views(nms_ws, nlev, pre_n, &nms_sorted_boxes, &nms_order);
@@ -691,7 +693,7 @@ extern "C" int upsnet_pyramid_proposals_joint_strided(void *stream, int nlev, co
     UPS_CHECK_LAUNCH("prop_key_joint_kernel");
     if (int rc = prop_select_compact(st, one, 1, (int)total, pre_n, kbuf[0], kbuf[1], hist, sel)) return rc;
     int M2;
-    if (int rc = prop_sort_lds(&prop_sortk_kernel, pre_n, &M2)) return rc;
+    if (int rc = prop_sort_lds<&prop_sortk_kernel>(pre_n, &M2)) return rc;
     hipLaunchKernelGGL(prop_sortk_kernel, dim3(1), dim3(M2 < 1024 ? M2 : 1024), (size_t)M2 * 8, st, one, sel, kbuf[1], pre_n, M2);
     UPS_CHECK_LAUNCH("prop_sortk_kernel");
     hipLaunchKernelGGL(prop_decode_joint_kernel, dim3((pre_n + 255) / 256), dim3(256), 0, st, lv, jt, kbuf[1], sel, pre_n, im_info,

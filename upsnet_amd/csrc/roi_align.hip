@@ -672,7 +672,9 @@ fpn_roi_align_nhwc_tab_kernel(const FpnFeat ft, const int channels, const float 
 // cells of a bin (r11); 4: the same with packed fp32 blend arithmetic; A/B knob (also env UPSNET_ROI_KERNEL)
 static int g_roi_variant = -1;
 static int g_roi_target_wg = 1536, g_roi_min_bins = 8;
-extern "C" void upsnet_roi_tuning(int variant) { g_roi_variant = variant < 0 ? -2 : variant; }   // < 0: automatic choice
+// >= 0: that variant, whatever the environment says; < 0: back to the default behaviour (the environment variable is read again at the
+// next launch: UPSNET_ROI_KERNEL = a variant number, or unset / "auto" / negative = the automatic choice)
+extern "C" void upsnet_roi_tuning(int variant) { g_roi_variant = variant < 0 ? -1 : variant; }
 // development knob: the bins of a ROI are split over workgroups until the launch has `target_workgroups`, `min_bins` bins each at least
 extern "C" void upsnet_roi_geometry(int target_workgroups, int min_bins)
 {
@@ -681,7 +683,10 @@ extern "C" void upsnet_roi_geometry(int target_workgroups, int min_bins)
 }
 static int roi_variant(const int bins)
 {
-    if (g_roi_variant == -1) { const char *e = getenv("UPSNET_ROI_KERNEL"); g_roi_variant = e ? atoi(e) : -2; }
+    if (g_roi_variant == -1) {
+        const char *e = getenv("UPSNET_ROI_KERNEL");
+        g_roi_variant = (e && *e && (*e >= '0' && *e <= '9')) ? atoi(e) : -2;     // unset, "auto", "-1": automatic
+    }
     if (g_roi_variant >= 0) return g_roi_variant;
     // auto (r11, measured on random ROIs, profiles/r11_roialign.txt): the corner-sharing form where the samples of a bin usually fall into
     // shared cells -- 14 x 14 bins: half a cell apart, 21.8 vs 24.0 us at 100 ROIs --, the plain table form for 7 x 7 bins (a cell apart:

@@ -56,7 +56,8 @@ REGISTRY = {
     'UPSNET_NMS_SCAN16': ('1', 'csrc/nms.hip', 'unrolled scan for <= 1024 boxes'),
     'UPSNET_OVERLAP': ('1', 'models/resnet_upsnet.py', 'semantic branch on a side stream'),
     'UPSNET_PIN': ('1', 'upsnet_end2end_test.py', 'pin each rank to its CPU slice'),
-    'UPSNET_ROI_KERNEL': ('0', 'csrc/roi_align.hip', 'ROIAlign kernel variant'),
+    'UPSNET_ROI_KERNEL': ('auto', 'csrc/roi_align.hip', 'ROIAlign kernel variant 0..4; auto = 3 (corner-sharing) for >= 100 bins per ROI, else 0 -- so '
+                                                        '"0" is NOT the default; upsnet_roi_tuning(v >= 0) overrides the variable, (v < 0) returns to it'),
     'UPSNET_ROI_PER_BIN': ('0', 'csrc/roi_align.hip', 'one wave per (roi, bin) (older decomposition)'),
     'UPSNET_SHARE_GPU': ('0', 'upsnet_end2end_test.py', 'let N ranks share one GPU (functional runs of the N > 1 path)'),
     'UPSNET_SPLITK': ('1', 'models/hipconv.py', 'split-K forms for small maps'),

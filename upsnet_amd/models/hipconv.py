@@ -49,8 +49,8 @@ WINOGRAD = os.environ.get('UPSNET_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_WORKGROUPS = int(os.environ.get('UPSNET_WINOGRAD_MIN_WG', '128'))
 WINO_TM64_MIN = int(os.environ.get('UPSNET_WINO_TM64_MIN', '768'))   # 64-tile Winograd workgroups above this many (csrc/conv_wino.hip reads the same)
 # r11: the largest of those layers (>= one workgroup of 32 4x4-tiles x 64 channels per CU, last round at least WINO36_MIN_FILL full: FPN P2 / P3,
-# the 5-level RPN launch, res2's 3x3) go through the F(4x4,3x3) kernel (csrc/conv_wino36.hip): 4 multiplies per output instead of 9
-# (F(2x2): 2.25), 1.4-1.6x faster than F(2x2) there (tools/bench_winograd36.py), slower on small maps. Its rounding error is 3-4x that of
+# the 5-level RPN launch, res2's 3x3) go through the F(4x4,3x3) kernel (csrc/conv_wino36.hip): 2.25 multiplies per output instead of 9
+# (F(2x2): 4), 1.4-1.6x faster than F(2x2) there (tools/bench_winograd36.py), slower on small maps. Its rounding error is 3-4x that of
 # F(2x2) (tools/winograd_error_cpu.py: <= 0.08 of the layer tolerance tests/test_layerwise_gpu.py allows); UPSNET_WINO36=0 switches it off.
 WINO36 = os.environ.get('UPSNET_WINO36', '1') != '0'
 WINO36_ROI = os.environ.get('UPSNET_WINO36_ROI', '0') != '0'   # the mask head (pinned kernel choice) on the F(4x4) form as well: same-box A/B 167.6 vs
@@ -530,7 +530,8 @@ def conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=
 
 def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin=False, out_dtype=None):
     """residual_up: `residual` is at half resolution and is added through a nearest x2 upsampling (FPN top-down add).
-    winograd=False / 'always' pins the direct / the Winograd form; pin=True (implied by 'always') makes every kernel choice
+    winograd=False / 'always' pins the direct / the Winograd form; 'f2x2' = the usual choice WITHOUT the F(4x4,3x3) form (3x3 layers upstream
+    of a chain of deformable bottlenecks: models/resnet.py, _Block.feeds_deformable); pin=True (implied by 'always') makes every kernel choice
     (bf16 or fp32, lean 1x1 GEMM or general kernel) independent of the batch size, for layers fed by ROI batches whose size
     varies at run time: the logits of a ROI must not depend on how many other ROIs share the launch."""
     if supported(m, x):

@@ -34,6 +34,12 @@ class _Block(nn.Module):
     """1x1(stride) -> 3x3 (plain or deformable) -> 1x1(x4), each followed by frozen BN; residual add; ReLU."""
     expansion = 4
     deformable = False
+    # (r13) True on a plain bottleneck that lies UPSTREAM of a deformable one (ResNetBackbone sets it): its 3x3 stays on the F(2x2) Winograd
+    # form. The F(4x4) form's rounding error is 3-4x larger, and a chain of deformable layers multiplies an upstream difference by the
+    # local feature gradient per layer -- UPSNet-101-DCN at 1024x2048: the 30th offset prediction at 1.069 of the 1e-4 bound with res2's
+    # three 3x3 layers on F(4x4), 0.918 with them on F(2x2) (profiles/r12_parity.txt, r11_parity.txt). Costs 3 x ~13 us there, nothing on
+    # UPSNet-50 (no deformable bottleneck in its backbone).
+    feeds_deformable = False
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, fix_bn=True, deformable_group=1):
         super().__init__()
@@ -86,7 +92,7 @@ class _Block(nn.Module):
             hipconv._trace('dcn', module=self.conv2, xs=[y_in], offsets=[off], outs=[y], relu=True, 
                            form='dcn_fused' + (' bf16' if hipconv.ops.dcn_precision() == 'bf16' else ''))
         else:
-            y = hipconv.conv(self.conv2, y, relu=True, out_dtype=ad)
+            y = hipconv.conv(self.conv2, y, relu=True, out_dtype=ad, winograd='f2x2' if self.feeds_deformable else True)
         if shortcut is None:
             shortcut = x if self.downsample is None else hipconv.conv(self.downsample[0], x, out_dtype=ad)
         if nxt is not None and isinstance(nxt.bn1, nn.Identity) and hipconv.use_pair(self.conv3, nxt.conv1, y, shortcut):
@@ -166,6 +172,10 @@ class ResNetBackbone(nn.Module):
                                                (512, blocks[3], r5)], start=3):
             kind = DCNBottleneck if dconv_from <= idx else Bottleneck
             setattr(self, 'res%d' % idx, res_block(planes, n, block=kind, fix_bn=self.fix_bn, **kw))
+        blocks_in_order = [b for name in ('res2', 'res3', 'res4', 'res5') for b in getattr(self, name).layers]
+        last_dcn = max([i for i, b in enumerate(blocks_in_order) if b.deformable], default=-1)
+        for b in blocks_in_order[:last_dcn + 1]:
+            b.feeds_deformable = not b.deformable
 
     def forward(self, x):
         feats = []
