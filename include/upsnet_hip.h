@@ -389,6 +389,24 @@ int upsnet_conv2d_winograd36_nhwc_f32(void *stream, int nseg, const float *const
                                       int Cout, int relu);
 int upsnet_conv_pack_weight_winograd36(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
 
+/* 1x1 convolution (stride 1 / 2; + bias, + residual, ReLU) on SMALL tiles (csrc/conv1x1_ksw.hip, r13): `v_mfma_f32_16x16x4_f32` fragments,
+ * every wave of a workgroup holds the whole tile_pixels x tile_channels tile and walks a quarter of K straight from the NHWC map (no LDS /
+ * barrier in the K loop); the four partial tiles are added in LDS in a fixed order ((w0 + w1) + (w2 + w3): bit-repeatable, independent
+ * of the batch size for a given tile). For maps the 64-pixel tiles of upsnet_conv1x1_frag_nhwc_f32 do not spread evenly over the CUs
+ * (UPSNet-101-DCN at 800x1333: 4200-pixel maps; the layers replaced are the bottlenecks' conv1 / conv3, upsnet/models/resnet.py:53-153).
+ * Tiles (pixels x channels of a workgroup; anything else is an error): split_n == 0 -- 16 x 64, 32 x 32, 32 x 64, 64 x 64, the waves split K
+ * as described; split_n == 1 -- 16 x 256, 32 x 128, 32 x 256: the four waves split the tile's CHANNELS instead and each walks all of K (no
+ * reduction; for a short K walk into many channels, a bottleneck's conv3). x [N,H,W,Cin] NHWC, out [N,Ho,Wo,Cout] NHWC,
+ * residual like out or NULL; Cin % 16 == 0, Cout % 4 == 0, all pointers 16-byte aligned. wpack: upsnet_conv1x1_ksw_packed_weight_floats
+ * floats from upsnet_conv1x1_ksw_pack_weight (weight [Cout, Cin]). Finite weights assumed (a K step beyond a wave's share multiplies
+ * zeros by the last valid weights). upsnet_conv1x1_ksw_tuning(1000 split_n + 100 RB + CB of a wave's tile): development knob forcing an instance (0: the caller's). */
+size_t upsnet_conv1x1_ksw_packed_weight_floats(int cout, int cin);
+int upsnet_conv1x1_ksw_pack_weight(void *stream, const float *weight, int cout, int cin, float *wpack);
+int upsnet_conv1x1_ksw_nhwc_f32(void *stream, const float *x, const float *residual, float *out, int batch, int height, int width, int Cin,
+                                const float *wpack, const float *bias, int Cout, int stride, int relu, int tile_pixels, int tile_channels,
+                                int split_n);
+void upsnet_conv1x1_ksw_tuning(int tile);
+
 /* upsnet_conv1x1_frag_nhwc_f32 with the K walk of every tile split over `ksplit` (2..16) workgroups + the shared reduce / epilogue
  * kernel (bias, residual, ReLU; fixed summation order: bit-repeatable). For maps whose tile count does not spread evenly over the CUs:
  * a workgroup of this kernel keeps all four SIMDs of its CU at the MFMA rate, so a launch lasts (most workgroups on one CU) x (one K

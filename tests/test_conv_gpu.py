@@ -797,6 +797,43 @@ def test_conv1x1_frag_splitk(N, Cin, Cout, H, W, ks, relu, res):
     assert torch.equal(out, ops.conv1x1_frag(x, wp, b, Cout, 1, relu=relu, residual=r, ksplit=ks))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride,relu,res,bias", [
+    (1, 1024, 256, 50, 84, 1, True, False, True),     # UPSNet-101-DCN res4 conv1 at 800x1333 (4200 pixels: ragged last tile for every tile size)
+    (1, 256, 1024, 50, 84, 1, True, True, True),      # res4 conv3 + residual
+    (2, 128, 512, 13, 9, 1, False, True, False),      # two images, 234 pixels, no bias
+    (1, 512, 256, 27, 43, 2, True, False, True),      # stride 2, odd map
+    (1, 32, 64, 7, 5, 1, False, False, True),         # Cin = 32: two 16-channel steps for four waves (two waves walk nothing)
+    (1, 80, 36, 6, 6, 1, True, True, True),           # Cin % 32 != 0 (5 steps), Cout % 16 != 0 (padded column blocks), Cout % 4 == 0
+    (3, 2048, 128, 5, 5, 1, True, False, True),       # long K walk, 75 pixels
+])
+def test_conv1x1_ksw_vs_fp64(N, Cin, Cout, H, W, stride, relu, res, bias):
+    """csrc/conv1x1_ksw.hip (r13: 16x16x4 MFMA fragments, K split over the four waves of a workgroup, no LDS in the K loop): every tile
+    (K split over the waves: 16x64, 32x32, 32x64, 64x64; N split: 16x256, 32x128, 32x256) within rtol = atol = 1e-4 of float64, bit-repeatable, bit-identical for a pixel whatever the batch it
+    is launched in (the tile decides the summation order, not the batch), and within fp32 summation-order distance of the 64-pixel kernel."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 1, 1, device='cuda') / Cin ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, Cout, Ho, Wo, device='cuda').contiguous(memory_format=torch.channels_last) if res else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride) + (r.double() if res else 0)
+    ref = ref.clamp_min(0) if relu else ref
+    wk = ops.pack_conv1x1_ksw_weight(w)
+    frag = ops.conv1x1_frag(x, ops.pack_conv1x1_weight(w), b, Cout, stride, relu=relu, residual=r) if (Cin % 32 == 0 and Cout >= 32) else None
+    for tile, sn in [((16, 64), 0), ((32, 32), 0), ((32, 64), 0), ((64, 64), 0), ((16, 256), 1), ((32, 128), 1), ((32, 256), 1)]:
+        y = ops.conv1x1_ksw(x, wk, b, Cout, tile, stride=stride, relu=relu, residual=r, split_n=sn)
+        assert ops.last_kernel_form() == 'conv1x1_ksw<%d,%d,%s>' % (tile + ('n' if sn else 'k',))
+        np.testing.assert_allclose(y.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=str(tile))
+        assert torch.equal(y, ops.conv1x1_ksw(x, wk, b, Cout, tile, stride=stride, relu=relu, residual=r, split_n=sn))
+        y1 = ops.conv1x1_ksw(x[N - 1:], wk, b, Cout, tile, stride=stride, relu=relu, residual=None if r is None else r[N - 1:], split_n=sn)
+        assert torch.equal(y[N - 1:], y1), tile
+        if frag is not None:
+            assert float((y - frag).abs().max()) < 5e-5
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_ksw(x, wk, b, Cout, (48, 64), stride=stride, relu=relu, residual=r)
+
+
 def test_conv1x1_balanced_main_plus_tail():
     """hipconv: the 1024 -> 256 layer on the 50 x 84 map (66 x 4 = 264 tiles on 256 CUs) runs as 4096 unsplit rows + 104 split-K rows into
     ONE output tensor; 1e-4 vs float64, and equal to the plain launch on the unsplit rows."""
@@ -805,6 +842,7 @@ def test_conv1x1_balanced_main_plus_tail():
     m = torch.nn.Conv2d(1024, 256, 1).cuda()
     x = torch.randn(1, 1024, 50, 84, device='cuda').contiguous(memory_format=torch.channels_last)
     was, hipconv.BALANCE = hipconv.BALANCE, True       # (opt-in: UPSNET_CONV1X1_BALANCE=1)
+    was_ksw, hipconv.KSW = hipconv.KSW, False          # (r13: this layer goes to the small-tile kernel by default -- the balanced form is what the 64-pixel kernel does without it)
     rows, ks = hipconv._c1_balance(m, x)
     assert rows == 4096 and ks > 1
     hipconv.TRACE = []
@@ -815,7 +853,7 @@ def test_conv1x1_balanced_main_plus_tail():
             hipconv.BALANCE = False
             y0 = hipconv.conv(m, x, relu=True)
     finally:
-        hipconv.TRACE, hipconv.BALANCE = None, was
+        hipconv.TRACE, hipconv.BALANCE, hipconv.KSW = None, was, was_ksw
     assert form.startswith('conv1x1 main + tail splitk') and y.shape == y0.shape
     ref = F.relu(F.conv2d(x.double(), m.weight.double(), m.bias.double()))
     np.testing.assert_allclose(y.double().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)

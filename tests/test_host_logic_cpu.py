@@ -216,6 +216,31 @@ def test_winograd_f4x4_routing_rule(monkeypatch):
     assert not use(c3, [x(1, 256, 512)])
 
 
+def test_small_tile_1x1_routing_rule(monkeypatch):
+    """hipconv, r13: the 16x16x4-fragment 1x1 kernel only where the 64-pixel tiles leave the last round of workgroups < 0.75 full AND the
+    layer is a long K walk into few channels (Cin >= 2 Cout, Cin >= 256). Shape-only; the headline's power-of-two maps never take it."""
+    import torch
+    import torch.nn as nn
+    from upsnet_amd.models import hipconv
+    monkeypatch.setattr(hipconv, 'KSW', True)
+    monkeypatch.setattr(hipconv, 'KSW_MAX_FILL', 0.75)
+    monkeypatch.setattr(hipconv, 'PRECISION', 'fp32')
+    x = lambda c, h, w, n=1: torch.empty(n, c, h, w, device='meta')
+    use = lambda cin, cout, h, w, st=1: hipconv._use_ksw(nn.Conv2d(cin, cout, 1, stride=st), x(cin, h, w), cus=256)
+    assert use(1024, 256, 50, 84)            # UPSNet-101-DCN res4 conv1 at 800x1333: 264 workgroups of 512 slots
+    assert use(2048, 512, 25, 42) and use(2048, 256, 25, 42)      # res5 conv1 (136 of 256), the P5 lateral (68 of 256)
+    assert use(512, 256, 100, 168, 2)        # a stage's first conv1 (stride 2) when it runs alone
+    assert use(512, 128, 100, 168)           # res3 conv1: 526 of 768
+    assert not use(256, 1024, 50, 84) and not use(512, 2048, 25, 42) and not use(128, 512, 100, 168)   # conv3 layers: Cin < 2 Cout
+    assert not use(256, 64, 200, 336)        # res2 conv1: 1050 of 1280 = 0.82 full
+    for cin, cout, h, w in [(1024, 256, 64, 128), (2048, 512, 32, 64), (512, 128, 128, 256), (256, 64, 256, 512)]:
+        assert not use(cin, cout, h, w), (cin, cout, h, w)       # the headline workload (1024x2048): its bottleneck maps tile evenly
+    assert use(2048, 256, 32, 64)            # ... its P5 lateral is 128 workgroups for 256 CUs: 29.2 -> 21.0 us (was the general kernel, split-K x4)
+    assert not hipconv._use_ksw(nn.Conv2d(1024, 256, 1), torch.empty(1, 1024, 50, 84, device='meta', dtype=torch.bfloat16), cus=256)
+    monkeypatch.setattr(hipconv, 'KSW', False)
+    assert not use(1024, 256, 50, 84)
+
+
 def test_knobs_report_set_variables_and_reject_unknown_names():
     """bench hygiene (VERDICT r03 #8): every UPSNET_* variable that is set goes into the bench line; a name no source file reads is an error."""
     from upsnet_amd import knobs

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libupsnet_hip.so")
 STAMP = LIB + ".srchash"   # git-ignored, travels with the .so
-SOURCES = ["capi.cpp", "fill.hip", "roi_align.hip", "nms.hip", "deform_conv.hip", "deform_fused.hip", "deform_fused_bf16.hip", "backward.hip", "conv.hip", "conv1x1.hip", "conv1x1_pair.hip", "conv_wino.hip", "conv_wino36.hip", "conv_bf16.hip", "bottleneck_bf16.hip", "conv3x3_wreg_bf16.hip", "conv1x1_wreg_bf16.hip", "stem_pool_bf16.hip", "stem_pool.hip", "proposal.hip", "detect.hip", "panoptic.hip", "fcn_head.hip", "preprocess.hip", "postprocess.hip"]
+SOURCES = ["capi.cpp", "fill.hip", "roi_align.hip", "nms.hip", "deform_conv.hip", "deform_fused.hip", "deform_fused_bf16.hip", "backward.hip", "conv.hip", "conv1x1.hip", "conv1x1_ksw.hip", "conv1x1_pair.hip", "conv_wino.hip", "conv_wino36.hip", "conv_bf16.hip", "bottleneck_bf16.hip", "conv3x3_wreg_bf16.hip", "conv1x1_wreg_bf16.hip", "stem_pool_bf16.hip", "stem_pool.hip", "proposal.hip", "detect.hip", "panoptic.hip", "fcn_head.hip", "preprocess.hip", "postprocess.hip"]
 # -fno-slp-vectorize: the SLP vectorizer turns adjacent scalar fp32 adds / multiplies (the bilinear blend of the deformable kernels)
 # into v_pk_add_f32 / v_pk_mul_f32, and a packed fp32 VALU instruction beside MFMAs costs far more than its issue slot
 # (/opt/skills/guides/MI355X_MICROARCH.md); same IEEE operations either way, so results do not change.

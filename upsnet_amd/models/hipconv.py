@@ -209,6 +209,41 @@ def _conv1x1_balanced(m, x, relu, residual):
     return out, 'conv1x1 %s splitk%d' % ('main + tail' if rows_main else 'all', ks)
 
 
+# r13: the small-tile 1x1 kernel (csrc/conv1x1_ksw.hip: 16 pixels x 64 channels of v_mfma_f32_16x16x4_f32 fragments, K split over the four
+# waves of a workgroup, no LDS in the K loop) where the 64-pixel tiles of the lean kernel leave the chip idle: the last round of its
+# workgroups is less than KSW_MAX_FILL full (UPSNet-101-DCN at 800x1333: 4200-pixel maps are 66 x 4 = 264 workgroups = two K walks for
+# 1.03 walks of work) AND the layer has a long K walk into few channels (Cin >= 2 Cout, Cin >= 256: a bottleneck's conv1, the FPN's P5
+# lateral) -- the small tile re-fetches the weights once per 16 pixels, which costs more than it spreads for a conv3 (measured,
+# tools/bench_conv1x1_ksw.py: 1024 -> 256 on 50 x 84 36.3 -> 27.0 us, 2048 -> 256 on 25 x 42 34.2 -> 19.5, 2048 -> 512 35.2 -> 28.3,
+# 256 -> 1024 30.0 -> 30.4). Power-of-two maps (the headline workload) tile evenly and never take it. Shape-only; never for a pinned choice.
+KSW = os.environ.get('UPSNET_CONV1X1_KSW', '1') != '0'
+KSW_MAX_FILL = float(os.environ.get('UPSNET_CONV1X1_KSW_MAX_FILL', '0.75'))
+KSW_TILE = (16, 64)
+
+
+def _ksw_plan(m):
+    w = m.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('ksw')
+    if ent is None or ent[0] != key:
+        ent = (key, ops.pack_conv1x1_ksw_weight(w.detach()))
+        _plans(m)['ksw'] = ent
+    return ent[1]
+
+
+def _use_ksw(m, x, cus=None):
+    if not (KSW and PRECISION == 'fp32' and x.dtype == torch.float32 and tuple(m.kernel_size) == (1, 1) and tuple(m.padding) == (0, 0) and
+            m.stride[0] in (1, 2) and m.in_channels % 16 == 0 and m.out_channels % 4 == 0 and m.in_channels >= 256 and
+            m.in_channels >= 2 * m.out_channels):
+        return False
+    st = m.stride[0]
+    pix = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
+    m_tiles = -(-pix // 64)
+    wgs = m_tiles * -(-m.out_channels // _c1_bn(m_tiles, m.out_channels))
+    cus = cus or _cus(x.device)
+    return wgs < KSW_MAX_FILL * -(-wgs // cus) * cus
+
+
 PAIR = os.environ.get('UPSNET_CONV1X1_PAIR', '1') != '0'
 PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
 
@@ -560,6 +595,10 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
                 return _wino_split_launch(m, x, n_main, relu), 'winograd tm32 + tail tn32'
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0], 'winograd tm%d' % _wino_tm(m, [x])
+        if not pin and not residual_up and _use_ksw(m, x):
+            # (before the lean / general choice: maps below CONV1X1_MIN_WG workgroups -- res5, the P5 lateral -- are the emptiest launches)
+            return ops.conv1x1_ksw(x, _ksw_plan(m), m.bias, m.out_channels, KSW_TILE, stride=m.stride[0], relu=relu,
+                                   residual=residual), 'conv1x1 ksw %dx%d' % KSW_TILE
         if _use_conv1x1(m, x, always=pin):
             if not pin and not residual_up and m.stride[0] == 1:
                 return _conv1x1_balanced(m, x, relu, residual)

@@ -755,6 +755,50 @@ def conv1x1_frag(x, wpack, bias, cout, stride=1, relu=False, residual=None, resi
     return out
 
 
+def pack_conv1x1_ksw_weight(weight):
+    """[Cout,Cin,1,1] -> 16x16x4 fragment-order pack for conv1x1_ksw (csrc/conv1x1_ksw.hip)."""
+    require_cuda(weight)
+    w = f32c(weight)
+    cout, cin = w.shape[0], w.shape[1]
+    wp = torch.empty((lib().upsnet_conv1x1_ksw_packed_weight_floats(cout, cin),), dtype=torch.float32, device=w.device)
+    check(lib().upsnet_conv1x1_ksw_pack_weight(stream(), ptr(w), cout, cin, ptr(wp)), "conv1x1_ksw_pack_weight")
+    return wp
+
+
+def conv1x1_ksw(x, wpack, bias, cout, tile, stride=1, relu=False, residual=None, out=None, split_n=False):
+    """1x1 convolution (stride 1 / 2) on the small-tile kernel of csrc/conv1x1_ksw.hip (16x16x4 MFMA fragments, K split over the waves):
+    out = relu?(conv(x) + bias + residual). tile = (pixels, channels) of a workgroup: {(16, 64), (32, 32), (32, 64), (64, 64)} with the waves
+    splitting K, {(16, 256), (32, 128), (32, 256)} with split_n (the waves split the channels, each walks all of K).
+    x: logical NCHW (any batch), returns channels_last [N,Cout,Ho,Wo]."""
+    require_cuda(wpack, x)
+    x = nhwc(x.float())
+    N, cin, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = _nhwc_out(N, cout, Ho, Wo, x.device)
+    elif tuple(out.shape) != (N, cout, Ho, Wo) or out.dtype != torch.float32 or not out.permute(0, 2, 3, 1).is_contiguous():
+        raise RuntimeError("conv1x1_ksw: out must be a channels_last fp32 [%d,%d,%d,%d]" % (N, cout, Ho, Wo))
+    res = None
+    if residual is not None:
+        res = nhwc(residual.float())
+        if tuple(res.shape) != tuple(out.shape):
+            raise RuntimeError("conv1x1_ksw: residual shape %s != %s" % (tuple(res.shape), tuple(out.shape)))
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv1x1_ksw_nhwc_f32(stream(), ptr(x), ptr(res), ptr(out), N, H, W, int(cin), ptr(wpack),
+                                            ptr(None if bias is None else f32c(bias)), int(cout), int(stride), int(bool(relu)),
+                                            int(tile[0]), int(tile[1]), int(bool(split_n))), "conv1x1_ksw_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = out.shape[0] * out.shape[2] * out.shape[3]
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * npix,
+                                  4.0 * (cin * npix + cout * npix * (2 if res is not None else 1) + cout * cin),
+                                  "direct 1x1/%d %d->%d [%s]%s (gemm ksw %dx%d%s)" % (stride, cin, cout, tuple(x.shape[0:1] + x.shape[2:]),
+                                                                                     " +res" if res is not None else "", tile[0], tile[1], "n" if split_n else "k")))
+    return out
+
+
 def conv1x1_siblings(x, wpack, bias, cout_a, cout_b, stride=1, relu_a=True, relu_b=False):
     """Two 1x1 convolutions of the same input in one launch (csrc/conv1x1.hip, sibling mode): rows [0, cout_a) of the concatenated weight
     -> out_a (ReLU flag relu_a), the remaining cout_b rows -> out_b. wpack: pack_conv1x1_weight(torch.cat([w_a, w_b])); bias: both biases
