@@ -407,6 +407,18 @@ int upsnet_conv1x1_ksw_nhwc_f32(void *stream, const float *x, const float *resid
                                 int split_n);
 void upsnet_conv1x1_ksw_tuning(int tile);
 
+/* 3x3 / stride 1 / pad 1 convolution (+ bias, ReLU) into Cout <= 32 channels on the small-tile scheme of upsnet_conv1x1_ksw_nhwc_f32
+ * (csrc/conv1x1_ksw.hip, r13): 16-pixel x 32-channel workgroups, the (tap, channel) walk split over the four waves, no LDS in the K loop.
+ * Replaces the separate launch pair (split-K general kernel + reduce) of the 18-channel offset predictors of the deformable bottlenecks on
+ * small maps (conv2_offset, upsnet/models/resnet.py:102-153). x [N,H,W,Cin] NHWC, out [N,H,W,Cout] NHWC, Cin % 16 == 0; wpack:
+ * upsnet_conv3x3_ksw_packed_weight_floats(Cin) floats from upsnet_conv3x3_ksw_pack_weight (weight [Cout, Cin, 3, 3]). Finite weights
+ * assumed. Fixed summation order for a given pixel count (bit-repeatable; the number of waves that share a tile's walk -- 4, 8 or 16 --
+ * follows the tile count, so a pixel's bits may differ between launches of different sizes: not for ROI batches). */
+size_t upsnet_conv3x3_ksw_packed_weight_floats(int cin);
+int upsnet_conv3x3_ksw_pack_weight(void *stream, const float *weight, int cout, int cin, float *wpack);
+int upsnet_conv3x3_ksw_nhwc_f32(void *stream, const float *x, float *out, int batch, int height, int width, int Cin, const float *wpack,
+                                const float *bias, int Cout, int relu);
+
 /* upsnet_conv1x1_frag_nhwc_f32 with the K walk of every tile split over `ksplit` (2..16) workgroups + the shared reduce / epilogue
  * kernel (bias, residual, ReLU; fixed summation order: bit-repeatable). For maps whose tile count does not spread evenly over the CUs:
  * a workgroup of this kernel keeps all four SIMDs of its CU at the MFMA rate, so a launch lasts (most workgroups on one CU) x (one K

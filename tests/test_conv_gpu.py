@@ -834,6 +834,34 @@ def test_conv1x1_ksw_vs_fp64(N, Cin, Cout, H, W, stride, relu, res, bias):
         ops.conv1x1_ksw(x, wk, b, Cout, (48, 64), stride=stride, relu=relu, residual=r)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,relu,bias", [
+    (1, 256, 18, 50, 84, False, True),      # UPSNet-101-DCN res4 offset predictor at 800x1333 (263 tiles: 4 waves per tile)
+    (1, 512, 18, 25, 42, False, True),      # res5 (66 tiles: 16 waves)
+    (1, 128, 18, 21, 77, True, True),       # 102 tiles: 8 waves; ReLU
+    (2, 64, 32, 9, 7, False, False),        # two images (taps must not cross into the neighbouring image), all 32 columns, no bias
+    (1, 48, 5, 3, 3, True, True),           # 3 channel chunks per tap, one ragged tile
+    (3, 16, 27, 1, 5, False, True),         # H = 1: only the middle row of taps is inside
+])
+def test_conv3x3_ksw_vs_fp64(N, Cin, Cout, H, W, relu, bias):
+    """csrc/conv1x1_ksw.hip, conv3x3_ksw_f32_kernel (r13): 3x3 / stride 1 / pad 1 into <= 32 channels on 16-pixel tiles, the (tap, channel)
+    walk split over 4 / 8 / 16 waves: rtol = atol = 1e-4 vs float64, bit-repeatable; the last image alone gives the same values up to the
+    summation tree of its wave count."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    ref = ref.clamp_min(0) if relu else ref
+    wk = ops.pack_conv3x3_ksw_weight(w)
+    y = ops.conv3x3_ksw(x, wk, b, Cout, relu=relu)
+    assert ops.last_kernel_form().startswith('conv3x3_ksw<16,32,')
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(y, ops.conv3x3_ksw(x, wk, b, Cout, relu=relu))
+    y1 = ops.conv3x3_ksw(x[N - 1:], wk, b, Cout, relu=relu)     # (a different wave count may be picked for the smaller launch: then only 1e-4-close)
+    np.testing.assert_allclose(y[N - 1:].cpu().numpy(), y1.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_conv1x1_balanced_main_plus_tail():
     """hipconv: the 1024 -> 256 layer on the 50 x 84 map (66 x 4 = 264 tiles on 256 CUs) runs as 4096 unsplit rows + 104 split-K rows into
     ONE output tensor; 1e-4 vs float64, and equal to the plain launch on the unsplit rows."""

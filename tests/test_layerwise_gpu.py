@@ -101,14 +101,14 @@ def _check_model(preset, h, w, seed, need_forms, min_shapes, precision='fp32', w
         update_config_dict(CITYSCAPES_R50)
 
 
-_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd36', 'winograd36 multi', 'winograd tm32', 'winograd tm32 + tail tn32', 'winograd splitk', 'igemm', 'igemm splitk',
+_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd36', 'winograd36 multi', 'winograd tm32', 'winograd tm32 + tail tn32', 'winograd splitk', 'igemm', 'conv1x1 ksw',
              'igemm multi cat', 'deconv2x2', 'dcn_fused multi']
 
 
 @pytest.mark.parametrize("h,w", [(256, 512), (1024, 2048)])
 def test_every_convolution_launch_vs_fp64_on_identical_inputs_upsnet50(h, w):
     """C1 (UPSNet-50 Cityscapes). At 1024x2048: each of its convolution shapes at the real size, in the kernel form hipconv picks there
-    (64-tile Winograd on FPN-P2 / the RPN launch, split-K on res5 / P5, the res2 pair kernel, ...)."""
+    (F(4x4) Winograd on FPN-P2 / the RPN launch, split-K on res5, the small-tile 1x1 kernel on the P5 lateral, the res2 pair kernel, ...)."""
     from upsnet_amd.config.config import CITYSCAPES_R50
     full = h * w >= 1 << 21
     _check_model(CITYSCAPES_R50, h, w, seed=3, need_forms=_C1_FORMS if full else ['stem', 'deconv2x2', 'dcn_fused multi'],
@@ -126,7 +126,9 @@ def test_every_convolution_launch_vs_fp64_on_identical_inputs_upsnet101_dcn(h, w
     """C2 (BASELINE configs[3]): R101 with 30 deformable bottlenecks (each checked at its recorded offsets = identical sampling
     positions, its offset prediction as a convolution of its own), GAP, 3 FCN layers, 81 / 133 classes."""
     from upsnet_amd.config.config import COCO_R101_DCN
-    _check_model(COCO_R101_DCN, h, w, seed=4, need_forms=['stem', 'deconv2x2', 'dcn_fused'], min_shapes=30)
+    # (r13) at 800x1333 the small-tile kernels carry the bottlenecks' conv1 layers / the P5 lateral (conv1x1 ksw) and the offset predictors of res4 / res5
+    # (conv3x3 ksw): each of those launches is replayed in float64 like every other one
+    _check_model(COCO_R101_DCN, h, w, seed=4, need_forms=['stem', 'deconv2x2', 'dcn_fused'] + (['conv1x1 ksw', 'conv3x3 ksw'] if h >= 800 else []), min_shapes=30)
 
 
 # ----------------------------------------------------------------------------- bf16 mode (BASELINE.json configs[2]) and configs[4]

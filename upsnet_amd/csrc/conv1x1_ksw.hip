@@ -278,3 +278,188 @@ extern "C" int upsnet_conv1x1_ksw_nhwc_f32(void *stream, const float *x, const f
     ups_set_form("conv1x1_ksw<%d,%d,%c>", tile_pixels, tile_channels, split_n ? 'n' : 'k');
     return 0;
 }
+
+// =====================================================================================================================================
+// 3x3 / stride 1 / pad 1 convolution into FEW channels (<= 32) on the same scheme: the 18-channel offset predictors of the deformable
+// bottlenecks (conv2_offset, upsnet/models/resnet.py:102-153; UPSNet-101-DCN has 30, on maps of 16 800 / 4200 / 1050 pixels at 800x1333).
+// On the general kernel such a layer was 33 workgroups of 128 pixels walking 72 slabs, split 8 ways over K + a reduce launch: 22 us for
+// 4 us of matrix work, 23 times per image (profiles/r12_layer_table_c3.txt). Here a workgroup is 16 pixels x 32 channels, its four waves
+// split the 9 Cin / 16 steps of the (tap, channel) walk; a lane's A operand is 16 bytes of the tap's shifted pixel straight from the map
+// (a tap outside the image: out-of-range offset, reads the 0 of the padding), B from the fragment-order pack; the partial tiles meet in LDS.
+// weight [Cout, Cin, 3, 3] -> [cbk = co / 16 (2 blocks)][step = tap * (Cin / 16) + c / 16][lane = 16 ((c % 16) / 4) + co % 16][c % 4]
+__global__ void conv3x3_ksw_pack_kernel(const float *__restrict__ w, int cout, int cin, float *__restrict__ wp)
+{
+    const long total = (long)2 * 16 * cin * 9;
+    const int nch = cin >> 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)blockDim.x * gridDim.x) {
+        const int c4 = idx & 3, j = (idx >> 2) & 15, k = (idx >> 6) & 3;
+        const long r = idx >> 8;
+        const int s = (int)(r % (9 * nch)), cbk = (int)(r / (9 * nch));
+        const int tap = s / nch, ch = s - tap * nch;
+        const int co = 16 * cbk + j, c = 16 * ch + 4 * k + c4;
+        wp[idx] = co < cout ? w[((long)co * cin + c) * 9 + tap] : 0.f;
+    }
+}
+
+extern "C" size_t upsnet_conv3x3_ksw_packed_weight_floats(int cin) { return cin > 0 ? (size_t)32 * 9 * (size_t)cin : 0; }
+
+extern "C" int upsnet_conv3x3_ksw_pack_weight(void *stream, const float *weight, int cout, int cin, float *wpack)
+{
+    UPS_REQUIRE(weight && wpack && cout > 0 && cout <= 32 && cin > 0 && cin % 16 == 0, "conv3x3_ksw_pack_weight: Cout <= 32 and Cin %% 16 == 0 (got %d, %d)", cout, cin);
+    const long total = (long)32 * 9 * cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(conv3x3_ksw_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, cout, cin, wpack);
+    UPS_CHECK_LAUNCH("conv3x3_ksw_pack_kernel");
+    return 0;
+}
+
+// NW: waves per workgroup = shares of the (tap, channel) walk (4, 8 or 16); RB: 16-pixel row blocks per workgroup
+template <int RING, int NW, int RB>
+__global__ void __launch_bounds__(64 * NW, 1) conv3x3_ksw_f32_kernel(const ConvParams p)
+{
+    constexpr int LDP = 36;
+    __shared__ __attribute__((aligned(16))) float red[NW * 16 * RB * LDP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, li = lane & 15;
+    const ConvSeg sg = p.seg[0];
+    const long p0 = (long)blockIdx.x * (16 * RB);
+    const int nch = p.Cin >> 4, nst = 9 * nch;
+    const int s_begin = (wave * nst) / NW, s_end = ((wave + 1) * nst) / NW;
+    const long HW = (long)sg.H * sg.W;
+    // this lane's pixels: byte offset of the channel vector (+ 16 lk), and the 9-bit mask of taps that fall inside the image
+    unsigned base[RB], tapmask[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        base[rb] = 0; tapmask[rb] = 0;
+        const long pp = p0 + 16 * rb + li;
+        if (pp < sg.M) {
+            const int n = (int)(pp / HW);
+            const int rem = (int)(pp - (long)n * HW);
+            const int h = rem / sg.W, w = rem - h * sg.W;
+            base[rb] = (unsigned)pp * 4u * (unsigned)p.Cin + 16u * (unsigned)lk;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+                tapmask[rb] |= (hh >= 0 && hh < sg.H && ww >= 0 && ww < sg.W) ? (1u << t) : 0u;
+            }
+        }
+    }
+    const size_t xaddr = reinterpret_cast<size_t>(sg.x);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)xhi << 32) | xlo), 0, (int)xbytes, 0x00020000);
+    const size_t waddr = reinterpret_cast<size_t>(p.w);
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0, 2 * nst * 1024, 0x00020000);
+    const unsigned b_lane = (unsigned)lane * 16u;
+    const int pixb = 4 * p.Cin;                     // bytes of one pixel's channel vector
+
+    kfloatx4 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc[rb][0] = (kfloatx4){0.f, 0.f, 0.f, 0.f}; acc[rb][1] = (kfloatx4){0.f, 0.f, 0.f, 0.f}; }
+    kfloatx4 ra[RING][RB], rw0[RING], rw1[RING];
+    // step S = tap * nch + chunk (wave-uniform): pixel shifted by the tap, channels 16 chunk + 4 lk ..; a tap outside the image or a step
+    // beyond this wave's range: offset out of range, reads 0 (B then multiplies zeros: finite weights assumed, as above)
+#define K3_LOAD(U, S)                                                                                                                  \
+    {                                                                                                                                  \
+        const int s_ = (S);                                                                                                            \
+        const int sc_ = min(s_, nst - 1);                                                                                              \
+        const int tap_ = sc_ / nch, ch_ = sc_ - tap_ * nch;                                                                            \
+        const int ty_ = tap_ / 3, tx_ = tap_ - 3 * ty_;                                                                                \
+        const int delta_ = ((ty_ - 1) * sg.W + (tx_ - 1)) * pixb + ch_ * 64;                                                           \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < RB; ++rb_) {                                                                         \
+            const bool ok_ = s_ < s_end && ((tapmask[rb_] >> tap_) & 1u);                                                              \
+            const kuintx4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok_ ? base[rb_] + (unsigned)delta_ : 0x80000000u, 0, 0);   \
+            ra[U][rb_] = (kfloatx4){__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)};       \
+        }                                                                                                                              \
+        const kuintx4 b0_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)sc_ * 1024u, 0);                            \
+        const kuintx4 b1_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_lane, (unsigned)(nst + sc_) * 1024u, 0);                    \
+        rw0[U] = (kfloatx4){__uint_as_float(b0_.x), __uint_as_float(b0_.y), __uint_as_float(b0_.z), __uint_as_float(b0_.w)};           \
+        rw1[U] = (kfloatx4){__uint_as_float(b1_.x), __uint_as_float(b1_.y), __uint_as_float(b1_.z), __uint_as_float(b1_.w)};           \
+    }
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+        K3_LOAD(u, s_begin + u)
+        __builtin_amdgcn_sched_barrier(0);          // (ring order: see conv1x1_ksw_f32_kernel)
+    }
+    for (int s = s_begin; s < s_end; s += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][rb][e], rw0[u][e], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][rb][e], rw1[u][e], acc[rb][1], 0, 0, 0);
+                }
+            K3_LOAD(u, s + u + RING)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef K3_LOAD
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[((wave * RB + rb) * 16 + 4 * lk + r) * LDP + li] = acc[rb][0][r];
+            red[((wave * RB + rb) * 16 + 4 * lk + r) * LDP + 16 + li] = acc[rb][1][r];
+        }
+    __syncthreads();
+    // 16 RB pixels x 32 channels over the workgroup's threads; the NW partial sums are added as a fixed binary tree
+    for (int e = tid; e < 512 * RB; e += 64 * NW) {
+        const int row = e >> 5, co = e & 31;
+        const long pp = p0 + row;
+        if (pp < sg.M && co < p.Cout) {
+            float t[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[w] = red[(w * RB * 16 + row) * LDP + co];
+#pragma unroll
+            for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+                for (int w = 0; w < NW; w += 2 * span) t[w] = t[w] + t[w + span];
+            float v = t[0];
+            if (p.bias != nullptr) v += p.bias[co];
+            if (p.relu) v = fmaxf(v, 0.f);
+            sg.out[pp * p.Cout + co] = v;
+        }
+    }
+}
+
+/* out = relu?(conv3x3(x; stride 1, pad 1) + bias) for Cout <= 32 (the 18-channel offset predictors of the deformable bottlenecks,
+ * upsnet/models/resnet.py:102-153) on small maps: 16-pixel x 32-channel workgroups, K split over the waves. x [N,H,W,Cin] NHWC,
+ * out [N,H,W,Cout] NHWC; Cin % 16 == 0; wpack from upsnet_conv3x3_ksw_pack_weight (weight [Cout, Cin, 3, 3]). Finite weights assumed.
+ * Fixed summation order for a given pixel count: bit-repeatable (the wave count follows the tile count: not for ROI batches). */
+extern "C" int upsnet_conv3x3_ksw_nhwc_f32(void *stream, const float *x, float *out, int batch, int height, int width, int Cin,
+                                           const float *wpack, const float *bias, int Cout, int relu)
+{
+    UPS_REQUIRE(x && out && wpack && batch > 0 && height > 0 && width > 0, "conv3x3_ksw_nhwc_f32: bad args");
+    UPS_REQUIRE(Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout <= 32, "conv3x3_ksw_nhwc_f32: Cin %% 16 == 0 and Cout <= 32 (got %d, %d)", Cin, Cout);
+    UPS_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(wpack)) & 15) == 0, "conv3x3_ksw_nhwc_f32: x / wpack must be 16-byte aligned");
+    UPS_REQUIRE((long)batch * height * width * Cin < (1L << 29), "conv3x3_ksw_nhwc_f32: feature map exceeds 2 GiB; split the batch");
+    ConvParams p;
+    p.w = wpack; p.bias = bias; p.nseg = 1; p.Cin = Cin; p.Cout = Cout; p.ldw = 32; p.KH = p.KW = 3;
+    p.stride = 1; p.pad = 1; p.dil = 1; p.relu = relu; p.res_up = 0;
+    p.ksplit = 1; p.partial = nullptr; p.m_total = 0; p.io = 0; p.sib_split = 0; p.sib_relu = 0; p.sib_out = nullptr;
+    for (int i = 0; i < CV_MAXSEG; ++i) {
+        ConvSeg &s = p.seg[i];
+        s.x = s.res = s.off = s.mask = nullptr; s.w = nullptr; s.out = nullptr;
+        s.N = s.H = s.W = s.Ho = s.Wo = s.OH = s.OW = 0; s.M = 0; s.tile_start = 0x7fffffff;
+    }
+    ConvSeg &s = p.seg[0];
+    s.x = x; s.out = out; s.N = batch; s.H = s.Ho = height; s.W = s.Wo = width;
+    s.M = (long)batch * height * width; s.tile_start = 0;
+    // (measured r13, tools/bench_conv3x3_ksw.py: 16-pixel tiles; 32-pixel ones are no faster on 4200-pixel maps and slower on 1050-pixel ones.
+    // 4 / 8 / 16 waves per workgroup differ by < 1 us; more waves for fewer tiles keeps the SIMDs supplied)
+    const int rb = 1;
+    p.m_tiles = (int)((s.M + 16 * rb - 1) / (16 * rb)); p.n_tiles = 1;
+    const int nw = p.m_tiles >= 192 ? 4 : (p.m_tiles >= 96 ? 8 : 16);
+    hipStream_t st = (hipStream_t)stream;
+#define K3_GO(NW, RB) hipLaunchKernelGGL((conv3x3_ksw_f32_kernel<2, NW, RB>), dim3(p.m_tiles), dim3(64 * NW), 0, st, p)
+    if (nw == 16) K3_GO(16, 1); else if (nw == 8) K3_GO(8, 1); else K3_GO(4, 1);
+#undef K3_GO
+    UPS_CHECK_LAUNCH("conv3x3_ksw_f32_kernel");
+    ups_set_form("conv3x3_ksw<%d,32,%d>", 16 * rb, nw);
+    return 0;
+}

@@ -32,6 +32,7 @@ REGISTRY = {
     'UPSNET_CONV1X1_MIN_WG': ('256', 'models/hipconv.py', 'fewest workgroups for the lean 1x1 kernel'),
     'UPSNET_CONV1X1_KSW': ('1', 'models/hipconv.py', 'small-tile (16x16x4 fragment) 1x1 kernel for maps the 64-pixel tiles do not fill evenly'),
     'UPSNET_CONV1X1_KSW_MAX_FILL': ('0.75', 'models/hipconv.py', 'use it when the last round of 64-pixel workgroups is less than this full'),
+    'UPSNET_CONV3X3_KSW': ('1', 'models/hipconv.py', 'small-tile 3x3 kernel for <= 32-channel layers (offset predictors) on small maps'),
     'UPSNET_CONV1X1_PAIR': ('1', 'models/hipconv.py', 'conv3 + next conv1 in one launch'),
     'UPSNET_CONV1X1_PAIR32_WAVES': ('8', 'ops.py', 'waves per workgroup of the res4 pair kernel'),
     'UPSNET_CONV1X1_PAIR_MIN_TILES': ('1024', 'models/hipconv.py', 'fewest tiles for the res2 pair kernel'),

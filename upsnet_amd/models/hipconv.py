@@ -244,6 +244,28 @@ def _use_ksw(m, x, cus=None):
     return wgs < KSW_MAX_FILL * -(-wgs // cus) * cus
 
 
+# r13: 3x3 / stride 1 / pad 1 layers into <= 32 channels (the 18-channel offset predictors of the deformable bottlenecks) on maps too small
+# for the Winograd 32-channel form: the small-tile kernel (csrc/conv1x1_ksw.hip, conv3x3_ksw_f32_kernel) instead of the general kernel
+# split 6-8 ways over K + its reduce launch (tools/bench_conv3x3_ksw.py: 256 -> 18 on 50 x 84 21.4 -> 14.4 us, 512 -> 18 on 25 x 42
+# 21.8 -> 14.9; 23 + 3 such layers per image of UPSNet-101-DCN at 800x1333). Shape-only.
+KSW3 = os.environ.get('UPSNET_CONV3X3_KSW', '1') != '0'
+
+
+def _ksw3_plan(m):
+    w = m.weight
+    key = (w.data_ptr(), w._version, tuple(w.shape), None if m.bias is None else m.bias._version)
+    ent = _plans(m).get('ksw3')
+    if ent is None or ent[0] != key:
+        ent = (key, ops.pack_conv3x3_ksw_weight(w.detach()))
+        _plans(m)['ksw3'] = ent
+    return ent[1]
+
+
+def _use_ksw3(m, x):
+    return (KSW3 and PRECISION == 'fp32' and x.dtype == torch.float32 and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and
+            tuple(m.padding) == (1, 1) and tuple(m.dilation) == (1, 1) and m.out_channels <= 32 and m.in_channels % 16 == 0)
+
+
 PAIR = os.environ.get('UPSNET_CONV1X1_PAIR', '1') != '0'
 PAIR_MIN_TILES = int(os.environ.get('UPSNET_CONV1X1_PAIR_MIN_TILES', '1024'))
 
@@ -595,6 +617,9 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
                 return _wino_split_launch(m, x, n_main, relu), 'winograd tm32 + tail tn32'
             return ops.conv2d_winograd_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu,
                                              residuals=None if residual is None else [residual])[0], 'winograd tm%d' % _wino_tm(m, [x])
+        if not pin and residual is None and _use_ksw3(m, x):
+            # (reached only where the Winograd 32-channel form was not taken: maps below WINOGRAD_MIN_WORKGROUPS workgroups)
+            return ops.conv3x3_ksw(x, _ksw3_plan(m), m.bias, m.out_channels, relu=relu), 'conv3x3 ksw 16x32'
         if not pin and not residual_up and _use_ksw(m, x):
             # (before the lean / general choice: maps below CONV1X1_MIN_WG workgroups -- res5, the P5 lateral -- are the emptiest launches)
             return ops.conv1x1_ksw(x, _ksw_plan(m), m.bias, m.out_channels, KSW_TILE, stride=m.stride[0], relu=relu,

@@ -799,6 +799,36 @@ def conv1x1_ksw(x, wpack, bias, cout, tile, stride=1, relu=False, residual=None,
     return out
 
 
+def pack_conv3x3_ksw_weight(weight):
+    """[Cout <= 32, Cin, 3, 3] -> 16x16x4 fragment-order pack for conv3x3_ksw (csrc/conv1x1_ksw.hip)."""
+    require_cuda(weight)
+    w = f32c(weight)
+    cout, cin = w.shape[0], w.shape[1]
+    wp = torch.empty((lib().upsnet_conv3x3_ksw_packed_weight_floats(cin),), dtype=torch.float32, device=w.device)
+    check(lib().upsnet_conv3x3_ksw_pack_weight(stream(), ptr(w), cout, cin, ptr(wp)), "conv3x3_ksw_pack_weight")
+    return wp
+
+
+def conv3x3_ksw(x, wpack, bias, cout, relu=False):
+    """3x3 / stride 1 / pad 1 convolution into cout <= 32 channels on the small-tile kernel (csrc/conv1x1_ksw.hip, conv3x3_ksw_f32_kernel):
+    the offset predictors of the deformable bottlenecks on small maps. x: logical NCHW, returns channels_last [N,cout,H,W]."""
+    require_cuda(wpack, x)
+    x = nhwc(x.float())
+    N, cin, H, W = x.shape
+    out = _nhwc_out(N, cout, H, W, x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv3x3_ksw_nhwc_f32(stream(), ptr(x), ptr(out), N, H, W, int(cin), ptr(wpack), ptr(None if bias is None else f32c(bias)),
+                                            int(cout), int(bool(relu))), "conv3x3_ksw_nhwc_f32")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * H * W
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix, 4.0 * (cin * npix + cout * npix + cout * cin * 9),
+                                  "direct 3x3/1 %d->%d [%s] (ksw 16x32)" % (cin, cout, (N, H, W))))
+    return out
+
+
 def conv1x1_siblings(x, wpack, bias, cout_a, cout_b, stride=1, relu_a=True, relu_b=False):
     """Two 1x1 convolutions of the same input in one launch (csrc/conv1x1.hip, sibling mode): rows [0, cout_a) of the concatenated weight
     -> out_a (ReLU flag relu_a), the remaining cout_b rows -> out_b. wpack: pack_conv1x1_weight(torch.cat([w_a, w_b])); bias: both biases
