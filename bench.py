@@ -92,19 +92,33 @@ def roialign_microbench(H, W, n_iter=10):
         row = {'launch': 'roialign %dx256x%dx%d' % (n, ps, ps), 'algorithmic_bytes': alg}
         scales = [0.25, 0.125, 0.0625, 0.03125]
 
-        def put(tag, us):
+        def put(tag, us, row=row):
             row[tag + '_us'] = round(us, 1)
             row[tag + '_GBs'] = round(alg / us / 1e3, 1)
             row[tag + '_frac'] = round(alg / us / 1e3 / PEAK_HBM_GBS, 4)
+        # r13: launches of >= ops.ROI_XCD_ORDER_MIN ROIs deal the ROIs to the XCDs by image neighbourhood (one extra single-workgroup launch,
+        # INSIDE the timed op below); the same launch in the ROIs' own order is reported as 'natural_order' (what r12 and earlier measured)
+        dealt = ops.ROI_XCD_ORDER and n >= ops.ROI_XCD_ORDER_MIN
+        row['roi_order'] = 'dealt per XCD (fpn_roi_order_kernel inside the timed op)' if dealt else 'natural'
+        passes = [(row, 'auto')] + ([(row.setdefault('natural_order', {}), None)] if dealt else [])
+        for row_, order_ in passes:
+            _roialign_times(ops, feats, rois, ps, scales, flush, n_iter, lambda tag, us, r=row_: put(tag, us, r), order_)
+        out.append(row)
+    del flush, feats
+    return out
+
+
+def _roialign_times(ops, feats, rois, ps, scales, flush, n_iter, put, order):
+    if True:
         # warm: 8 launches back to back between two events (one launch after a synchronize would time the host's launch path: the
         # device is idle when the first event is recorded -- what r10's `warm` did)
         for _ in range(2):
-            ops.fpn_roi_align(feats, rois, ps, ps, scales)
+            ops.fpn_roi_align(feats, rois, ps, ps, scales, order=order)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         flush.add_(1.0)
         e0.record()
         for _ in range(8):
-            ops.fpn_roi_align(feats, rois, ps, ps, scales)
+            ops.fpn_roi_align(feats, rois, ps, ps, scales, order=order)
         e1.record()
         torch.cuda.synchronize()
         put('warm', e0.elapsed_time(e1) * 1000.0 / 8)
@@ -116,14 +130,11 @@ def roialign_microbench(H, W, n_iter=10):
                 fl()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.fpn_roi_align(feats, rois, ps, ps, scales)
+                ops.fpn_roi_align(feats, rois, ps, ps, scales, order=order)
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1000.0)
             put(tag, sorted(ts[2:])[n_iter // 2])
-        out.append(row)
-    del flush, feats
-    return out
 
 
 def main():

@@ -65,6 +65,20 @@ int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], 
                                  const float *rois, int num_rois, const int *num_rois_dev, int pooled_height,
                                  int pooled_width, int sampling_ratio, float *out_nhwc, int *levels_out);
 
+/* r13: the same launch with a workgroup -> ROI table: workgroup b takes ROI order[b] (order == NULL: its own index). Output rows stay at the
+ * ROI's own index: results are bit-identical whatever the table, only the workgroup -> XCD assignment changes (workgroup b runs on XCD
+ * b % 8, each XCD has its own L2). upsnet_fpn_roi_order fills the table so that every XCD's workgroups take one contiguous range of the
+ * ROIs bucketed by (pyramid level, 1/16 stripe of the image, 1/8 column cell; image_height x image_width = the extent the ROIs live in):
+ * neighbouring ROIs share an L2 instead of every L2 fetching its own
+ * copy of the shared pyramid cells (FPNRoIAlign.forward, upsnet/operators/modules/fpn_roi_align.py:32-62, processes level by level too).
+ * num_rois <= 2048 for the table; caller-allocated int[num_rois]. */
+int upsnet_fpn_roi_order(void *stream, const float *rois, int num_rois, const int *num_rois_dev, int image_height, int image_width,
+                         int *order_out);
+int upsnet_fpn_roi_align_forward_ordered(void *stream, const float *const feat_nhwc[4], const int feat_h[4], const int feat_w[4],
+                                         const float spatial_scale[4], int channels, const float *rois, int num_rois, const int *num_rois_dev,
+                                         int pooled_height, int pooled_width, int sampling_ratio, float *out_nhwc, int *levels_out,
+                                         const int *order);
+
 /* Development knob of upsnet_fpn_roi_align_forward: 0 = LDS tap-table kernel, one register set; 1 = two sets;
  * 2 = the r03-r07 kernel (per-bin tap setup in registers); 3 = the table kernel loading only the UNIQUE corner cells of a bin (r11);
  * 4 = 3 with packed fp32 blend arithmetic; < 0 = back to the default behaviour: the environment variable UPSNET_ROI_KERNEL (a variant number)

@@ -81,6 +81,46 @@ def test_fpn_roi_align_padded_tail(U):
     assert not out[6:].any()
 
 
+@pytest.mark.parametrize("N,ph,nvalid", [(1000, 7, None), (300, 7, None), (100, 14, None), (1, 7, None), (37, 7, 21), (2048, 7, 1999), (9, 14, 0)])
+def test_fpn_roi_align_xcd_order_is_a_permutation_and_changes_no_bit(U, N, ph, nvalid):
+    """r13 (csrc/roi_align.hip, fpn_roi_order_kernel): the workgroup -> ROI table that deals the ROIs to the XCDs by image neighbourhood is a
+    permutation of 0..N-1 for every N (multiples of 8 or not, a device-side valid count, none valid), rows beyond the valid count sit at
+    its end, and the launch through it returns the SAME bits as the launch in ROI order == the oracle -- at the benchmark shapes too."""
+    rng = np.random.default_rng(N + ph)
+    H, W = 256, 512
+    feats = [rng.normal(size=(1, 32, H // s, W // s)).astype(np.float32) for s in (4, 8, 16, 32)]
+    rois = gen_rois(rng, N, H, W, 4, 200)
+    nd = None if nvalid is None else torch.tensor([nvalid], dtype=torch.int32).cuda()
+    g = [cu(f) for f in feats]
+    order = U.fpn_roi_order(cu(rois), (H, W), num_rois_dev=nd)
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(N))
+    nv = N if nvalid is None else nvalid
+    # workgroup b runs on XCD b % 8 and takes ROI o[b]: rows beyond the valid count were ordered last = the last positions of the last XCDs
+    cnt = [(N - j + 7) // 8 for j in range(8)]
+    pos = np.empty(N, np.int64)
+    for b in range(N):
+        pos[o[b]] = sum(cnt[:b % 8]) + b // 8
+    if nv < N:
+        assert pos[nv:].min() >= nv and (nv == 0 or pos[:nv].max() < nv)
+    sc = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    a = U.fpn_roi_align(g, cu(rois), ph, ph, sc, num_rois_dev=nd, order=None)
+    b = U.fpn_roi_align(g, cu(rois), ph, ph, sc, num_rois_dev=nd, order=order)
+    c = U.fpn_roi_align(g, cu(rois), ph, ph, sc, num_rois_dev=nd)            # 'auto'
+    assert torch.equal(a, b) and torch.equal(a, c)
+    if N <= 300:
+        assert not a.cpu().numpy()[nv:].any()
+        if nv:
+            assert np.array_equal(a.cpu().numpy()[:nv], oops.fpn_roi_align(feats, rois[:nv], ph, ph))
+    if nv >= 64:   # the dealing does what it is for: the ROIs of one XCD are neighbours (same level, nearby stripes) -- fewer distinct
+        lv = oops.fpn_level(rois[:nv])            # (level, stripe) cells per XCD than in ROI order
+        stripe = np.clip(((rois[:nv, 2] + rois[:nv, 4]) * 0.5 * 16 / H).astype(np.int64), 0, 15)
+        cell = lv * 16 + stripe
+        dealt = np.mean([len(set(cell[[o[b] for b in range(j, N, 8) if o[b] < nv]])) for j in range(8)])
+        plain = np.mean([len(set(cell[[b for b in range(j, N, 8) if b < nv]])) for j in range(8)])
+        assert dealt < 0.6 * plain, (dealt, plain)
+
+
 # ------------------------------------------------------------------ deformable conv
 @pytest.mark.parametrize("C,H,W,k,pad,stride,dil,dg", [(8, 12, 17, 3, 1, 1, 1, 1), (12, 9, 9, 3, 2, 1, 2, 2), (4, 16, 16, 3, 1, 2, 1, 1)])
 def test_deform_im2col_bitexact(U, C, H, W, k, pad, stride, dil, dg):

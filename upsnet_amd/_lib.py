@@ -22,6 +22,8 @@ _SIGNATURES = {
     "upsnet_roi_align_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "upsnet_roi_align_forward_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int, c_int, c_int, P]),
     "upsnet_fpn_roi_align_forward": (c_int, [P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P]),
+    "upsnet_fpn_roi_order": (c_int, [P, P, c_int, P, c_int, c_int, P]),
+    "upsnet_fpn_roi_align_forward_ordered": (c_int, [P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P]),
     "upsnet_roi_tuning": (None, [c_int]),
     "upsnet_roi_geometry": (None, [c_int, c_int]),
     "upsnet_deform_im2col": (c_int, [P, P, P] + [c_int] * 13 + [P]),

@@ -548,11 +548,14 @@ template <int SETS, int SHARE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SETS == 1 ? 4 : 3, SETS == 1 ? 5 : 3)))
 fpn_roi_align_nhwc_tab_kernel(const FpnFeat ft, const int channels, const float *__restrict__ rois, const int num_rois,
                               const int *__restrict__ num_rois_dev, const int pooled_h, const int pooled_w,
-                              float *__restrict__ out, int *__restrict__ levels_out)
+                              float *__restrict__ out, int *__restrict__ levels_out, const int *__restrict__ order)
 {
     __shared__ RoiAxis ytab[2 * ROI_MAXP], xtab[2 * ROI_MAXP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n = blockIdx.x;
+    if ((int)blockIdx.x >= num_rois) return;        // (grid.x is padded to a multiple of 8: workgroup (x, y) then runs on XCD x % 8 for every y)
+    // which ROI this workgroup takes: its own index, or -- r13 -- the entry of the XCD dealing table (fpn_roi_order_kernel): output rows
+    // stay at the ROI's own index, only the workgroup -> XCD assignment changes
+    const int n = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x;
     const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
     const int c4n = channels >> 2;
     const int nbins_all = pooled_h * pooled_w;
@@ -694,11 +697,109 @@ static int roi_variant(const int bins)
     return bins >= 100 ? 3 : 0;
 }
 
+// ---- ROI -> XCD dealing (r13). Workgroup b of the ROIAlign launch runs on XCD b % 8 and every XCD has its own L2: with the ROIs in score
+// order (proposals) or random order, each of the eight L2s fetches its own copy of the pyramid cells its ROIs share with the other XCDs'
+// ROIs -- 346 MB fetched at the fabric for a 178 MB pyramid on the 1000 x 7 x 7 launch (profiles/r11_roialign_pmc.txt), which is what
+// bounds the kernel. This kernel orders the ROIs by (pyramid level, image stripe of the centre, column cell) and deals the ordered
+// list so that XCD j's workgroups (b = j, j + 8, ...) take one contiguous range of it: neighbours in the image share an L2.
+// order[b] = ROI index workgroup b processes; the output rows are untouched (bit-identical results). One workgroup, <= 2048 ROIs.
+#define ROI_ORDER_MAX 2048
+#define ROI_ORDER_NB (4 * 16 * 8 + 1)     // (level, 16 image stripes, 8 column cells) + one bucket for the rows beyond the valid count
+// A counting sort, not a comparison sort (a 1024-key bitonic network in one workgroup takes ~20 us -- more than the dealing saves): bucket =
+// (pyramid level, stripe of the ROI centre, column cell), position = bucket base + arrival slot. The order INSIDE a bucket is the order in
+// which the LDS atomics of phase 1 are served -- it only decides which of two neighbouring workgroups takes which of two neighbouring ROIs.
+__global__ void __launch_bounds__(1024)
+fpn_roi_order_kernel(const float *__restrict__ rois, const int num_rois, const int *__restrict__ num_rois_dev, const float inv_stripe_h,
+                     const float inv_cell_w, int *__restrict__ order)
+{
+    __shared__ int cnt[ROI_ORDER_NB + 63];
+    const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
+    for (int i = threadIdx.x; i < ROI_ORDER_NB + 63; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    int bkt[2], slot[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = threadIdx.x + q * 1024;
+        bkt[q] = -1;
+        if (i < num_rois) {
+            int b = ROI_ORDER_NB - 1;
+            if (i < nvalid) {
+                const float *r = rois + (long)i * 5;
+                const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
+                const int lvl = fpn_level_of(x1, y1, x2, y2);
+                const int st = min(max((int)((y1 + y2) * 0.5f * inv_stripe_h), 0), 15), cell = min(max((int)((x1 + x2) * 0.5f * inv_cell_w), 0), 7);
+                b = (lvl * 16 + st) * 8 + ((st & 1) ? 7 - cell : cell);     // (boustrophedon: consecutive buckets are neighbours in the image)
+            }
+            bkt[q] = b;
+            slot[q] = atomicAdd(&cnt[b], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                  // exclusive scan of the bucket counts by one wave: 9 consecutive buckets per lane
+        constexpr int PER = (ROI_ORDER_NB + 63) / 64;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { loc[u] = cnt[threadIdx.x * PER + u]; sum += loc[u]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += v; }
+        int run = incl - sum;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { cnt[threadIdx.x * PER + u] = run; run += loc[u]; }
+    }
+    __syncthreads();
+    // XCD j owns workgroups j, j + 8, ...: n_j = ceil((N - j) / 8) of them; it takes sorted positions [start_j, start_j + n_j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (bkt[q] < 0) continue;
+        const int k = cnt[bkt[q]] + slot[q];
+        int j = 0, start = 0;
+        bool found = false;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int nj = (num_rois - x + 7) >> 3;
+            if (!found) { if (k < start + nj) { j = x; found = true; } else start += nj; }
+        }
+        order[(k - start) * 8 + j] = threadIdx.x + q * 1024;
+    }
+}
+
+/* order_out[b] = the ROI workgroup b of upsnet_fpn_roi_align_forward_ordered should take so that each XCD's workgroups cover one contiguous
+ * range of the ROIs bucketed by (pyramid level, 1/16 stripe of the image, 1/8 column cell of the image). rois [num_rois, 5] device in image
+ * pixels, num_rois <= 2048; image_height / image_width: the extent the ROIs live in (only the bucket granularity depends on it). */
+extern "C" int upsnet_fpn_roi_order(void *stream, const float *rois, int num_rois, const int *num_rois_dev, int image_height, int image_width,
+                                    int *order_out)
+{
+    UPS_REQUIRE(rois && order_out && num_rois >= 0 && num_rois <= ROI_ORDER_MAX, "fpn_roi_order: 0..%d rois (got %d)", ROI_ORDER_MAX, num_rois);
+    UPS_REQUIRE(image_height > 0 && image_width > 0, "fpn_roi_order: bad image extent");
+    if (num_rois == 0) return 0;
+    hipLaunchKernelGGL(fpn_roi_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rois, num_rois, num_rois_dev, 16.0f / (float)image_height,
+                       8.0f / (float)image_width, order_out);
+    UPS_CHECK_LAUNCH("fpn_roi_order_kernel");
+    return 0;
+}
+
+extern "C" int upsnet_fpn_roi_align_forward_ordered(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
+                                                    const int feat_w[4], const float spatial_scale[4], int channels,
+                                                    const float *rois, int num_rois, const int *num_rois_dev,
+                                                    int pooled_height, int pooled_width, int sampling_ratio,
+                                                    float *out_nhwc, int *levels_out, const int *order);
+
 extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
                                             const int feat_w[4], const float spatial_scale[4], int channels,
                                             const float *rois, int num_rois, const int *num_rois_dev,
                                             int pooled_height, int pooled_width, int sampling_ratio,
                                             float *out_nhwc, int *levels_out)
+{
+    return upsnet_fpn_roi_align_forward_ordered(stream, feat_nhwc, feat_h, feat_w, spatial_scale, channels, rois, num_rois, num_rois_dev,
+                                                pooled_height, pooled_width, sampling_ratio, out_nhwc, levels_out, nullptr);
+}
+
+extern "C" int upsnet_fpn_roi_align_forward_ordered(void *stream, const float *const feat_nhwc[4], const int feat_h[4],
+                                                    const int feat_w[4], const float spatial_scale[4], int channels,
+                                                    const float *rois, int num_rois, const int *num_rois_dev,
+                                                    int pooled_height, int pooled_width, int sampling_ratio,
+                                                    float *out_nhwc, int *levels_out, const int *order)
 {
     UPS_REQUIRE(feat_nhwc && rois && out_nhwc, "fpn_roi_align_forward: null pointer");
     UPS_REQUIRE(channels > 0 && (channels & 3) == 0, "fpn_roi_align_forward: channels must be a multiple of 4 (got %d)", channels);
@@ -717,19 +818,21 @@ extern "C" int upsnet_fpn_roi_align_forward(void *stream, const float *const fea
         if (nsplit > nb / g_roi_min_bins) nsplit = nb / g_roi_min_bins;
         if (nsplit < 1) nsplit = 1;
         const int variant = (pooled_height <= ROI_MAXP && pooled_width <= ROI_MAXP) ? roi_variant(nb) : 2;
+        const int nx8 = (num_rois + 7) / 8 * 8;
+        // (variant 2, the r03-r07 kernel kept for A/B runs, has no table: it runs in ROI order -- same bits)
         if (variant == 3 || variant == 4) {
             if (variant == 3)
-                hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 1>), dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
-                                   num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+                hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 1>), dim3(nx8, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                                   num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out, order);
             else
-                hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 2>), dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
-                                   num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+                hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 2>), dim3(nx8, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                                   num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out, order);
         } else if (variant == 0)
-            hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 0>), dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
-                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+            hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<1, 0>), dim3(nx8, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out, order);
         else if (variant == 1)
-            hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<2, 0>), dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
-                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);
+            hipLaunchKernelGGL((fpn_roi_align_nhwc_tab_kernel<2, 0>), dim3(nx8, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
+                               num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out, order);
         else
             hipLaunchKernelGGL(fpn_roi_align_nhwc_roi_kernel, dim3(num_rois, nsplit), dim3(256), 0, (hipStream_t)stream, ft, channels, rois, num_rois,
                                num_rois_dev, pooled_height, pooled_width, out_nhwc, levels_out);

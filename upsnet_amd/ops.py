@@ -63,9 +63,28 @@ def roi_align_algorithmic_bytes(feats, n, C, ph, pw):
     return 4.0 * n * C * ph * pw + 20.0 * n + min(feat_bytes, 4.0 * n * C * (2 * ph + 1) * (2 * pw + 1))
 
 
+# r13: deal the ROIs to the XCDs by image neighbourhood (csrc/roi_align.hip, fpn_roi_order_kernel: one extra single-workgroup launch per call).
+# 'auto': for launches of >= ROI_XCD_ORDER_MIN ROIs. Results are bit-identical either way.
+ROI_XCD_ORDER = os.environ.get('UPSNET_ROI_XCD_ORDER', '1') != '0'
+ROI_XCD_ORDER_MIN = int(os.environ.get('UPSNET_ROI_XCD_ORDER_MIN', '256'))
+
+
+def fpn_roi_order(rois, image_hw, num_rois_dev=None):
+    """int32 [N]: the workgroup -> ROI table of fpn_roi_align(order=...) that gives every XCD one contiguous range of the ROIs sorted by
+    (pyramid level, image stripe, column cell). image_hw: extent of the image the ROIs live in. N <= 2048."""
+    require_cuda(rois)
+    rois = f32c(rois)
+    order = torch.empty((max(rois.shape[0], 1),), dtype=torch.int32, device=rois.device)
+    check(lib().upsnet_fpn_roi_order(stream(), ptr(rois), int(rois.shape[0]), ptr(num_rois_dev), int(image_hw[0]), int(image_hw[1]), ptr(order)),
+          "fpn_roi_order")
+    return order[:rois.shape[0]]
+
+
 def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=2, num_rois_dev=None,
-                  return_levels=False):
+                  return_levels=False, order='auto'):
     """FPNRoIAlign.forward on device: feats = 4 logical-NCHW tensors (batch 1), rois [N,5].
+    order: None = workgroup b takes ROI b; an int32 [N] table from fpn_roi_order; 'auto' = build the table when the launch has at least
+    ROI_XCD_ORDER_MIN ROIs (UPSNET_ROI_XCD_ORDER=0 switches it off). Same bits in every case.
 
     Returns a channels_last [N,C,PH,PW] tensor in the original ROI order."""
     require_cuda(rois, *feats)
@@ -80,13 +99,17 @@ def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio
     dev = rois.device
     out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     levels = torch.empty((max(N, 1),), dtype=torch.int32, device=dev) if return_levels else None
+    if isinstance(order, str):
+        order = fpn_roi_order(rois, (int(round(feats[0].shape[2] / spatial_scale[0])), int(round(feats[0].shape[3] / spatial_scale[0]))),
+                              num_rois_dev) if (ROI_XCD_ORDER and sampling_ratio == 2 and ROI_XCD_ORDER_MIN <= N <= 2048 and
+                                                       max(pooled_h, pooled_w) <= 16) else None
     if PROFILE['enabled']:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().upsnet_fpn_roi_align_forward(stream(), ptr_array(feats), int_array([f.shape[2] for f in feats]),
-                                             int_array([f.shape[3] for f in feats]), float_array(spatial_scale), C,
-                                             ptr(rois), N, ptr(num_rois_dev), int(pooled_h), int(pooled_w),
-                                             int(sampling_ratio), ptr(out), ptr(levels)), "fpn_roi_align_forward")
+    check(lib().upsnet_fpn_roi_align_forward_ordered(stream(), ptr_array(feats), int_array([f.shape[2] for f in feats]),
+                                                     int_array([f.shape[3] for f in feats]), float_array(spatial_scale), C,
+                                                     ptr(rois), N, ptr(num_rois_dev), int(pooled_h), int(pooled_w),
+                                                     int(sampling_ratio), ptr(out), ptr(levels), ptr(order)), "fpn_roi_align_forward_ordered")
     if PROFILE['enabled']:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
