@@ -402,6 +402,13 @@ int upsnet_conv2d_winograd36_nhwc_f32(void *stream, int nseg, const float *const
                                       const int height[], const int width[], int Cin, const float *wpack, int ldw, const float *bias,
                                       int Cout, int relu);
 int upsnet_conv_pack_weight_winograd36(void *stream, const float *weight, int cout, int cin, int ldw, float *wpack);
+/* r13: upsnet_conv2d_winograd36_nhwc_f32 of ONE map with the channel walk of every tile split over `ksplit` (2..8, <= Cin / 16) workgroups: each
+ * stores the output transform of its partial sums, the shared reduce / epilogue kernel adds them in a fixed order (+ bias, ReLU;
+ * bit-repeatable). For maps with fewer 32-tile x 64-channel workgroups than CUs (res3 / res4 conv2, FPN P4 at 1024x2048). workspace:
+ * upsnet_conv2d_winograd36_splitk_workspace_bytes(batch, height, width, Cout, ksplit) bytes, caller-allocated. */
+size_t upsnet_conv2d_winograd36_splitk_workspace_bytes(int batch, int height, int width, int Cout, int ksplit);
+int upsnet_conv2d_winograd36_nhwc_f32_splitk(void *stream, const float *x, float *out, int batch, int height, int width, int Cin,
+                                             const float *wpack, int ldw, const float *bias, int Cout, int relu, int ksplit, void *workspace);
 
 /* 1x1 convolution (stride 1 / 2; + bias, + residual, ReLU) on SMALL tiles (csrc/conv1x1_ksw.hip, r13): `v_mfma_f32_16x16x4_f32` fragments,
  * every wave of a workgroup holds the whole tile_pixels x tile_channels tile and walks a quarter of K straight from the NHWC map (no LDS /

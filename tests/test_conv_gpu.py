@@ -962,6 +962,33 @@ def test_winograd36_real_size_margin(name, segs, Cin, Cout):
     assert worst <= 0.35 and worst2 <= 0.15, (worst, worst2)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,relu,bias", [
+    (1, 64, 128, 256, 256, 4, True, True),        # res4 conv2 / FPN P4 at 1024x2048
+    (1, 128, 256, 128, 128, 2, True, True),       # res3 conv2
+    (1, 33, 47, 64, 100, 3, False, True),         # ragged tiles, Cout % 64 != 0, 4 slabs split 3 ways (1 + 1 + 2)
+    (2, 9, 13, 32, 64, 2, True, False),           # two images, one slab each
+])
+def test_winograd36_splitk_vs_fp64_and_unsplit(N, H, W, Cin, Cout, ks, relu, bias):
+    """csrc/conv_wino36.hip, r13: the split-K instance (each workgroup stores the output transform of its partial sums, the reduce kernel adds
+    them + bias + ReLU) within 1e-4 of float64 with the margin of the unsplit kernel (<= 0.35), within summation-order distance of the unsplit
+    kernel, bit-repeatable."""
+    from upsnet_amd import ops
+    torch.manual_seed(Cin + Cout + ks)
+    x = torch.randn(N, Cin, H, W, device='cuda').relu_().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, device='cuda') if bias else None
+    wp, ldw = ops.pack_winograd36_weight(w)
+    y = ops.conv2d_winograd36_splitk(x, wp, ldw, b, Cout, ks, relu=relu)
+    assert ops.last_kernel_form() == 'wino36<32,64> splitk%d' % ks
+    y0 = ops.conv2d_winograd36_multi([x], wp, ldw, b, Cout, relu)[0]
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    ref = ref.clamp_min(0) if relu else ref
+    worst = ((y.double() - ref).abs() / (1e-4 + 1e-4 * ref.abs())).max().item()
+    assert worst <= 0.35, worst
+    assert float((y - y0).abs().max()) < 5e-5
+    assert torch.equal(y, ops.conv2d_winograd36_splitk(x, wp, ldw, b, Cout, ks, relu=relu))
+
+
 @pytest.mark.gpu
 def test_winograd36_roi_batches_do_not_depend_on_the_batch(monkeypatch):
     """hipconv (r11, UPSNET_WINO36_ROI=1): a pinned layer fed by ROI batches (the mask head) runs on the F(4x4,3x3) kernel for every batch

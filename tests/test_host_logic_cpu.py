@@ -208,6 +208,9 @@ def test_winograd_f4x4_routing_rule(monkeypatch):
     assert use(c3, [x(1, 200, 336)])                                                       # UPSNet-101-DCN 800x1333 FPN P2: 528 of 768 = 0.69
     assert use(c3, [x(1, 200, 336), x(1, 100, 168), x(1, 50, 84), x(1, 25, 42), x(1, 13, 21)])
     assert not use(c3, [x(1, 132, 256)])                                                   # 264 workgroups: a second round 3 % full
+    assert use(c3, [x(1, 100, 168)])                                                       # r13: UPSNet-101-DCN 800x1333 FPN P3, 132 workgroups = half a round, 16 slabs: 94.9 vs 120.6 us
+    assert hipconv._wino36_ksplit(c3, x(1, 64, 128)) == 4 and hipconv._wino36_ksplit(nn.Conv2d(128, 128, 3, padding=1), x(1, 128, 256, 128)) == 2   # (opt-in split-K form)
+    assert hipconv._wino36_ksplit(c3, x(1, 100, 168)) == 1 and hipconv._wino36_ksplit(c3, x(1, 32, 64)) == 1 and hipconv._wino36_ksplit(c3, x(1, 256, 512)) == 1
     assert not use(nn.Conv2d(256, 18, 3, padding=1), [x(1, 256, 512)])                     # offset predictors: Cout % 64
     assert not use(nn.Conv2d(48, 64, 3, padding=1), [x(1, 256, 512, 48)])                  # Cin % 32
     assert not use(c3, [x(1, 256, 512, dt=torch.bfloat16)])

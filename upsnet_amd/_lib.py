@@ -56,6 +56,8 @@ _SIGNATURES = {
     "upsnet_conv3x3_ksw_packed_weight_floats": (ctypes.c_size_t, [c_int]),
     "upsnet_conv3x3_ksw_pack_weight": (c_int, [P, P, c_int, c_int, P]),
     "upsnet_conv3x3_ksw_nhwc_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int]),
+    "upsnet_conv2d_winograd36_splitk_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "upsnet_conv2d_winograd36_nhwc_f32_splitk": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P]),
     "upsnet_conv1x1_pair_nhwc_f32": (c_int, [P, P, P, P, P, c_long, c_int, P, P, c_int, P, P, c_int]),
     "upsnet_conv2d_nhwc_f32": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "upsnet_conv2d_nhwc_f32_multiw": (c_int, [P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -77,6 +77,10 @@ typedef unsigned w36_uintx4 __attribute__((ext_vector_type(4)));
         Y3 = __builtin_fmaf(3.375f, d2_, __builtin_fmaf(0.421875f, d1_, (M5)));                                      \
     }
 
+// SK (r13): split-K instance for single maps with fewer workgroups than CUs (res3 / res4 conv2, FPN P4 at 1024x2048: 64-128 workgroups): workgroup
+// (tile, kz) walks slabs [kz, kz + 1) * nslabs / ksplit and stores the output transform of its PARTIAL M (the transform is linear) without bias
+// / ReLU into p.partial[kz]; conv_splitk_reduce adds the partials in a fixed order, + bias, ReLU. The unsplit instance is the r12 kernel.
+template <bool SK>
 __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -86,11 +90,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
     const int lhalf = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD gets a contiguous range of m-tiles, and all n-tiles of an
     // m-tile (they share the input patches) stay on that XCD. Same scheme as conv_wino16_f32_kernel.
-    int m_t, n_t;
+    int m_t, n_t, kz = 0;
     {
         const int nt = p.n_tiles;
         const int per = (p.m_tiles + 7) >> 3;
-        const int bid = (int)blockIdx.x;
+        int bid = (int)blockIdx.x;
+        if constexpr (SK) { const int base_grid = 8 * per * nt; kz = bid / base_grid; bid -= kz * base_grid; }
         const int q = bid >> 3;
         n_t = q % nt;
         const int local = q / nt;
@@ -102,7 +107,10 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
     for (int q = 1; q < CV_MAXSEG; ++q) if (q < p.nseg && m_t >= p.seg[q].tile_start) si = q;
     const ConvSeg sg = p.seg[si];
     const long p0 = (long)(m_t - sg.tile_start) * W36_TM;
-    const int nslabs = p.Cin >> 4;
+    const int nslabs_all = p.Cin >> 4;
+    // this workgroup's slabs [s_first, s_first + nslabs): all of them, or (SK) the kz-th share (launcher: never empty)
+    const int s_first = SK ? (kz * nslabs_all) / p.ksplit : 0;
+    const int nslabs = SK ? ((kz + 1) * nslabs_all) / p.ksplit - s_first : nslabs_all;
     const long HoWo = (long)sg.Ho * sg.Wo;               // tiles per image (Ho, Wo count 4x4 output tiles here)
 
     // ---- loader geometry: thread = (tile tid / 16, channel tid % 16 of the slab)
@@ -164,8 +172,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
 #define W36_ROWOFF(R) (((unsigned)min(max(hrow0 + (R), hlo), max(hhi - 1, hlo)) * rowpitch) | ((hrow0 + (R) >= hlo && hrow0 + (R) < hhi) ? 0u : 0x80000000u))
     const size_t xaddr = reinterpret_cast<size_t>(sg.x);
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));
-    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin);
-    const char *xbase = reinterpret_cast<const char *>(((size_t)xhi << 32) | xlo);
+    const unsigned xbytes = __builtin_amdgcn_readfirstlane((unsigned)(sg.N * sg.H * sg.W) * 4u * (unsigned)p.Cin - (SK ? (unsigned)s_first * 64u : 0u));
+    const char *xbase = reinterpret_cast<const char *>(((size_t)xhi << 32) | xlo) + (SK ? (size_t)s_first * 64 : 0);   // (+ the first slab's channels)
     // LDS: stash address of this thread's 4 bytes inside unit [xi][q = c / 4][tile ^ swz(q)]; fragment unit of step (xi, h): [xi][2 h + lhalf][row ^ swz(q)].
     // swz(q) = 4 (q & 1) | 2 (q >> 1): with the first form of the kernel (tile ^ 4 q) the q = 0 / 2 and the q = 1 / 3 lanes of a half wave
     // shared their banks (SQ_LDS_BANK_CONFLICT: 4.2 M cycles per launch against 0 for the F(2x2) kernel, profiles/r12_wino_pmc.txt)
@@ -175,7 +183,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
     const unsigned fr_base0 = (unsigned)((lhalf * W36_TM + (l32 ^ W36_SWZ(lhalf))) * 16) + (unsigned)pg * 9u * XI_PITCH;             // h = 0: q = lhalf
     const unsigned fr_base1 = (unsigned)(((2 + lhalf) * W36_TM + (l32 ^ W36_SWZ(2 + lhalf))) * 16) + (unsigned)pg * 9u * XI_PITCH;  // h = 1: q = 2 + lhalf
     // B: lane's float4 of step g = s * 72 + 2 xi + h sits at wbase + g * BSTEP + lhalf * 1024 + (32 cb + l32) * 16
-    const size_t waddr = reinterpret_cast<size_t>(p.w) + (size_t)n_t * (size_t)nslabs * (W36_STEPS * W36_BSTEP);
+    const size_t waddr = reinterpret_cast<size_t>(p.w) + ((size_t)n_t * (size_t)nslabs_all + (size_t)s_first) * (W36_STEPS * W36_BSTEP);
     const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)waddr), whi = __builtin_amdgcn_readfirstlane((unsigned)(waddr >> 32));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((size_t)whi << 32) | wlo), 0,
                                                                             nslabs * (int)(W36_STEPS * W36_BSTEP), 0x00020000);
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
 
     // ---- output transform Y = A^T M A through LDS, one column block at a time: [element r][xi][lane] floats
     const unsigned crow = (unsigned)p.Cout * 4u;
-    const size_t oaddr_ = reinterpret_cast<size_t>(sg.out);
+    const size_t oaddr_ = reinterpret_cast<size_t>(SK ? p.partial + (size_t)kz * (size_t)p.m_total * (size_t)p.Cout : sg.out);
     const unsigned obytes_ = __builtin_amdgcn_readfirstlane((unsigned)((long)sg.N * sg.OH * sg.OW) * crow);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void *>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(oaddr_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)oaddr_)),
@@ -332,8 +340,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino36_f32_kernel(const ConvParam
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int oy = 4 * ty + a;
-                    float v = y[a] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    float v = y[a];
+                    if constexpr (!SK) { v = v + bv; if (p.relu) v = fmaxf(v, 0.f); }
                     const unsigned off = (oy < sg.OH && ox < sg.OW) ? (unsigned)((n * sg.OH + oy) * sg.OW + ox) * crow + 4u * (unsigned)co_ch : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, off, 0, 0);
                 }
@@ -376,12 +384,44 @@ extern "C" int upsnet_conv2d_winograd36_nhwc_f32(void *stream, int nseg, const f
     int rc = w36_fill(p, "conv2d_winograd36_nhwc_f32", nseg, x, out, batch, height, width, Cin, Cout, wpack, ldw, bias, relu);
     if (rc) return rc;
     static std::atomic<unsigned long long> attr_dev{0};
-    UPS_ONCE_PER_DEVICE(attr_dev, UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino36_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W36_XCH)));
+    UPS_ONCE_PER_DEVICE(attr_dev, UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino36_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W36_XCH)));
     const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles;
-    hipLaunchKernelGGL(conv_wino36_f32_kernel, dim3(grid), dim3(512), W36_XCH, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_wino36_f32_kernel<false>, dim3(grid), dim3(512), W36_XCH, (hipStream_t)stream, p);
     UPS_CHECK_LAUNCH("conv_wino36_f32_kernel");
     ups_set_form("wino36<%d,%d>", W36_TM, W36_TN);
     return 0;
+}
+
+/* The same convolution of ONE map with the channel walk of every tile split over `ksplit` (2..8) workgroups (+ the shared reduce / epilogue
+ * kernel; fixed summation order: bit-repeatable): for maps with fewer 32-tile x 64-channel workgroups than CUs. workspace:
+ * upsnet_conv2d_winograd36_splitk_workspace_bytes bytes, caller-allocated. Cin / 16 >= ksplit. */
+extern "C" size_t upsnet_conv2d_winograd36_splitk_workspace_bytes(int batch, int height, int width, int Cout, int ksplit)
+{
+    return (size_t)ksplit * (size_t)batch * height * width * Cout * sizeof(float);
+}
+
+extern "C" int upsnet_conv2d_winograd36_nhwc_f32_splitk(void *stream, const float *x, float *out, int batch, int height, int width, int Cin,
+                                                        const float *wpack, int ldw, const float *bias, int Cout, int relu, int ksplit,
+                                                        void *workspace)
+{
+    const float *xs[1] = {x};
+    float *os[1] = {out};
+    const int nb[1] = {batch}, hh[1] = {height}, ww[1] = {width};
+    ConvParams p;
+    int rc = w36_fill(p, "conv2d_winograd36_nhwc_f32_splitk", 1, xs, os, nb, hh, ww, Cin, Cout, wpack, ldw, bias, relu);
+    if (rc) return rc;
+    UPS_REQUIRE(workspace && ksplit >= 2 && ksplit <= 8 && Cin / 16 >= ksplit, "conv2d_winograd36_nhwc_f32_splitk: ksplit 2..8, <= Cin / 16, and a workspace");
+    p.ksplit = ksplit;
+    p.partial = (float *)workspace;
+    p.m_total = (long)batch * height * width;         // rows of one partial: the output pixels
+    UPS_REQUIRE(p.m_total * Cout < (1L << 29), "conv2d_winograd36_nhwc_f32_splitk: output exceeds 2 GiB; split the batch");
+    static std::atomic<unsigned long long> attr_dev{0};
+    UPS_ONCE_PER_DEVICE(attr_dev, UPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino36_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W36_XCH)));
+    const int grid = 8 * ((p.m_tiles + 7) / 8) * p.n_tiles * ksplit;
+    hipLaunchKernelGGL(conv_wino36_f32_kernel<true>, dim3(grid), dim3(512), W36_XCH, (hipStream_t)stream, p);
+    UPS_CHECK_LAUNCH("conv_wino36_f32_kernel<splitk>");
+    ups_set_form("wino36<%d,%d> splitk%d", W36_TM, W36_TN, ksplit);
+    return conv_splitk_reduce((hipStream_t)stream, p.partial, ksplit, p.m_total, p.m_total, Cout, bias, nullptr, relu, out);
 }
 
 // weight [Cout, Cin, 3, 3] -> U = G g G^T (double precision, rounded once), G of the points {0, 3/4, -3/4, 3/2, -3/2, inf} =

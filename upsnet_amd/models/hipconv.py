@@ -56,6 +56,11 @@ WINO36 = os.environ.get('UPSNET_WINO36', '1') != '0'
 WINO36_ROI = os.environ.get('UPSNET_WINO36_ROI', '0') != '0'   # the mask head (pinned kernel choice) on the F(4x4) form as well: same-box A/B 167.6 vs
 # 169.3 img/s, serial 6.375 vs 6.389 ms -- inside the run-to-run spread, so the F(2x2) form with its half-size tail stays the default
 WINO36_MIN_FILL = float(os.environ.get('UPSNET_WINO36_MIN_FILL', '0.65'))
+# r13: split-K F(4x4) for single maps with fewer workgroups than CUs (csrc/conv_wino36.hip, conv_wino36_f32_kernel<true> + reduce). Built and
+# measured (tools/bench_winograd36_splitk.py, 1024x2048): res3 conv2 54.8 -> 50.2 us (x2), res4 conv2 / FPN P4 48.2 -> 45.0 (x4), res5 conv2 and
+# P5 slower than the F(2x2) split-K form -- 3-5 us on ten launches (~0.7 % of the image) for 2-3x the rounding error on ten chained backbone
+# layers: OFF by default, UPSNET_WINO36_SPLITK=1 routes res3 / res4 conv2 and FPN P4 to it.
+WINO36_SPLITK = os.environ.get('UPSNET_WINO36_SPLITK', '0') != '0'
 SPLITK = os.environ.get('UPSNET_SPLITK', '1') != '0'
 # 1x1 convolutions (stride 1 / 2) with >= CONV1X1_MIN_WG workgroups of 64 pixels x 64 channels go through the lean GEMM kernel
 # (csrc/conv1x1.hip); smaller ones (res5's 2048-pixel maps: split-K) and Cout < 32 heads stay on the general kernel.
@@ -508,7 +513,25 @@ def _use_winograd36(m, xs):
         return False
     cus = _cus(xs[0].device)
     wgs = sum(-(-(x.shape[0] * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 3) // 4)) // 32) for x in xs) * (m.out_channels // 64)
+    if cus // 2 <= wgs < cus and m.in_channels >= 256:
+        # (r13) half a round of workgroups with a long channel walk (>= 16 slabs against the ~9.5 us a workgroup costs besides them): still faster
+        # than the F(2x2) form -- UPSNet-101-DCN at 800x1333, FPN P3 on the 100 x 168 map: 132 workgroups, 94.9 vs 120.6 us
+        # (tools/bench_winograd36_splitk.py); with 128 input channels (res3 conv2 at 1024x2048: 57.6 vs 54.8) it is not
+        return True
     return wgs >= cus and wgs >= WINO36_MIN_FILL * (-(-wgs // cus)) * cus
+
+
+def _wino36_ksplit(m, x):
+    """Split factor of the opt-in split-K F(4x4) form for one map: the split that brings the launch to one workgroup per CU, >= 4 slabs of 16
+    channels each; 1 = not this form (enough workgroups for the unsplit form, or fewer than cus / 8: res5 / P5, where F(2x2) split-K wins)."""
+    if not (WINO36 and WINOGRAD and _winograd36_shape_ok(m) and x.dtype == torch.float32):
+        return 1
+    cus = _cus(x.device)
+    wgs = -(-(x.shape[0] * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 3) // 4)) // 32) * (m.out_channels // 64)
+    if wgs >= cus or wgs < cus // 4 or (wgs >= cus // 2 and m.in_channels >= 256):   # (the last: the unsplit form takes those, _use_winograd36)
+        return 1
+    ks = min(cus // wgs, (m.in_channels // 16) // 4, 8)
+    return ks if ks >= 2 else 1
 
 
 def _use_winograd(m, xs, always=False):
@@ -598,6 +621,10 @@ def _conv(m, x, relu=False, residual=None, residual_up=False, winograd=True, pin
             return ops.conv2d_nhwc_bf16_multi([x], hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0],
                                               relu=relu, residuals=None if residual is None else [residual],
                                               residual_up=residual_up, out_dtype=od)[0], _bf16_form()
+        if winograd is True and not pin and residual is None and WINO36_SPLITK and _wino36_ksplit(m, x) > 1:
+            wp, ldw = _winograd36_plan(m)
+            ks = _wino36_ksplit(m, x)
+            return ops.conv2d_winograd36_splitk(x, wp, ldw, m.bias, m.out_channels, ks, relu=relu), 'winograd36 splitk%d' % ks
         if winograd is True and not pin and residual is None and _use_winograd36(m, [x]):
             wp, ldw = _winograd36_plan(m)
             return ops.conv2d_winograd36_multi([x], wp, ldw, m.bias, m.out_channels, relu=relu)[0], 'winograd36'

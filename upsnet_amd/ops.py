@@ -1352,6 +1352,28 @@ def conv2d_winograd36_multi(xs, wpack, ldw, bias, cout, relu=False, outs=None):
     return outs
 
 
+def conv2d_winograd36_splitk(x, wpack, ldw, bias, cout, ksplit, relu=False):
+    """conv2d_winograd36_multi for ONE map with the channel walk of every tile split over `ksplit` workgroups + the reduce / epilogue kernel
+    (csrc/conv_wino36.hip, r13): maps with fewer 32-tile x 64-channel workgroups than CUs."""
+    require_cuda(wpack, x)
+    x = nhwc(x.float())
+    N, cin, H, W = x.shape
+    out = _nhwc_out(N, cout, H, W, x.device)
+    ws = _ws(lib().upsnet_conv2d_winograd36_splitk_workspace_bytes(N, H, W, int(cout), int(ksplit)), x.device)
+    if PROFILE['enabled']:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().upsnet_conv2d_winograd36_nhwc_f32_splitk(stream(), ptr(x), ptr(out), N, H, W, int(cin), ptr(wpack), int(ldw),
+                                                         ptr(None if bias is None else f32c(bias)), int(cout), int(bool(relu)), int(ksplit), ptr(ws)),
+          "conv2d_winograd36_nhwc_f32_splitk")
+    if PROFILE['enabled']:
+        ev1.record()
+        npix = N * H * W
+        PROFILE['events'].append(('conv', ev0, ev1, 2.0 * cout * cin * 9 * npix, 4.0 * (cin * npix + cout * npix + cout * cin * 9),
+                                  "winograd36 split-K x%d 3x3/1 %d->%d %s" % (ksplit, cin, cout, (N, H, W))))
+    return out
+
+
 # ----------------------------------------------------------------------------- bf16 matrix-core convolution (opt-in)
 def pack_conv_weight_bf16(weight, split=True):
     """[Cout,Cin,kh,kw] fp32 -> (hi, lo, ldw): bf16 [kh*kw*Cin/32, ldw, 32] (as int16 storage), ldw = Cout rounded up to 64.
