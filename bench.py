@@ -298,7 +298,7 @@ def main():
         ex = f_exec / t_c / 1e12
         roofline = {'kernel': 'dense convolution family: conv1x1_frag_f32_kernel (csrc/conv1x1.hip) + conv_igemm_f32_kernel (csrc/conv.hip) + '
                               'conv_wino16_f32_kernel (Winograd F(2x2,3x3), csrc/conv_wino.hip) + conv_wino36_f32_kernel (Winograd F(4x4,3x3), '
-                              'csrc/conv_wino36.hip)', 'bound': 'mfma',
+                              'csrc/conv_wino36.hip) + conv1x1_ksw_f32_kernel / conv3x3_ksw_f32_kernel (small tiles of 16x16x4 fragments, csrc/conv1x1_ksw.hip)', 'bound': 'mfma',
                     'achieved': round(ex, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
                     'frac_of_launch_bounds': bound_frac('conv')[0], 'hbm_bound_launches': bound_frac('conv')[1],

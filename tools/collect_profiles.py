@@ -8,7 +8,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 for n in ('kernel_stats.txt', 'per_call.txt', 'timeline_serial.txt', 'conv_pmc.json', 'mfma_util_serial.txt', 'layer_table.txt', 'roialign.txt', 'parity.txt',
-          'pmc_FETCH_SIZE.txt', 'pmc_WRITE_SIZE.txt', 'timeline_graph_serial.txt', 'c3_conv_pmc.json', 'c3_pmc_FETCH_SIZE.txt', 'c3_pmc_WRITE_SIZE.txt', 'layer_table_c3.txt', 'bf16_kernel_stats.txt', 'bf16_timeline_serial.txt', 'bf16_micro.txt', 'stem_micro.txt', 'winograd36_micro.txt', 'mfma_valu.txt', 'mfma_util_graph.txt'):
+          'pmc_FETCH_SIZE.txt', 'pmc_WRITE_SIZE.txt', 'timeline_graph_serial.txt', 'c3_conv_pmc.json', 'c3_pmc_FETCH_SIZE.txt', 'c3_pmc_WRITE_SIZE.txt', 'layer_table_c3.txt', 'bf16_kernel_stats.txt', 'bf16_timeline_serial.txt', 'bf16_micro.txt', 'stem_micro.txt', 'winograd36_micro.txt', 'mfma_valu.txt', 'mfma_util_graph.txt', 'conv1x1_ksw.txt', 'conv3x3_ksw.txt', 'winograd36_splitk.txt', 'roi_xcd_order.txt'):
     p = os.path.join(src, '%s_%s' % (tag, n))
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, n)))

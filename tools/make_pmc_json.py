@@ -34,7 +34,7 @@ fetch, write = parse(fpath, 'FETCH_SIZE'), parse(wpath, 'WRITE_SIZE')
 # the launches bench.py's roofline counts as the dense family (upsnet_amd/ops.py, PROFILE events of kind 'conv'): the three convolution
 # kernels, the block-boundary pair kernels and the fused stem; a split-K launch's reduce kernel belongs to that launch (bytes, no count)
 DENSE = ('conv_igemm_f32_kernel', 'conv_wino16_f32_kernel', 'conv_wino36_f32_kernel', 'conv_wino16_tail_f32_kernel', 'conv1x1_frag_f32_kernel', 'conv1x1_pair_f32_kernel',
-         'conv1x1_pair32_f32_kernel', 'stem_pool_f32_kernel')
+         'conv1x1_pair32_f32_kernel', 'stem_pool_f32_kernel', 'conv1x1_ksw_f32_kernel', 'conv3x3_ksw_f32_kernel')
 EXTRA = ('conv_splitk_reduce',)
 per, n_tot, f_tot, w_tot = {}, 0, 0.0, 0.0
 for name, (n, f) in fetch.items():

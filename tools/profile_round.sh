@@ -40,6 +40,11 @@ cd $REPO
 python tools/microbench_stem.py > $OUT/${TAG}_stem_micro.txt 2>&1
 python tools/bench_winograd36.py > $OUT/${TAG}_winograd36_micro.txt 2>&1
 (hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_valu tools/ubench/mfma_valu.hip && /tmp/mfma_valu) > $OUT/${TAG}_mfma_valu.txt 2>&1
+# r13: the small-tile kernels against what they replace, the split-K F(4x4) form, the ROI -> XCD dealing
+python tools/bench_conv1x1_ksw.py > $OUT/${TAG}_conv1x1_ksw.txt 2>&1
+python tools/bench_conv3x3_ksw.py > $OUT/${TAG}_conv3x3_ksw.txt 2>&1
+python tools/bench_winograd36_splitk.py > $OUT/${TAG}_winograd36_splitk.txt 2>&1
+python tools/bench_roi_xcd_order.py > $OUT/${TAG}_roi_xcd_order.txt 2>&1
 UPSNET_WINO36=0 python bench.py --no-cpu-baseline --no-configs2 --no-wide-offsets --no-roialign > $OUT/${TAG}_bench_ab_no_wino36.log 2>&1
 python tools/make_pmc_json.py $TAG $OUT/${TAG}_pmc_FETCH_SIZE.txt $OUT/${TAG}_pmc_WRITE_SIZE.txt > $OUT/${TAG}_conv_pmc.json 2> $OUT/${TAG}_conv_pmc.err
 cp $OUT/${TAG}_conv_pmc.json profiles/${TAG}_conv_pmc.json   # (so that the bench line of this very run can report roofline.traffic)
