@@ -96,13 +96,14 @@ def roialign_microbench(H, W, n_iter=10):
             row[tag + '_us'] = round(us, 1)
             row[tag + '_GBs'] = round(alg / us / 1e3, 1)
             row[tag + '_frac'] = round(alg / us / 1e3 / PEAK_HBM_GBS, 4)
-        # r13: launches of >= ops.ROI_XCD_ORDER_MIN ROIs deal the ROIs to the XCDs by image neighbourhood (one extra single-workgroup launch,
-        # INSIDE the timed op below); the same launch in the ROIs' own order is reported as 'natural_order' (what r12 and earlier measured)
-        dealt = ops.ROI_XCD_ORDER and n >= ops.ROI_XCD_ORDER_MIN
-        row['roi_order'] = 'dealt per XCD (fpn_roi_order_kernel inside the timed op)' if dealt else 'natural'
-        passes = [(row, 'auto')] + ([(row.setdefault('natural_order', {}), None)] if dealt else [])
-        for row_, order_ in passes:
-            _roialign_times(ops, feats, rois, ps, scales, flush, n_iter, lambda tag, us, r=row_: put(tag, us, r), order_)
+        # r13: the same launch with the ROI -> XCD dealing table (csrc/roi_order.h; in the model prop_merge_kernel writes it for the box head's
+        # proposals, so the table is built BEFORE the timed launch here too) is reported as 'dealt'; the main figures stay the launch in the ROIs'
+        # own order (what r12 and earlier measured, and what a free-standing ROI set gets)
+        _roialign_times(ops, feats, rois, ps, scales, flush, n_iter, put, None)
+        if n >= ops.ROI_XCD_ORDER_MIN:
+            table = ops.fpn_roi_order(rois, (H, W))
+            drow = row.setdefault('dealt', {'what': 'workgroup b takes ROI order[b]: each XCD gets one contiguous range of the ROIs bucketed by (level, image stripe, column cell); table prebuilt'})
+            _roialign_times(ops, feats, rois, ps, scales, flush, n_iter, lambda tag, us, r=drow: put(tag, us, r), table)
         out.append(row)
     del flush, feats
     return out

@@ -532,6 +532,14 @@ int upsnet_pyramid_proposals_strided(void *stream, int nlev, const float *const 
                                      const int *strides_host, const float *anchors_host, int num_anchors, const float *im_info,
                                      int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float *rois_out,
                                      float *scores_out, int *num_out, void *workspace);
+/* r13: the same + roi_order_out (int[post_nms_top_n] or NULL): the workgroup -> ROI table of upsnet_fpn_roi_align_forward_ordered for these
+ * rois (see upsnet_fpn_roi_order), written by the launch that ranks them -- no launch of its own. post_nms_top_n <= 2048 when given. */
+int upsnet_pyramid_proposals_strided_ordered(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                     const long *cls_chan_stride, const long *cls_pix_stride, const long *box_chan_stride,
+                                     const long *box_pix_stride, const int *heights_host, const int *widths_host,
+                                     const int *strides_host, const float *anchors_host, int num_anchors, const float *im_info,
+                                     int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float *rois_out,
+                                     float *scores_out, int *num_out, void *workspace, int *roi_order_out);
 
 /* individual_proposals=False -- the DEFAULT of the reference's constructors (functions/pyramid_proposal.py:26,
  * modules/pyramid_proposal.py:24) -- i.e. the joint branch functions/pyramid_proposal.py:181-208: every anchor of every level is decoded,

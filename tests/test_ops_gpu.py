@@ -468,6 +468,37 @@ def test_pyramid_proposals_bitexact(U, H, W, pre, post):
     assert np.array_equal(rois.cpu().numpy(), ref_rois)
 
 
+def test_pyramid_proposals_write_the_roi_xcd_table_of_the_box_head(U):
+    """r13: prop_merge_kernel (the launch that ranks the proposals) also writes the workgroup -> ROI table of the box head's ROIAlign launch
+    (csrc/roi_order.h): a permutation of 0..post-1 with the rows beyond the kept count at its end, attached to the rois tensor; ops.fpn_roi_align
+    picks it up from that tensor ('auto') and returns the bits of the launch in ROI order. The proposals themselves are untouched (== oracle)."""
+    from upsnet_amd.operators.functions.pyramid_proposal import PyramidProposalFunction
+    H, W, pre, post = 512, 1024, 1000, 1000
+    rng = np.random.default_rng(11)
+    cls, box = _rpn_inputs(rng, H, W)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    ref_rois, ref_scores = oops.pyramid_proposal(cls, box, im_info[0], pre_nms_top_n=pre, post_nms_top_n=post, nms_thresh=0.7)
+    fn = PyramidProposalFunction((4, 8, 16, 32, 64), (8,), (0.5, 1, 2), pre, post, 0.7, 0, individual_proposals=True)
+    rois, scores, num = fn.forward_padded([cu(c) for c in cls], [cu(b) for b in box], cu(im_info[0]))
+    k = int(num.item())
+    assert np.array_equal(rois[:k].cpu().numpy(), ref_rois) and np.array_equal(scores[:k].cpu().numpy(), ref_scores)
+    order = getattr(rois, '_ups_roi_order', None)
+    assert order is not None and order.dtype == torch.int32 and order.numel() == post
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(post))
+    cnt = [(post - j + 7) // 8 for j in range(8)]
+    pos = np.empty(post, np.int64)
+    for b in range(post):
+        pos[o[b]] = sum(cnt[:b % 8]) + b // 8
+    assert k == post or (pos[k:].min() >= k and pos[:k].max() < k)
+    feats = [cu(rng.normal(size=(1, 32, H // s, W // s)).astype(np.float32)) for s in (4, 8, 16, 32)]
+    sc = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    a = U.fpn_roi_align(feats, rois, 7, 7, sc, num_rois_dev=num, order=None)
+    b = U.fpn_roi_align(feats, rois, 7, 7, sc, num_rois_dev=num)                 # 'auto': the attached table
+    assert torch.equal(a, b)
+    assert np.array_equal(a[:k].cpu().numpy(), oops.fpn_roi_align([f.cpu().numpy() for f in feats], ref_rois, 7, 7))
+
+
 @pytest.mark.parametrize("H,W,pre,post,thr,min_size", [(256, 512, 6000, 300, 0.7, 0), (64, 96, 1000, 300, 0.7, 4), (1024, 2048, 2000, 1000, 0.7, 16),
                                                        (32, 32, 50, 20, 0.5, 0), (96, 160, 300, 250, 0.3, 8)])
 def test_pyramid_proposals_joint_bitexact(U, H, W, pre, post, thr, min_size):

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "upsnet_soft_nms": (c_int, [P, P, P, c_int, c_float, c_float, c_float, c_int, P, P]),
     "upsnet_proposal_workspace_bytes": (c_size_t, [c_int, P, P, c_int, c_int, c_int]),
     "upsnet_pyramid_proposals_strided": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "upsnet_pyramid_proposals_strided_ordered": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P, P]),
     "upsnet_pyramid_proposals_joint_strided": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "upsnet_pyramid_proposals": (c_int, [P, c_int, P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "upsnet_mask_roi_capacity": (c_int, [c_int, c_int, c_int]),

@@ -16,6 +16,7 @@
 // batched NMS of nms.hip handles all levels at once; (5) prop_merge_kernel concatenates the kept boxes per level
 // and ranks them (score desc, concatenation index asc). 13 launches (r10: 21). No host synchronisation anywhere.
 #include "common.h"
+#include "roi_order.h"
 #include "sort.h"
 #include "upsnet_hip.h"
 
@@ -350,7 +351,8 @@ prop_sort_decode_kernel(const PropLevels lv, const PropSel *__restrict__ sel, co
 __global__ void __launch_bounds__(1024)
 prop_merge_kernel(const int nlev, const int pre_n, const int post_n, const float *__restrict__ boxes,
                   const float *__restrict__ scores, const int *__restrict__ keep_idx, const int *__restrict__ keep_cnt,
-                  float *__restrict__ rois_out, float *__restrict__ scores_out, int *__restrict__ num_out)
+                  float *__restrict__ rois_out, float *__restrict__ scores_out, int *__restrict__ num_out, int *__restrict__ roi_order,
+                  const float *__restrict__ im_info)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ups_u64 *keys = reinterpret_cast<ups_u64 *>(smem_raw);
@@ -399,6 +401,11 @@ prop_merge_kernel(const int nlev, const int pre_n, const int post_n, const float
         }
     }
     if (threadIdx.x == 0) *num_out = nout;
+    // r13: the ROI -> XCD dealing table of the box head's ROIAlign launch (roi_order.h), here because the ranked rois exist here: no launch of its own
+    if (roi_order != nullptr && post_n <= ROI_ORDER_MAX) {
+        __syncthreads();                     // rois_out complete and visible to the workgroup; the key buffer is free: its first ints become the counters
+        ups_roi_order_block(rois_out, post_n, nout, 16.0f / im_info[0], 8.0f / im_info[1], roi_order, reinterpret_cast<int *>(smem_raw));
+    }
 }
 
 
@@ -597,11 +604,28 @@ static int prop_sort_lds(int pre_n, int *M2_out)
     return 0;
 }
 
+extern "C" int upsnet_pyramid_proposals_strided_ordered(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                        const long *cls_cs, const long *cls_ps, const long *box_cs, const long *box_ps, const int *heights, const int *widths, const int *strides, const float *anchors,
+                                        int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
+                                        float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace, int *roi_order_out);
+
 extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
                                         const long *cls_cs, const long *cls_ps, const long *box_cs, const long *box_ps, const int *heights, const int *widths, const int *strides, const float *anchors,
                                         int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
                                         float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace)
 {
+    return upsnet_pyramid_proposals_strided_ordered(stream, nlev, cls_prob, bbox_pred, cls_cs, cls_ps, box_cs, box_ps, heights, widths, strides, anchors, num_anchors,
+                                                    im_info, pre_n, post_n, nms_thresh, min_size, rois_out, scores_out, num_out, workspace, nullptr);
+}
+
+/* upsnet_pyramid_proposals_strided + (r13) roi_order_out: int[post_n] or NULL -- the workgroup -> ROI table of upsnet_fpn_roi_align_forward_ordered for
+ * these rois (see upsnet_fpn_roi_order), written by the launch that ranks them; post_n <= 2048, else the table is not written (pass NULL). */
+extern "C" int upsnet_pyramid_proposals_strided_ordered(void *stream, int nlev, const float *const cls_prob[], const float *const bbox_pred[],
+                                        const long *cls_cs, const long *cls_ps, const long *box_cs, const long *box_ps, const int *heights, const int *widths, const int *strides, const float *anchors,
+                                        int num_anchors, const float *im_info, int pre_n, int post_n, float nms_thresh,
+                                        float min_size, float *rois_out, float *scores_out, int *num_out, void *workspace, int *roi_order_out)
+{
+    UPS_REQUIRE(roi_order_out == nullptr || post_n <= ROI_ORDER_MAX, "pyramid_proposals: the ROI order table needs post_nms_top_n <= %d", ROI_ORDER_MAX);
     UPS_REQUIRE(nlev >= 1 && nlev <= PROP_MAXLEV, "pyramid_proposals: nlev must be 1..%d", PROP_MAXLEV);
     UPS_REQUIRE(cls_prob && bbox_pred && heights && widths && strides && anchors && im_info && rois_out && scores_out &&
                     num_out && workspace, "pyramid_proposals: null pointer");
@@ -646,7 +670,7 @@ extern "C" int upsnet_pyramid_proposals_strided(void *stream, int nlev, const fl
     int rc = ups_nms_batched_presorted_impl(st, counts, pre_removed, nlev, pre_n, nms_thresh, keep_idx, keep_cnt, nms_ws, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(prop_merge_kernel, dim3(1), dim3(1024), (size_t)PROP_CH * 8, st, nlev, pre_n, post_n, boxes, scores,
-                       keep_idx, keep_cnt, rois_out, scores_out, num_out);
+                       keep_idx, keep_cnt, rois_out, scores_out, num_out, roi_order_out, im_info);
     UPS_CHECK_LAUNCH("prop_merge_kernel");
     return 0;
 }

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "roi_order.h"
 #include "upsnet_hip.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -195,15 +196,6 @@ extern "C" int upsnet_roi_align_forward(void *stream, const float *bottom_data, 
 
 // ---------------------------------------------------------------------------------------------
 // FPN level (fpn_roi_align.py:36-38): floor(2 + log2(sqrt(w*h)/224 + 1e-6)) clipped to [0,3], fp32.
-__device__ static inline int fpn_level_of(float x1, float y1, float x2, float y2)
-{
-    float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
-    float s = sqrtf(w * h) / 224.0f + 1e-6f;
-    float l = floorf(2.0f + ups_log2_f32(s));
-    l = fminf(fmaxf(l, 0.f), 3.f);
-    return (int)l;
-}
-
 struct FpnFeat {
     const float *ptr[4];
     int h[4], w[4];
@@ -702,66 +694,15 @@ static int roi_variant(const int bins)
 // ROIs -- 346 MB fetched at the fabric for a 178 MB pyramid on the 1000 x 7 x 7 launch (profiles/r11_roialign_pmc.txt), which is what
 // bounds the kernel. This kernel orders the ROIs by (pyramid level, image stripe of the centre, column cell) and deals the ordered
 // list so that XCD j's workgroups (b = j, j + 8, ...) take one contiguous range of it: neighbours in the image share an L2.
-// order[b] = ROI index workgroup b processes; the output rows are untouched (bit-identical results). One workgroup, <= 2048 ROIs.
-#define ROI_ORDER_MAX 2048
-#define ROI_ORDER_NB (4 * 16 * 8 + 1)     // (level, 16 image stripes, 8 column cells) + one bucket for the rows beyond the valid count
-// A counting sort, not a comparison sort (a 1024-key bitonic network in one workgroup takes ~20 us -- more than the dealing saves): bucket =
-// (pyramid level, stripe of the ROI centre, column cell), position = bucket base + arrival slot. The order INSIDE a bucket is the order in
-// which the LDS atomics of phase 1 are served -- it only decides which of two neighbouring workgroups takes which of two neighbouring ROIs.
+// order[b] = ROI index workgroup b processes; the output rows are untouched (bit-identical results). One workgroup, <= 2048 ROIs
+// (roi_order.h; the proposals' table is produced inside prop_merge_kernel, proposal.hip).
 __global__ void __launch_bounds__(1024)
 fpn_roi_order_kernel(const float *__restrict__ rois, const int num_rois, const int *__restrict__ num_rois_dev, const float inv_stripe_h,
                      const float inv_cell_w, int *__restrict__ order)
 {
-    __shared__ int cnt[ROI_ORDER_NB + 63];
+    __shared__ int cnt[ROI_ORDER_LDS];
     const int nvalid = num_rois_dev ? min(*num_rois_dev, num_rois) : num_rois;
-    for (int i = threadIdx.x; i < ROI_ORDER_NB + 63; i += blockDim.x) cnt[i] = 0;
-    __syncthreads();
-    int bkt[2], slot[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = threadIdx.x + q * 1024;
-        bkt[q] = -1;
-        if (i < num_rois) {
-            int b = ROI_ORDER_NB - 1;
-            if (i < nvalid) {
-                const float *r = rois + (long)i * 5;
-                const float x1 = r[1], y1 = r[2], x2 = r[3], y2 = r[4];
-                const int lvl = fpn_level_of(x1, y1, x2, y2);
-                const int st = min(max((int)((y1 + y2) * 0.5f * inv_stripe_h), 0), 15), cell = min(max((int)((x1 + x2) * 0.5f * inv_cell_w), 0), 7);
-                b = (lvl * 16 + st) * 8 + ((st & 1) ? 7 - cell : cell);     // (boustrophedon: consecutive buckets are neighbours in the image)
-            }
-            bkt[q] = b;
-            slot[q] = atomicAdd(&cnt[b], 1);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                  // exclusive scan of the bucket counts by one wave: 9 consecutive buckets per lane
-        constexpr int PER = (ROI_ORDER_NB + 63) / 64;
-        int loc[PER], sum = 0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) { loc[u] = cnt[threadIdx.x * PER + u]; sum += loc[u]; }
-        int incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += v; }
-        int run = incl - sum;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) { cnt[threadIdx.x * PER + u] = run; run += loc[u]; }
-    }
-    __syncthreads();
-    // XCD j owns workgroups j, j + 8, ...: n_j = ceil((N - j) / 8) of them; it takes sorted positions [start_j, start_j + n_j)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (bkt[q] < 0) continue;
-        const int k = cnt[bkt[q]] + slot[q];
-        int j = 0, start = 0;
-        bool found = false;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int nj = (num_rois - x + 7) >> 3;
-            if (!found) { if (k < start + nj) { j = x; found = true; } else start += nj; }
-        }
-        order[(k - start) * 8 + j] = threadIdx.x + q * 1024;
-    }
+    ups_roi_order_block(rois, num_rois, nvalid, inv_stripe_h, inv_cell_w, order, cnt);      // (roi_order.h)
 }
 
 /* order_out[b] = the ROI workgroup b of upsnet_fpn_roi_align_forward_ordered should take so that each XCD's workgroups cover one contiguous

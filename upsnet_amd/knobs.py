@@ -61,8 +61,9 @@ REGISTRY = {
     'UPSNET_PIN': ('1', 'upsnet_end2end_test.py', 'pin each rank to its CPU slice'),
     'UPSNET_ROI_KERNEL': ('auto', 'csrc/roi_align.hip', 'ROIAlign kernel variant 0..4; auto = 3 (corner-sharing) for >= 100 bins per ROI, else 0 -- so '
                                                         '"0" is NOT the default; upsnet_roi_tuning(v >= 0) overrides the variable, (v < 0) returns to it'),
-    'UPSNET_ROI_XCD_ORDER': ('1', 'ops.py', 'deal the ROIs of a ROIAlign launch to the XCDs by image neighbourhood (one extra tiny launch)'),
-    'UPSNET_ROI_XCD_ORDER_MIN': ('256', 'ops.py', 'only for launches with at least this many ROIs'),
+    'UPSNET_ROI_XCD_ORDER': ('1', 'ops.py', 'deal the ROIs of the box head\'s ROIAlign launch to the XCDs by image neighbourhood (table written by prop_merge_kernel)'),
+    'UPSNET_ROI_XCD_ORDER_MIN': ('512', 'ops.py', 'only for launches with at least this many ROIs'),
+    'UPSNET_ROI_XCD_ORDER_STANDALONE': ('0', 'ops.py', 'build the table with a launch of its own for ROI sets that do not come from pyramid_proposals'),
     'UPSNET_ROI_PER_BIN': ('0', 'csrc/roi_align.hip', 'one wave per (roi, bin) (older decomposition)'),
     'UPSNET_SHARE_GPU': ('0', 'upsnet_end2end_test.py', 'let N ranks share one GPU (functional runs of the N > 1 path)'),
     'UPSNET_SPLITK': ('1', 'models/hipconv.py', 'split-K forms for small maps'),

@@ -63,10 +63,13 @@ def roi_align_algorithmic_bytes(feats, n, C, ph, pw):
     return 4.0 * n * C * ph * pw + 20.0 * n + min(feat_bytes, 4.0 * n * C * (2 * ph + 1) * (2 * pw + 1))
 
 
-# r13: deal the ROIs to the XCDs by image neighbourhood (csrc/roi_align.hip, fpn_roi_order_kernel: one extra single-workgroup launch per call).
-# 'auto': for launches of >= ROI_XCD_ORDER_MIN ROIs. Results are bit-identical either way.
+# r13: deal the ROIs to the XCDs by image neighbourhood (csrc/roi_order.h). 'auto': launches of >= ROI_XCD_ORDER_MIN ROIs whose rois tensor carries
+# the table pyramid_proposals wrote for it (the box head's 1000 proposals). Results are bit-identical either way.
 ROI_XCD_ORDER = os.environ.get('UPSNET_ROI_XCD_ORDER', '1') != '0'
-ROI_XCD_ORDER_MIN = int(os.environ.get('UPSNET_ROI_XCD_ORDER_MIN', '256'))
+ROI_XCD_ORDER_MIN = int(os.environ.get('UPSNET_ROI_XCD_ORDER_MIN', '512'))
+# a ROI set that does not come with a table (not straight from pyramid_proposals) gets one from a launch of its own only if this is set: measured
+# (profiles/r13_bench.log, random ROIs) the extra launch costs what the dealing saves cold -- 1000 ROIs 63.6 vs 62.7 us, 300 ROIs 28.3 vs 25.2
+ROI_XCD_ORDER_STANDALONE = os.environ.get('UPSNET_ROI_XCD_ORDER_STANDALONE', '0') != '0'
 
 
 def fpn_roi_order(rois, image_hw, num_rois_dev=None):
@@ -100,9 +103,14 @@ def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio
     out = torch.empty((N, C, pooled_h, pooled_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     levels = torch.empty((max(N, 1),), dtype=torch.int32, device=dev) if return_levels else None
     if isinstance(order, str):
-        order = fpn_roi_order(rois, (int(round(feats[0].shape[2] / spatial_scale[0])), int(round(feats[0].shape[3] / spatial_scale[0]))),
-                              num_rois_dev) if (ROI_XCD_ORDER and sampling_ratio == 2 and ROI_XCD_ORDER_MIN <= N <= 2048 and
-                                                       max(pooled_h, pooled_w) <= 16) else None
+        given = getattr(rois, '_ups_roi_order', None)          # the proposals' own table (pyramid_proposals wrote it: no launch here)
+        eligible = ROI_XCD_ORDER and sampling_ratio == 2 and ROI_XCD_ORDER_MIN <= N <= 2048 and max(pooled_h, pooled_w) <= 32
+        if eligible and given is not None and given.numel() == N and given.device == rois.device:
+            order = given
+        elif eligible and ROI_XCD_ORDER_STANDALONE:
+            order = fpn_roi_order(rois, (int(round(feats[0].shape[2] / spatial_scale[0])), int(round(feats[0].shape[3] / spatial_scale[0]))), num_rois_dev)
+        else:
+            order = None
     if PROFILE['enabled']:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -484,12 +492,18 @@ def pyramid_proposals(cls_probs, bbox_preds, im_info, anchors, strides, pre_nms_
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     anc = float_array(np.asarray(anchors, np.float32).reshape(-1).tolist())
     long_array = lambda v: (_lib.c_long * len(v))(*[int(x) for x in v])
-    entry = lib().upsnet_pyramid_proposals_joint_strided if joint else lib().upsnet_pyramid_proposals_strided
-    check(entry(stream(), L, ptr_array(cls_probs), ptr_array(bbox_preds), long_array(cls_cs),
-                                                 long_array(cls_ps), long_array(box_cs), long_array(box_ps), hs, ws_,
-                                                 int_array(strides), anc, A, ptr(f32c(im_info)), int(pre_nms_top_n),
-                                         int(post_nms_top_n), float(nms_thresh), float(min_size), ptr(rois), ptr(scores),
-                                         ptr(num), ptr(ws)), "pyramid_proposals")
+    args = (stream(), L, ptr_array(cls_probs), ptr_array(bbox_preds), long_array(cls_cs), long_array(cls_ps), long_array(box_cs), long_array(box_ps),
+            hs, ws_, int_array(strides), anc, A, ptr(f32c(im_info)), int(pre_nms_top_n), int(post_nms_top_n), float(nms_thresh), float(min_size),
+            ptr(rois), ptr(scores), ptr(num), ptr(ws))
+    if joint:
+        check(lib().upsnet_pyramid_proposals_joint_strided(*args), "pyramid_proposals")
+    else:
+        # r13: the launch that ranks the proposals also writes the ROI -> XCD dealing table of the box head's ROIAlign launch (csrc/roi_order.h);
+        # it travels with the rois tensor (fpn_roi_align(order='auto') picks it up when it is handed this very tensor)
+        order = torch.empty((post_nms_top_n,), dtype=torch.int32, device=dev) if (ROI_XCD_ORDER and ROI_XCD_ORDER_MIN <= post_nms_top_n <= 2048) else None
+        check(lib().upsnet_pyramid_proposals_strided_ordered(*args, ptr(order)), "pyramid_proposals")
+        if order is not None:
+            rois._ups_roi_order = order
     return rois, scores, num
 
 
