@@ -284,14 +284,17 @@ DCN_SPLITK = os.environ.get('UPSNET_DCN_SPLITK', '1') != '0'
 
 
 def dcn_ksplit(outs, cin, cout, taps):
-    """Split-K factor of the fused deformable kernel for one small map: enough workgroups for ~2 per CU, >= 9 K steps each."""
+    """Split-K factor of the fused deformable kernel for one small map: enough workgroups for ~2 per CU (~3 for the smallest maps), >= 9 K steps each."""
     if not DCN_SPLITK or cout % 4:
         return 1
     o = outs[0]
     wgs = o.shape[0] * -(-o.shape[2] // 8) * -(-o.shape[3] // 8) * -(-cout // 128)
     nsl = cin // 32 * taps
+    # (r13) maps of <= 128 tiles (res5 of UPSNet-101-DCN: 96 at 800x1333, 128 at 1024x2048) split until ~3 workgroups per CU: 512 -> 512 on 25 x 42
+    # x4 86.8, x6 84.3, x8 68.6 us (tools/bench_c3_layers.py); larger maps are flat beyond 384 workgroups (256 -> 256 on 50 x 84: x3 64.0, x4 68.3, x6 64.0)
+    target = 768 if wgs <= 128 else 384
     ks = 1
-    while ks < 8 and wgs * ks < 384 and nsl // (ks + 1) >= 9:
+    while ks < 8 and wgs * ks < target and nsl // (ks + 1) >= 9:
         ks += 1
     while ks > 1 and -(-nsl // ks) * (ks - 1) >= nsl:
         ks -= 1
