@@ -101,7 +101,7 @@ def _check_model(preset, h, w, seed, need_forms, min_shapes, precision='fp32', w
         update_config_dict(CITYSCAPES_R50)
 
 
-_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd36', 'winograd36 multi', 'winograd tm32', 'winograd tm32 + tail tn32', 'winograd splitk', 'igemm', 'conv1x1 ksw',
+_C1_FORMS = ['stem', 'conv1x1', 'pair(conv3)', 'pair(conv1)', 'winograd36', 'winograd36 multi', 'winograd36 roi', 'winograd tm32', 'winograd splitk', 'igemm', 'conv1x1 ksw',
              'igemm multi cat', 'deconv2x2', 'dcn_fused multi']
 
 

@@ -53,8 +53,10 @@ WINO_TM64_MIN = int(os.environ.get('UPSNET_WINO_TM64_MIN', '768'))   # 64-tile W
 # (F(2x2): 4), 1.4-1.6x faster than F(2x2) there (tools/bench_winograd36.py), slower on small maps. Its rounding error is 3-4x that of
 # F(2x2) (tools/winograd_error_cpu.py: <= 0.08 of the layer tolerance tests/test_layerwise_gpu.py allows); UPSNET_WINO36=0 switches it off.
 WINO36 = os.environ.get('UPSNET_WINO36', '1') != '0'
-WINO36_ROI = os.environ.get('UPSNET_WINO36_ROI', '0') != '0'   # the mask head (pinned kernel choice) on the F(4x4) form as well: same-box A/B 167.6 vs
-# 169.3 img/s, serial 6.375 vs 6.389 ms -- inside the run-to-run spread, so the F(2x2) form with its half-size tail stays the default
+WINO36_ROI = os.environ.get('UPSNET_WINO36_ROI', '1') != '0'   # the mask head (pinned kernel choice, ROI batches of 14 x 14) on the F(4x4) form as well.
+# r12 measured ONE same-box pair (167.6 vs 169.3 img/s, "inside the spread") and left it off; r13, three interleaved pairs on one box: 168.26 /
+# 168.31 / 168.47 -> 169.86 / 170.05 / 169.55 img/s (+ 0.9 %, every pair), and the strict end-to-end margins of the mask tensors do not move
+# (mask_probs 0.036 / 0.064, pan_mask_logit 0.144 / 0.266 of the 1e-4 bound at 256x512 / 1024x2048; F(2x2): 0.035 / 0.065, 0.150 / 0.253): on.
 WINO36_MIN_FILL = float(os.environ.get('UPSNET_WINO36_MIN_FILL', '0.65'))
 # r13: split-K F(4x4) for single maps with fewer workgroups than CUs (csrc/conv_wino36.hip, conv_wino36_f32_kernel<true> + reduce). Built and
 # measured (tools/bench_winograd36_splitk.py, 1024x2048): res3 conv2 54.8 -> 50.2 us (x2), res4 conv2 / FPN P4 48.2 -> 45.0 (x4), res5 conv2 and
