@@ -215,6 +215,12 @@ def test_winograd_f4x4_routing_rule(monkeypatch):
     assert not use(nn.Conv2d(48, 64, 3, padding=1), [x(1, 256, 512, 48)])                  # Cin % 32
     assert not use(c3, [x(1, 256, 512, dt=torch.bfloat16)])
     assert not use(nn.Conv2d(256, 256, 3, stride=2, padding=1), [x(1, 256, 512)]) and not use(nn.Conv2d(256, 256, 1), [x(1, 256, 512)])
+    # r13 (opt-in, UPSNET_WINO36_PREFIX): a multi-map launch whose last round of workgroups is less than half full keeps only the leading maps that make whole rounds
+    monkeypatch.setattr(hipconv, 'WINO36_PREFIX', True)
+    pre = hipconv._wino36_round_prefix
+    assert pre(c3, [x(1, 256 >> l, 512 >> l) for l in range(5)]) == 2       # RPN at 1024x2048: 1024 + 256 = 5 rounds | 64 + 16 + 4 would be a third of a sixth
+    assert pre(c3, [x(1, 200, 336), x(1, 100, 168), x(1, 50, 84), x(1, 25, 42), x(1, 13, 21)]) == 5      # 712 workgroups: last round 0.78 full
+    assert pre(c3, [x(1, 256, 512)]) == 1 and pre(c3, [x(1, 64 >> l, 128 >> l) for l in range(5)]) == 5  # (no prefix makes a whole round: nothing to cut)
     monkeypatch.setattr(hipconv, 'WINO36', False)
     assert not use(c3, [x(1, 256, 512)])
 

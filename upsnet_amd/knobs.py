@@ -70,6 +70,7 @@ REGISTRY = {
     'UPSNET_STEM_POOL': ('1', 'models/hipconv.py', 'fused stem + pool kernel (0: stem kernel + library pool)'),
     'UPSNET_WINO36': ('1', 'models/hipconv.py', 'largest 3x3 / stride 1 layers on the Winograd F(4x4,3x3) kernel'),
     'UPSNET_WINO36_SPLITK': ('0', 'models/hipconv.py', 'res3 / res4 conv2 and FPN P4 on the split-K F(4x4) form (3-5 us per launch; more rounding error)'),
+    'UPSNET_WINO36_PREFIX': ('0', 'models/hipconv.py', 'multi-map F(4x4) launches keep only the leading maps that fill whole rounds of workgroups (measured: no gain)'),
     'UPSNET_WINO36_ROI': ('1', 'models/hipconv.py', 'mask head (ROI batches) on the Winograd F(4x4,3x3) kernel (0: F(2x2) with the half-size tail)'),
     'UPSNET_WINO36_MIN_FILL': ('0.65', 'models/hipconv.py', 'F(4x4,3x3) only if its last round of workgroups is at least this full'),
     'UPSNET_WINOGRAD': ('1', 'models/hipconv.py', '3x3 / stride 1 layers on the Winograd kernel'),

@@ -523,6 +523,31 @@ def _use_winograd36(m, xs):
     return wgs >= cus and wgs >= WINO36_MIN_FILL * (-(-wgs // cus)) * cus
 
 
+# (r13, measured and left OFF: the five-level RPN launch at 1024x2048 is 1364 workgroups = 5.33 rounds; cutting it into P2 + P3 on F(4x4) (5 whole
+# rounds) and P4-P6 on the F(2x2) multi-map launch -- three interleaved same-box pairs 171.09 / 171.05 / 171.13 img/s without, 170.77 / 170.67 /
+# 170.43 with, serial 6.33 vs 6.35 ms: the third-full last round costs less than a launch of its own)
+WINO36_PREFIX = os.environ.get('UPSNET_WINO36_PREFIX', '0') != '0'
+
+
+def _wino36_round_prefix(m, xs):
+    """How many leading maps of a multi-map F(4x4) launch to keep in it: all of them, unless the launch's last round of workgroups is less than
+    half full AND a prefix of the maps makes whole rounds (last round >= 0.95 full) -- then that prefix. Shape-only."""
+    n = len(xs)
+    if not WINO36_PREFIX or n < 2:
+        return n
+    cus = _cus(xs[0].device)
+    per = [-(-(x.shape[0] * ((x.shape[2] + 3) // 4) * ((x.shape[3] + 3) // 4)) // 32) * (m.out_channels // 64) for x in xs]
+    fill = lambda w: w / float(-(-w // cus) * cus)
+    last = sum(per) % cus
+    if last == 0 or last >= cus // 2:
+        return n
+    for k in range(n - 1, 0, -1):
+        w = sum(per[:k])
+        if w >= cus and fill(w) >= 0.95:
+            return k
+    return n
+
+
 def _wino36_ksplit(m, x):
     """Split factor of the opt-in split-K F(4x4) form for one map: the split that brings the launch to one workgroup per CU, >= 4 slabs of 16
     channels each; 1 = not this form (enough workgroups for the unsplit form, or fewer than cus / 8: res5 / P5, where F(2x2) split-K wins)."""
@@ -681,6 +706,15 @@ def conv_multi(m, xs, relu=False):
             ys, form = ops.conv2d_nhwc_bf16_multi(xs, hi, lo, ldw, m.bias, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], relu=relu), _bf16_form()
         elif _use_winograd36(m, xs):
             wp, ldw = _winograd36_plan(m)
+            k = _wino36_round_prefix(m, xs)
+            if k < len(xs):
+                # (r13) the leading maps fill whole rounds of F(4x4) workgroups; the small trailing maps would be a last round that is mostly empty
+                # (the five-level RPN launch at 1024x2048: 1024 + 256 | + 64 + 16 + 4 workgroups = 5 rounds | + a third of a sixth): they go where
+                # maps of their size go anyway (the F(2x2) multi-map launch)
+                ys = ops.conv2d_winograd36_multi(xs[:k], wp, ldw, m.bias, m.out_channels, relu=relu)
+                for x, y in zip(xs[:k], ys):
+                    _trace('conv', module=m, x=x, out=y, relu=relu, residual=None, residual_up=False, form='winograd36 multi')
+                return ys + conv_multi(m, xs[k:], relu=relu)
             ys, form = ops.conv2d_winograd36_multi(xs, wp, ldw, m.bias, m.out_channels, relu=relu), 'winograd36 multi'
         elif _use_winograd(m, xs):
             wp, ldw = _winograd_plan(m)
