@@ -111,6 +111,10 @@ def fpn_roi_align(feats, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio
             order = fpn_roi_order(rois, (int(round(feats[0].shape[2] / spatial_scale[0])), int(round(feats[0].shape[3] / spatial_scale[0]))), num_rois_dev)
         else:
             order = None
+    elif order is not None:
+        # (the kernel trusts the table: a table that is not a permutation of 0..N-1 would leave output rows unwritten)
+        if not (isinstance(order, torch.Tensor) and order.dtype == torch.int32 and order.numel() == N and order.device == rois.device and order.is_contiguous()):
+            raise RuntimeError("fpn_roi_align: order must be a contiguous int32 tensor of %d entries on %s (from fpn_roi_order / pyramid_proposals)" % (N, rois.device))
     if PROFILE['enabled']:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
